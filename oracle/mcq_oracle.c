@@ -1,0 +1,425 @@
+/*
+ * mcq_oracle.c -- CPU restatement of the reference's index search and decode.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under quantization_amd/ may import, link or
+ * call this file; it is the checker for tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py.  The product path is the HIP library
+ * (quantization_amd/csrc) and fails loudly without it.
+ *
+ * What it restates (file:line are relative to /root/reference):
+ *   Quantizer.get_centers        quantization/quantization.py:77-79
+ *   Quantizer._logits            quantization/quantization.py:277-279
+ *   Quantizer._compute_indexes   quantization/quantization.py:281-305
+ *   Quantizer._refine_indexes    quantization/quantization.py:308-547
+ *   Quantizer.decode             quantization/quantization.py:117-148
+ *
+ * Pinning: the reference's own tests hold no golden vectors for this path
+ * (SURVEY.md section 4); the oracle is pinned by tests/golden/ fixtures captured
+ * by importing the reference in the build container (tests/golden/make_golden.py).
+ * The reference's arithmetic is torch/MKL fp32 whose summation order is not
+ * specified, so agreement with the fixtures is "identical codes wherever the
+ * fp64 decision margin is not a near-tie" (tests/test_oracle_golden.py).
+ *
+ * Numeric specification (this IS the spec the HIP kernels match bit-for-bit):
+ *   Dp      = D rounded up to a multiple of 16, zero padded.
+ *   dot16   = one fp32 fmaf chain, accumulator starting at +0, over k in the
+ *             order  for blk: for i in 0..3: for g in 0..3: k = 16*blk + 4*g + i
+ *             (the order a v_mfma_f32_16x16x4_f32 chain consumes k when lane
+ *             (r, g) holds the float4 at 16*blk + 4*g).
+ *   sumsq64 = 64 partial fmaf chains, partial l over the float4 groups q with
+ *             (q mod 64) == l in increasing q, then the xor butterfly
+ *             p[l] += p[l^m] for m = 32,16,8,4,2,1 (a wave64 reduction).
+ *   every other operation is a single IEEE fp32 add/sub/mul, in the order the
+ *   reference writes it:  S = (R + Q) + 2X   (:418),
+ *   S' = ((Se + So) - E) + 2*dot   (:533-535),  delta = c - old  (:436-439),
+ *   delta' = delta_e + delta_o (:538-541), x_err = (old_0 + old_1 + ...) - x.
+ *   selections are by (value, position) ascending, lowest position on ties.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef struct {
+    int N, K, D, Dp;
+    float *C;      /* [N][K][Dp]   scaled centers, zero padded            */
+    float *CT;     /* [N][Dp][K]   row i = column order16[i] of C[n]      */
+    float *Q;      /* [N][K]       sumsq64 of each scaled center          */
+    float *WT;     /* [Dp][N*K]    to_logits.weight, chain order, padded  */
+    float *bias;   /* [N*K]                                               */
+    float lscale;  /* exp(10*logits_scale), computed by the caller        */
+    int *order16;  /* [Dp]                                                */
+} mcq_oracle;
+
+static int round_up16(int d) { return (d + 15) & ~15; }
+
+int mcq_oracle_dp(int D) { return round_up16(D); }
+
+static float sumsq64(const float *v, int Dp) {
+    float p[64], t[64];
+    for (int l = 0; l < 64; l++) p[l] = 0.0f;
+    for (int q = 0; q < Dp / 4; q++) {
+        int l = q & 63;
+        for (int c = 0; c < 4; c++) p[l] = fmaf(v[4 * q + c], v[4 * q + c], p[l]);
+    }
+    for (int m = 32; m >= 1; m >>= 1) {
+        for (int l = 0; l < 64; l++) t[l] = p[l] + p[l ^ m];
+        memcpy(p, t, sizeof(p));
+    }
+    return p[0];
+}
+
+mcq_oracle *mcq_oracle_create(const float *centers, float cscale_exp, const float *W,
+                              const float *bias, float lscale_exp, int N, int K, int D) {
+    mcq_oracle *o = (mcq_oracle *)calloc(1, sizeof(mcq_oracle));
+    int Dp = round_up16(D);
+    o->N = N; o->K = K; o->D = D; o->Dp = Dp; o->lscale = lscale_exp;
+    o->order16 = (int *)malloc(sizeof(int) * Dp);
+    for (int i = 0; i < Dp; i++) {
+        int blk = i / 16, w = i % 16;
+        o->order16[i] = 16 * blk + 4 * (w % 4) + (w / 4);
+    }
+    size_t nk = (size_t)N * K;
+    o->C = (float *)calloc(nk * Dp, sizeof(float));
+    o->CT = (float *)calloc(nk * Dp, sizeof(float));
+    o->Q = (float *)calloc(nk, sizeof(float));
+    /* get_centers(): exp(centers_scale * 10) * centers   (:77-79) */
+    for (size_t r = 0; r < nk; r++)
+        for (int d = 0; d < D; d++) o->C[r * Dp + d] = cscale_exp * centers[r * D + d];
+    for (size_t r = 0; r < nk; r++) o->Q[r] = sumsq64(o->C + r * Dp, Dp);  /* (:411) */
+    for (int n = 0; n < N; n++)
+        for (int i = 0; i < Dp; i++)
+            for (int k = 0; k < K; k++)
+                o->CT[((size_t)n * Dp + i) * K + k] = o->C[((size_t)n * K + k) * Dp + o->order16[i]];
+    if (W) {
+        o->WT = (float *)calloc(nk * Dp, sizeof(float));
+        o->bias = (float *)malloc(nk * sizeof(float));
+        memcpy(o->bias, bias, nk * sizeof(float));
+        for (int i = 0; i < Dp; i++) {
+            int d = o->order16[i];
+            if (d >= D) continue;
+            for (size_t r = 0; r < nk; r++) o->WT[(size_t)i * nk + r] = W[r * D + d];
+        }
+    }
+    return o;
+}
+
+void mcq_oracle_free(mcq_oracle *o) {
+    if (!o) return;
+    free(o->C); free(o->CT); free(o->Q); free(o->WT); free(o->bias); free(o->order16); free(o);
+}
+
+/* copy of the scaled centers (N,K,D) and their sumsq, for tests */
+void mcq_oracle_get_centers(const mcq_oracle *o, float *out_C, float *out_Q) {
+    size_t nk = (size_t)o->N * o->K;
+    if (out_C)
+        for (size_t r = 0; r < nk; r++) memcpy(out_C + r * o->D, o->C + r * o->Dp, sizeof(float) * o->D);
+    if (out_Q) memcpy(out_Q, o->Q, nk * sizeof(float));
+}
+
+/* K_cutoff rule (:453-463) */
+static int k_cutoff(int K, int L) {
+    int kc = (K <= 16) ? 8 : 16;
+    while (L >= 4) { L /= 4; kc *= 2; }
+    return kc < 128 ? kc : 128;
+}
+
+static int key_less(float v1, int p1, float v2, int p2) {
+    return (v1 < v2) || (v1 == v2 && p1 < p2);
+}
+
+/* the `cnt` smallest of S[0..M) by (value, position), ascending.  Repeated
+ * "smallest key greater than the previous one"; mirrors the wave-level
+ * extraction of the HIP kernels, including what happens to non-finite keys. */
+static void select_smallest(const float *S, int M, int cnt, int *pos_out, float *val_out) {
+    float pv = -INFINITY; int pp = -1;
+    for (int j = 0; j < cnt; j++) {
+        float bv = INFINITY; int bp = M;
+        for (int p = 0; p < M; p++) {
+            float v = S[p];
+            if (key_less(pv, pp, v, p) && key_less(v, p, bv, bp)) { bv = v; bp = p; }
+        }
+        if (bp >= M) bp = M - 1;  /* only reachable with NaN keys */
+        pos_out[j] = bp; val_out[j] = bv; pv = bv; pp = bp;
+    }
+}
+
+typedef struct {
+    /* optional per-vector trace for localising a divergence (one vector) */
+    float *xerr;    /* [Dp]   */
+    float *E;       /* [1]    */
+    float *R;       /* [N]    */
+    float *S0;      /* [N][K] */
+    int *sel_pos;   /* concatenated over prunes: groups*newK positions */
+    float *sel_val; /* same layout                                     */
+    float *comb;    /* concatenated over combines: groups*Kc*Kc scores */
+} mcq_trace;
+
+typedef struct {
+    float *old;    /* [N][Dp] */
+    float *xerr;   /* [Dp] */
+    float *xrem;   /* [Dp] */
+    float *S;      /* [N*K] or combine scores, max size */
+    float *S2;
+    float *dA;     /* delta buffers [groups][Dp][Kc] (transposed, chain order) */
+    float *dB;
+    uint8_t *tA;   /* tuples [groups][Kc][L] */
+    uint8_t *tB;
+    float *sA;     /* candidate scores [groups][Kc] */
+    float *sB;
+    int *pos;
+    size_t maxS;
+} scratch;
+
+static size_t max_sz(size_t a, size_t b) { return a > b ? a : b; }
+
+static void scratch_alloc(scratch *s, int N, int K, int Dp) {
+    /* largest candidate count per group after any prune, and largest combine */
+    size_t max_group_c = 0, maxS = (size_t)N * K;
+    int Ng = N, L = 1;
+    int kc = (N == 1) ? 1 : k_cutoff(K, L);
+    max_group_c = (size_t)Ng * kc;
+    while (Ng > 1) {
+        maxS = max_sz(maxS, (size_t)(Ng / 2) * kc * kc);
+        Ng /= 2; L *= 2;
+        kc = (Ng == 1) ? 1 : k_cutoff(K, L);
+        max_group_c = max_sz(max_group_c, (size_t)Ng * kc);
+    }
+    s->maxS = maxS;
+    s->old = (float *)malloc(sizeof(float) * N * Dp);
+    s->xerr = (float *)malloc(sizeof(float) * Dp);
+    s->xrem = (float *)malloc(sizeof(float) * Dp);
+    s->S = (float *)malloc(sizeof(float) * maxS);
+    s->S2 = (float *)malloc(sizeof(float) * maxS);
+    s->dA = (float *)malloc(sizeof(float) * max_group_c * Dp);
+    s->dB = (float *)malloc(sizeof(float) * max_group_c * Dp);
+    s->tA = (uint8_t *)malloc(max_group_c * N);
+    s->tB = (uint8_t *)malloc(max_group_c * N);
+    s->sA = (float *)malloc(sizeof(float) * max_group_c);
+    s->sB = (float *)malloc(sizeof(float) * max_group_c);
+    s->pos = (int *)malloc(sizeof(int) * max_group_c);
+}
+
+static void scratch_free(scratch *s) {
+    free(s->old); free(s->xerr); free(s->xrem); free(s->S); free(s->S2); free(s->dA); free(s->dB);
+    free(s->tA); free(s->tB); free(s->sA); free(s->sB); free(s->pos);
+}
+
+/* A.1: initial indexes from the logits (:297-301) */
+static void init_indexes(const mcq_oracle *o, const float *x, uint8_t *idx, float *acc /*[N*K]*/,
+                         float *sx /*[Dp]*/) {
+    int N = o->N, K = o->K, D = o->D, Dp = o->Dp;
+    size_t nk = (size_t)N * K;
+    for (int d = 0; d < Dp; d++) sx[d] = (d < D) ? o->lscale * x[d] : 0.0f;  /* (:278) */
+    for (size_t r = 0; r < nk; r++) acc[r] = 0.0f;
+    for (int i = 0; i < Dp; i++) {
+        float xv = sx[o->order16[i]];
+        const float *row = o->WT + (size_t)i * nk;
+        for (size_t r = 0; r < nk; r++) acc[r] = fmaf(row[r], xv, acc[r]);
+    }
+    for (int n = 0; n < N; n++) {
+        int best = 0; float bv = acc[(size_t)n * K] + o->bias[(size_t)n * K];
+        for (int k = 1; k < K; k++) {
+            float v = acc[(size_t)n * K + k] + o->bias[(size_t)n * K + k];
+            if (v > bv) { bv = v; best = k; }
+        }
+        idx[n] = (uint8_t)best;
+    }
+}
+
+/* A.2: one _refine_indexes pass for one vector (:308-547); idx updated in place */
+static void refine_one(const mcq_oracle *o, const float *x, uint8_t *idx, scratch *s, mcq_trace *tr) {
+    const int N = o->N, K = o->K, D = o->D, Dp = o->Dp;
+    /* old centers, x_err, E  (:338-340, :401) */
+    for (int n = 0; n < N; n++)
+        memcpy(s->old + (size_t)n * Dp, o->C + ((size_t)n * K + idx[n]) * Dp, sizeof(float) * Dp);
+    for (int d = 0; d < Dp; d++) {
+        float t = s->old[d];
+        for (int n = 1; n < N; n++) t = t + s->old[(size_t)n * Dp + d];
+        s->xerr[d] = t - ((d < D) ? x[d] : 0.0f);
+    }
+    const float E = sumsq64(s->xerr, Dp);
+    if (tr && tr->xerr) memcpy(tr->xerr, s->xerr, sizeof(float) * Dp);
+    if (tr && tr->E) tr->E[0] = E;
+
+    /* stage 0 scores S[n][k] = (R + Q) + 2 X   (:403-418) */
+    for (int n = 0; n < N; n++) {
+        const float *old = s->old + (size_t)n * Dp;
+        for (int d = 0; d < Dp; d++) s->xrem[d] = s->xerr[d] - old[d];
+        const float R = sumsq64(s->xrem, Dp);
+        if (tr && tr->R) tr->R[n] = R;
+        float *acc = s->S + (size_t)n * K;
+        for (int k = 0; k < K; k++) acc[k] = 0.0f;
+        for (int i = 0; i < Dp; i++) {
+            float xv = s->xrem[o->order16[i]];
+            const float *row = o->CT + ((size_t)n * Dp + i) * K;
+            for (int k = 0; k < K; k++) acc[k] = fmaf(row[k], xv, acc[k]);
+        }
+        const float *Q = o->Q + (size_t)n * K;
+        for (int k = 0; k < K; k++) acc[k] = (R + Q[k]) + 2.0f * acc[k];
+    }
+    if (tr && tr->S0) memcpy(tr->S0, s->S, sizeof(float) * N * K);
+
+    int Ng = N, Kg = K, L = 1;
+    int tr_sel = 0, tr_comb = 0;
+    /* first prune: K -> Kc (or 1 if N == 1); deltas = c - old (:436-439, :470-503) */
+    int kc = (Ng == 1) ? 1 : k_cutoff(K, L);
+    float *dcur = s->dA, *dnext = s->dB;
+    uint8_t *tcur = s->tA, *tnext = s->tB;
+    float *scur = s->sA, *snext = s->sB;
+    for (int n = 0; n < N; n++) {
+        select_smallest(s->S + (size_t)n * K, K, kc, s->pos, scur + (size_t)n * kc);
+        const float *old = s->old + (size_t)n * Dp;
+        float *dg = dcur + (size_t)n * kc * Dp;
+        for (int j = 0; j < kc; j++) {
+            int k = s->pos[j];
+            tcur[((size_t)n * kc + j)] = (uint8_t)k;
+            const float *c = o->C + ((size_t)n * K + k) * Dp;
+            for (int i = 0; i < Dp; i++) {
+                int d = o->order16[i];
+                dg[(size_t)i * kc + j] = c[d] - old[d];
+            }
+            if (tr && tr->sel_pos) { tr->sel_pos[tr_sel] = k; tr->sel_val[tr_sel] = scur[(size_t)n * kc + j]; tr_sel++; }
+        }
+    }
+    Kg = kc;
+    while (Ng > 1) {
+        /* combine pairs of groups (:504-547) */
+        int newN = Ng / 2, M = Kg * Kg, newL = 2 * L;
+        for (int g = 0; g < newN; g++) {
+            const float *de = dcur + (size_t)(2 * g) * Kg * Dp;
+            const float *dod = dcur + (size_t)(2 * g + 1) * Kg * Dp;
+            float *acc = s->S + (size_t)g * M;
+            for (int p = 0; p < M; p++) acc[p] = 0.0f;
+            for (int i = 0; i < Dp; i++) {
+                const float *ea = de + (size_t)i * Kg, *ob = dod + (size_t)i * Kg;
+                for (int a = 0; a < Kg; a++) {
+                    float av = ea[a];
+                    float *row = acc + (size_t)a * Kg;
+                    for (int b = 0; b < Kg; b++) row[b] = fmaf(av, ob[b], row[b]);
+                }
+            }
+            const float *se = scur + (size_t)(2 * g) * Kg, *so = scur + (size_t)(2 * g + 1) * Kg;
+            for (int a = 0; a < Kg; a++)
+                for (int b = 0; b < Kg; b++) {
+                    float *v = acc + (size_t)a * Kg + b;
+                    *v = ((se[a] + so[b]) - E) + 2.0f * (*v);  /* (:533-535) */
+                }
+            if (tr && tr->comb) { memcpy(tr->comb + tr_comb, acc, sizeof(float) * M); tr_comb += M; }
+        }
+        /* prune to the next cutoff (or to 1 when one group is left) (:470-503) */
+        int newK = (newN == 1) ? 1 : k_cutoff(K, newL);
+        for (int g = 0; g < newN; g++) {
+            select_smallest(s->S + (size_t)g * M, M, newK, s->pos, snext + (size_t)g * newK);
+            const float *de = dcur + (size_t)(2 * g) * Kg * Dp;
+            const float *dod = dcur + (size_t)(2 * g + 1) * Kg * Dp;
+            float *dn = dnext + (size_t)g * newK * Dp;
+            for (int j = 0; j < newK; j++) {
+                int a = s->pos[j] / Kg, b = s->pos[j] % Kg;
+                uint8_t *tn = tnext + ((size_t)g * newK + j) * newL;
+                memcpy(tn, tcur + ((size_t)(2 * g) * Kg + a) * L, L);
+                memcpy(tn + L, tcur + ((size_t)(2 * g + 1) * Kg + b) * L, L);
+                if (newN > 1)
+                    for (int i = 0; i < Dp; i++)  /* (:538-541) */
+                        dn[(size_t)i * newK + j] = de[(size_t)i * Kg + a] + dod[(size_t)i * Kg + b];
+                if (tr && tr->sel_pos) { tr->sel_pos[tr_sel] = s->pos[j]; tr->sel_val[tr_sel] = snext[(size_t)g * newK + j]; tr_sel++; }
+            }
+        }
+        float *tf = dcur; dcur = dnext; dnext = tf;
+        uint8_t *tt = tcur; tcur = tnext; tnext = tt;
+        float *ts = scur; scur = snext; snext = ts;
+        Ng = newN; Kg = newK; L = newL;
+    }
+    /* Ng == 1, Kg == 1: the tuple is the new index vector (:468-469) */
+    memcpy(idx, tcur, N);
+}
+
+/* _compute_indexes for a batch (:281-305).  idx: uint8 [B][N]. */
+int mcq_oracle_compute_indexes(const mcq_oracle *o, const float *x, long B, int iters, uint8_t *idx,
+                               int nthreads) {
+    if (!o->WT) return -1;
+    const int N = o->N, K = o->K, D = o->D, Dp = o->Dp;
+    if (K < 16 || K > 256) return -2;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#else
+    (void)nthreads;
+#endif
+#pragma omp parallel
+    {
+        scratch s; scratch_alloc(&s, N, K, Dp);
+        float *acc = (float *)malloc(sizeof(float) * N * K);
+        float *sx = (float *)malloc(sizeof(float) * Dp);
+#pragma omp for schedule(dynamic, 8)
+        for (long b = 0; b < B; b++) {
+            uint8_t *id = idx + (size_t)b * N;
+            init_indexes(o, x + (size_t)b * D, id, acc, sx);
+            for (int it = 0; it < iters; it++) refine_one(o, x + (size_t)b * D, id, &s, NULL);
+        }
+        free(acc); free(sx); scratch_free(&s);
+    }
+    return 0;
+}
+
+/* one refinement pass from given indexes, with the per-stage trace (one vector) */
+int mcq_oracle_refine_trace(const mcq_oracle *o, const float *x, uint8_t *idx, float *xerr, float *E,
+                            float *R, float *S0, int *sel_pos, float *sel_val, float *comb) {
+    scratch s; scratch_alloc(&s, o->N, o->K, o->Dp);
+    mcq_trace tr = {xerr, E, R, S0, sel_pos, sel_val, comb};
+    refine_one(o, x, idx, &s, &tr);
+    scratch_free(&s);
+    return 0;
+}
+
+/* initial argmax only (iters == 0 path), exposing the logits for tests */
+int mcq_oracle_logits(const mcq_oracle *o, const float *x, long B, float *logits) {
+    if (!o->WT) return -1;
+    size_t nk = (size_t)o->N * o->K;
+    float *sx = (float *)malloc(sizeof(float) * o->Dp);
+    for (long b = 0; b < B; b++) {
+        float *acc = logits + (size_t)b * nk;
+        for (int d = 0; d < o->Dp; d++) sx[d] = (d < o->D) ? o->lscale * x[(size_t)b * o->D + d] : 0.0f;
+        for (size_t r = 0; r < nk; r++) acc[r] = 0.0f;
+        for (int i = 0; i < o->Dp; i++) {
+            float xv = sx[o->order16[i]];
+            const float *row = o->WT + (size_t)i * nk;
+            for (size_t r = 0; r < nk; r++) acc[r] = fmaf(row[r], xv, acc[r]);
+        }
+        for (size_t r = 0; r < nk; r++) acc[r] = acc[r] + o->bias[r];
+    }
+    free(sx);
+    return 0;
+}
+
+/* decode (:131-148): out[b,:] = sum_n C[n, idx[b,n], :], n ascending */
+void mcq_oracle_decode(const mcq_oracle *o, const uint8_t *idx, long B, float *out) {
+    const int N = o->N, K = o->K, D = o->D, Dp = o->Dp;
+#pragma omp parallel for schedule(static)
+    for (long b = 0; b < B; b++) {
+        const uint8_t *id = idx + (size_t)b * N;
+        float *ob = out + (size_t)b * D;
+        const float *c0 = o->C + ((size_t)0 * K + id[0]) * Dp;
+        for (int d = 0; d < D; d++) ob[d] = c0[d];
+        for (int n = 1; n < N; n++) {
+            const float *c = o->C + ((size_t)n * K + id[n]) * Dp;
+            for (int d = 0; d < D; d++) ob[d] = ob[d] + c[d];
+        }
+    }
+}
+
+/* the stage ladder, for tests: writes (Kin, Kout) per combine stage, returns count */
+int mcq_oracle_ladder(int N, int K, int *first_keep, int *kin, int *kout) {
+    int Ng = N, L = 1, n = 0;
+    int kc = (Ng == 1) ? 1 : k_cutoff(K, L);
+    *first_keep = kc;
+    while (Ng > 1) {
+        int newN = Ng / 2; L *= 2;
+        int nk = (newN == 1) ? 1 : k_cutoff(K, L);
+        kin[n] = kc; kout[n] = nk; n++;
+        kc = nk; Ng = newN;
+    }
+    return n;
+}

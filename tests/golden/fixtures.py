@@ -1,0 +1,48 @@
+"""Loads a golden fixture (see make_golden.py) and regenerates its inputs."""
+import glob
+import os
+
+import numpy as np
+
+from . import gen
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+# a vector whose fp64 decision margin is below this is a near-tie: the reference's
+# own codes for it depend on fp32 summation order
+NEAR_TIE = 2e-6
+
+
+def names(prefix=""):
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(HERE, prefix + "*.npz")))
+
+
+def load(name):
+    z = np.load(os.path.join(HERE, name + ".npz"))
+    fx = {k: z[k] for k in z.files}
+    D, K, N, B = int(fx["D"]), int(fx["K"]), int(fx["N"]), int(fx["B"])
+    if "state.centers" in fx:
+        state = {k[len("state."):]: fx[k] for k in fx if k.startswith("state.")}
+    else:
+        state = gen.synthetic_state(int(fx["state_seed"]), D, K, N)
+        assert gen.checksum(state["centers"]) == float(fx["centers_checksum"]), "regenerated state differs"
+    kind = str(fx["x_kind"])
+    x = gen.make_gaussian(int(fx["x_seed"]), B, D) if kind == "gaussian" else gen.make_x(int(fx["x_seed"]), B, D)
+    assert gen.checksum(x) == float(fx["x_checksum"]), "regenerated input differs from the fixture's"
+    fx.update(D=D, K=K, N=N, B=B, state=state, x=x)
+    fx["iters"] = sorted(int(k[len("codes_it"):]) for k in fx if k.startswith("codes_it"))
+    return fx
+
+
+def check_codes(fx, it, codes, what):
+    """codes must equal the reference's wherever the decision margin is not a near-tie"""
+    ref = fx[f"codes_it{it}"]
+    margin = fx[f"margin_it{it}"]
+    codes = np.asarray(codes).reshape(ref.shape)
+    bad = (codes != ref).any(axis=1)
+    hard = bad & (margin >= NEAR_TIE)
+    assert not hard.any(), (f"{what}: {int(hard.sum())} vectors differ from the reference with a clear margin, "
+                            f"first at {np.flatnonzero(hard)[:5]}")
+    # near-tie differences must stay rare, or the comparison means nothing
+    assert bad.sum() <= max(2, 0.005 * len(ref)), f"{what}: {int(bad.sum())} near-tie differences of {len(ref)}"
+    return int(bad.sum())
