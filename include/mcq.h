@@ -1,0 +1,102 @@
+/*
+ * mcq.h -- C ABI of libmcq_hip.so: the MI355X (gfx950) index search and decode
+ * of the multi-codebook quantizer.
+ *
+ * The reference (danpovey/quantization) has no FFI for this path: it is a Python
+ * class whose private methods call torch ops.  Each entry point below replaces
+ * the named reference method; the host-side mirror (quantization_amd/quantizer.py)
+ * binds them with ctypes -- INTEGRATION.md shows the binding a maintainer of the
+ * reference would add.
+ *
+ * Conventions
+ *  - every pointer except `prepared`/`workspace` sizes is a BORROWED DEVICE pointer
+ *    (torch `tensor.data_ptr()`), contiguous, alive until the stream has drained;
+ *  - every function only enqueues work on `stream` (a hipStream_t passed as void*;
+ *    NULL = the default stream) and returns immediately: no allocation, no
+ *    synchronisation, no global mutable state, re-entrant per (device, stream);
+ *  - return value: 0 = ok; MCQ_E* < 0 = rejected argument; > 0 = hipError_t of a
+ *    failed launch.  Nothing is thrown across the boundary.
+ *  - supported domain: codebook_size K a power of two in [16, 256], num_codebooks N
+ *    a power of two in [1, 64], any dim D >= 1 (rows are zero-padded to a multiple
+ *    of 16 inside `prepared`).  The reference crashes for K < 16
+ *    (quantization/quantization.py:506) and needs K <= 256 for byte output (:271).
+ *
+ * Numerics: bit-identical to oracle/mcq_oracle.c (see its header for the spec:
+ * v_mfma_f32_16x16x4_f32 k-order fmaf chains, wave64 butterfly reductions).
+ */
+#ifndef MCQ_H
+#define MCQ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCQ_EINVAL (-1)     /* bad shape / null pointer                         */
+#define MCQ_EUNSUPPORTED (-2) /* outside the supported (K, N) domain             */
+#define MCQ_EWORKSPACE (-3) /* workspace smaller than mcq_encode_workspace_bytes */
+
+#define MCQ_ABI_VERSION 1
+int mcq_abi_version(void);
+
+/* D rounded up to the padded row length used inside `prepared` and workspaces. */
+int mcq_padded_dim(int D);
+
+/* ---- derived state -------------------------------------------------------
+ * Replaces Quantizer.get_centers() (quantization/quantization.py:77-79, recomputed
+ * on every call there) and the parameter reads of Quantizer._logits (:277-279).
+ * `prepared` receives: scaled centers C[N][K][Dp] = cscale_exp * centers, their
+ * sum of squares Q[N][K] (:411), to_logits.weight padded to Dp and the bias.
+ * cscale_exp / lscale_exp = exp(10*centers_scale) / exp(10*logits_scale), formed
+ * by the caller in fp32 exactly as the reference does (:78, :278).
+ * weight/bias may be NULL when only decode is needed.                          */
+size_t mcq_prepared_bytes(int N, int K, int D);
+int mcq_prepare(const float *centers, float cscale_exp, const float *weight, const float *bias,
+                int N, int K, int D, void *prepared, void *stream);
+
+/* ---- index search ----------------------------------------------------------
+ * Replaces Quantizer._compute_indexes (:281-305): learned-logit argmax followed
+ * by `refine_iters` passes of Quantizer._refine_indexes (:308-547).
+ * x: fp32 [B][D].  Exactly one of out_u8 / out_i64 is non-NULL:
+ *   out_i64: int64 [B][N]            -- _compute_indexes / encode(as_bytes=False)
+ *   out_u8 : uint8 [B][N / pack]     -- encode(as_bytes=True) (:266-272), where
+ *            pack = 2 when K == 16 (low nibble = even codebook), else 1.
+ * workspace: device scratch of at least mcq_encode_workspace_bytes(B, N, K, D)
+ * bytes (the batch is processed in chunks that fit; any B >= 0 is accepted).   */
+size_t mcq_encode_workspace_bytes(long B, int N, int K, int D);
+int mcq_encode(const float *x, long B, const void *prepared, float lscale_exp, int N, int K, int D,
+               int refine_iters, uint8_t *out_u8, int64_t *out_i64, void *workspace,
+               size_t workspace_bytes, void *stream);
+
+/* ---- decode ----------------------------------------------------------------
+ * Replaces Quantizer.decode + _maybe_separate_indexes (:117-148, :551-573).
+ * codes: [B][codes_per_row] of uint8 (code_bytes == 1) or int64 (code_bytes == 8);
+ * codes_per_row == N, or N / r with r in {2,4,8,16} for packed codes (each code
+ * holds r base-K digits, least significant first).  out: fp32 [B][D],
+ * out[b] = sum over n ascending of C[n][index(b, n)].                          */
+int mcq_decode(const void *codes, int code_bytes, int codes_per_row, long B, const void *prepared,
+               int N, int K, int D, float *out, void *stream);
+
+/* ---- test / profiling hooks -------------------------------------------------
+ * Logits of Quantizer._logits (:277-279) for a batch, fp32 [B][N*K]; used by the
+ * parity tests to localise a divergence.                                       */
+int mcq_logits(const float *x, long B, const void *prepared, float lscale_exp, int N, int K, int D,
+               float *out, void *stream);
+
+/* Name and launch count of the kernels enqueued by the last mcq_encode on this
+ * thread (for bench.py's per-kernel HIP-event timing); returns the count.      */
+int mcq_last_encode_launches(void);
+
+/* Times one refinement pass's kernels separately with HIP events on `stream`
+ * (synchronises; bench/profiling only).  ms_out[0..n) receives milliseconds for
+ * {logits_argmax, residual, stage0_gemm, prune0, pair stages...}; returns n.   */
+int mcq_profile_encode(const float *x, long B, const void *prepared, float lscale_exp, int N, int K,
+                       int D, int refine_iters, void *workspace, size_t workspace_bytes, void *stream,
+                       float *ms_out, int ms_cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCQ_H */

@@ -1,0 +1,10 @@
+"""quantization_amd -- MI355X-native multi-codebook vector quantizer.
+
+Drop-in for the hot path of danpovey/quantization (`Quantizer.encode/decode`,
+`QuantizerTrainer.step`): same class names, arguments and state-dict layout as
+/root/reference/quantization/__init__.py:1-2 exports for this path.
+"""
+from .quantizer import Quantizer  # noqa: F401
+from .trainer import QuantizerTrainer  # noqa: F401
+
+__all__ = ["Quantizer", "QuantizerTrainer"]

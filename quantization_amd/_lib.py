@@ -1,0 +1,63 @@
+"""ctypes binding of libmcq_hip.so (C ABI: include/mcq.h).
+
+The library is built in-tree by `__graft_entry__.build()` (hipcc, gfx950).  There
+is no CPU fallback: a missing library or a non-HIP tensor is an error.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmcq_hip.so")
+
+# every symbol include/mcq.h declares
+SYMBOLS = (
+    "mcq_abi_version", "mcq_padded_dim", "mcq_prepared_bytes", "mcq_prepare", "mcq_encode_workspace_bytes",
+    "mcq_encode", "mcq_decode", "mcq_logits", "mcq_last_encode_launches", "mcq_profile_encode",
+)
+
+MCQ_EINVAL, MCQ_EUNSUPPORTED, MCQ_EWORKSPACE = -1, -2, -3
+_lib = None
+
+
+class McqError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise McqError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(hipcc --offload-arch=gfx950); quantization_amd has no CPU fallback")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, f32, i32, i64, sz = ctypes.c_void_p, ctypes.c_float, ctypes.c_int, ctypes.c_long, ctypes.c_size_t
+    L.mcq_abi_version.restype = i32
+    L.mcq_padded_dim.restype = i32
+    L.mcq_padded_dim.argtypes = [i32]
+    L.mcq_prepared_bytes.restype = sz
+    L.mcq_prepared_bytes.argtypes = [i32, i32, i32]
+    L.mcq_prepare.restype = i32
+    L.mcq_prepare.argtypes = [vp, f32, vp, vp, i32, i32, i32, vp, vp]
+    L.mcq_encode_workspace_bytes.restype = sz
+    L.mcq_encode_workspace_bytes.argtypes = [i64, i32, i32, i32]
+    L.mcq_encode.restype = i32
+    L.mcq_encode.argtypes = [vp, i64, vp, f32, i32, i32, i32, i32, vp, vp, vp, sz, vp]
+    L.mcq_decode.restype = i32
+    L.mcq_decode.argtypes = [vp, i32, i32, i64, vp, i32, i32, i32, vp, vp]
+    L.mcq_logits.restype = i32
+    L.mcq_logits.argtypes = [vp, i64, vp, f32, i32, i32, i32, vp, vp]
+    L.mcq_last_encode_launches.restype = i32
+    L.mcq_profile_encode.restype = i32
+    L.mcq_profile_encode.argtypes = [vp, i64, vp, f32, i32, i32, i32, i32, vp, sz, vp, ctypes.POINTER(f32), i32]
+    assert L.mcq_abi_version() == 1
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str):
+    if rc == 0:
+        return
+    names = {MCQ_EINVAL: "invalid argument", MCQ_EUNSUPPORTED: "unsupported (codebook_size, num_codebooks)",
+             MCQ_EWORKSPACE: "workspace too small"}
+    raise McqError(f"{what}: {names.get(rc, 'HIP error %d' % rc)}")

@@ -1,0 +1,373 @@
+// mcq_api.hip -- C ABI (include/mcq.h) over the gfx950 kernels of mcq_kernels.h.
+// Host side only enqueues kernels on the caller's stream; see mcq.h for the contract.
+#include "../../include/mcq.h"
+#include "mcq_kernels.h"
+
+#include <vector>
+
+using namespace mcq;
+
+namespace {
+
+inline int round_up16(int d) { return (d + 15) & ~15; }
+inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
+inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+// K_cutoff rule of _refine_indexes (quantization/quantization.py:453-463)
+int k_cutoff(int K, int L) {
+    int kc = (K <= 16) ? 8 : 16;
+    while (L >= 4) { L /= 4; kc *= 2; }
+    return kc < 128 ? kc : 128;
+}
+
+struct Prepared {
+    const float *C, *Q, *W, *bias;
+};
+
+struct PreparedLayout {
+    size_t offC, offQ, offW, offBias, total;
+};
+
+PreparedLayout prepared_layout(int N, int K, int D) {
+    const size_t nk = (size_t)N * K, Dp = round_up16(D);
+    PreparedLayout l;
+    l.offC = 0;
+    l.offQ = align256(l.offC + nk * Dp * 4);
+    l.offW = align256(l.offQ + nk * 4);
+    l.offBias = align256(l.offW + nk * Dp * 4);
+    l.total = align256(l.offBias + nk * 4);
+    return l;
+}
+
+Prepared prepared_view(const void *p, int N, int K, int D) {
+    const PreparedLayout l = prepared_layout(N, K, D);
+    const char *b = static_cast<const char *>(p);
+    return Prepared{reinterpret_cast<const float *>(b + l.offC), reinterpret_cast<const float *>(b + l.offQ),
+                    reinterpret_cast<const float *>(b + l.offW), reinterpret_cast<const float *>(b + l.offBias)};
+}
+
+struct Workspace {
+    uint8_t *idx;
+    float *xerr, *E, *R, *S0;
+    uint8_t *tup[2];
+    float *S[2];
+};
+
+size_t workspace_per_vector(int N, int K, int Dp) {
+    return (size_t)N + 4 * (size_t)Dp + 4 + 4 * (size_t)N + 4 * (size_t)N * K + 2 * 64 * (size_t)N +
+           2 * 4 * 16 * (size_t)N;
+}
+constexpr size_t kWorkspaceSlack = 16 * 256;
+constexpr long kDefaultChunk = 65536;
+
+Workspace carve(void *ws, long Bc, int N, int K, int Dp) {
+    char *p = static_cast<char *>(ws);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char *q = p + off; off = align256(off + bytes); return q; };
+    Workspace w;
+    w.idx = reinterpret_cast<uint8_t *>(take((size_t)Bc * N));
+    w.xerr = reinterpret_cast<float *>(take((size_t)Bc * Dp * 4));
+    w.E = reinterpret_cast<float *>(take((size_t)Bc * 4));
+    w.R = reinterpret_cast<float *>(take((size_t)Bc * N * 4));
+    w.S0 = reinterpret_cast<float *>(take((size_t)Bc * N * K * 4));
+    for (int i = 0; i < 2; ++i) w.tup[i] = reinterpret_cast<uint8_t *>(take((size_t)Bc * N * 64));
+    for (int i = 0; i < 2; ++i) w.S[i] = reinterpret_cast<float *>(take((size_t)Bc * N * 16 * 4));
+    return w;
+}
+
+bool domain_ok(int N, int K, int D) {
+    return is_pow2(K) && K >= 16 && K <= 256 && is_pow2(N) && N <= 64 && D >= 1;
+}
+
+// optional per-launch timing (mcq_profile_encode)
+struct Prof {
+    hipStream_t stream;
+    std::vector<hipEvent_t> ev;
+    std::vector<int> cat;
+    void begin() {
+        hipEvent_t e;
+        (void)hipEventCreate(&e);
+        (void)hipEventRecord(e, stream);
+        ev.push_back(e);
+    }
+    void end(int category) {
+        hipEvent_t e;
+        (void)hipEventCreate(&e);
+        (void)hipEventRecord(e, stream);
+        ev.push_back(e);
+        cat.push_back(category);
+    }
+};
+
+thread_local int g_last_launches = 0;
+
+#define MCQ_LAUNCH_CHECK()                               \
+    do {                                                 \
+        hipError_t e_ = hipGetLastError();               \
+        if (e_ != hipSuccess) return (int)e_;            \
+        ++g_last_launches;                               \
+    } while (0)
+
+template <int MODE>
+int launch_gemm(int K, const float *Bm, const float *xin, const uint8_t *idx_in, float lscale, const float *bias,
+                const float *R, const float *Q, long B, int N, int D, int Dp, uint8_t *idx_out, float *out,
+                hipStream_t st) {
+    const unsigned grid = (unsigned)(((B + kGemmVec - 1) / kGemmVec) * N);
+    const size_t lds = ((size_t)K * 8 + kGemmVec * 8) * 16;
+#define MCQ_GEMM_CASE(TT)                                                                                       \
+    case 16 * TT:                                                                                               \
+        hipLaunchKernelGGL((k_gemm<TT, MODE>), dim3(grid), dim3(256), lds, st, Bm, xin, idx_in, lscale, bias, R, \
+                           Q, B, N, D, Dp, idx_out, out);                                                       \
+        break;
+    switch (K) {
+        MCQ_GEMM_CASE(1)
+        MCQ_GEMM_CASE(2)
+        MCQ_GEMM_CASE(4)
+        MCQ_GEMM_CASE(8)
+        MCQ_GEMM_CASE(16)
+        default: return MCQ_EUNSUPPORTED;
+    }
+#undef MCQ_GEMM_CASE
+    MCQ_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_prune0(int K, const float *S0, long BN, int keep, uint8_t *tup, float *S, uint8_t *idx_final,
+                  hipStream_t st) {
+    const unsigned grid = (unsigned)((BN + 3) / 4);
+    switch (K) {
+        case 16: hipLaunchKernelGGL((k_prune0<16>), dim3(grid), dim3(256), 0, st, S0, BN, keep, tup, S, idx_final); break;
+        case 32: hipLaunchKernelGGL((k_prune0<32>), dim3(grid), dim3(256), 0, st, S0, BN, keep, tup, S, idx_final); break;
+        case 64: hipLaunchKernelGGL((k_prune0<64>), dim3(grid), dim3(256), 0, st, S0, BN, keep, tup, S, idx_final); break;
+        case 128: hipLaunchKernelGGL((k_prune0<128>), dim3(grid), dim3(256), 0, st, S0, BN, keep, tup, S, idx_final); break;
+        case 256: hipLaunchKernelGGL((k_prune0<256>), dim3(grid), dim3(256), 0, st, S0, BN, keep, tup, S, idx_final); break;
+        default: return MCQ_EUNSUPPORTED;
+    }
+    MCQ_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int L, int KI>
+int launch_pair_t(const float *C, const uint8_t *idx, const float *E, const uint8_t *tup_in, const float *S_in,
+                  long B, int N, int K, int Dp, int Gout, int keep, uint8_t *tup_out, float *S_out,
+                  uint8_t *idx_final, hipStream_t st) {
+    const size_t per_wave = (size_t)2 * L * Dp * 4;
+    int wpb = 4;
+    bool old_lds = true;
+    if (per_wave * 4 <= 65536) wpb = 4;
+    else if (per_wave * 2 <= 65536) wpb = 2;
+    else if (per_wave <= 65536) wpb = 1;
+    else { wpb = 4; old_lds = false; }
+    const long waves = B * Gout;
+    const unsigned grid = (unsigned)((waves + wpb - 1) / wpb);
+    if (old_lds)
+        hipLaunchKernelGGL((k_pair<L, KI, true>), dim3(grid), dim3(64 * wpb), per_wave * wpb, st, C, idx, E, tup_in,
+                           S_in, B, N, K, Dp, Gout, keep, tup_out, S_out, idx_final);
+    else
+        hipLaunchKernelGGL((k_pair<L, KI, false>), dim3(grid), dim3(64 * wpb), 0, st, C, idx, E, tup_in, S_in, B, N,
+                           K, Dp, Gout, keep, tup_out, S_out, idx_final);
+    MCQ_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_pair(int L, int KI, const float *C, const uint8_t *idx, const float *E, const uint8_t *tup_in,
+                const float *S_in, long B, int N, int K, int Dp, int Gout, int keep, uint8_t *tup_out, float *S_out,
+                uint8_t *idx_final, hipStream_t st) {
+#define MCQ_PAIR_CASE(LL, KK)                                                                                     \
+    if (L == LL && KI == KK)                                                                                      \
+        return launch_pair_t<LL, KK>(C, idx, E, tup_in, S_in, B, N, K, Dp, Gout, keep, tup_out, S_out, idx_final, st);
+    // K >= 32 ladders: 16,16,32,32,64 ; K == 16 ladders: 8,8,16,16,32,32
+    MCQ_PAIR_CASE(1, 16)
+    MCQ_PAIR_CASE(2, 16)
+    MCQ_PAIR_CASE(4, 32)
+    MCQ_PAIR_CASE(8, 32)
+    MCQ_PAIR_CASE(16, 64)
+    MCQ_PAIR_CASE(1, 8)
+    MCQ_PAIR_CASE(2, 8)
+    MCQ_PAIR_CASE(4, 16)
+    MCQ_PAIR_CASE(8, 16)
+    MCQ_PAIR_CASE(16, 32)
+    MCQ_PAIR_CASE(32, 32)
+#undef MCQ_PAIR_CASE
+    return MCQ_EUNSUPPORTED;
+}
+
+// categories for profiling
+enum { CAT_LOGITS = 0, CAT_RESIDUAL = 1, CAT_STAGE0 = 2, CAT_PRUNE0 = 3, CAT_PAIR0 = 4 };
+
+int run_encode(const float *x, long B, const void *prepared, float lscale, int N, int K, int D, int iters,
+               uint8_t *out_u8, int64_t *out_i64, void *workspace, size_t workspace_bytes, hipStream_t st,
+               Prof *prof) {
+    g_last_launches = 0;
+    if (!domain_ok(N, K, D)) return (K < 16 || K > 256 || N > 64) ? MCQ_EUNSUPPORTED : MCQ_EINVAL;
+    if (B < 0 || iters < 0 || (out_u8 == nullptr) == (out_i64 == nullptr)) return MCQ_EINVAL;
+    if (B == 0) return 0;
+    if (!x || !prepared || !workspace) return MCQ_EINVAL;
+    const int Dp = round_up16(D);
+    const size_t per = workspace_per_vector(N, K, Dp);
+    if (workspace_bytes < kWorkspaceSlack + per) return MCQ_EWORKSPACE;
+    long chunk = (long)((workspace_bytes - kWorkspaceSlack) / per);
+    if (chunk > B) chunk = B;
+    if (chunk < B && chunk < 64) return MCQ_EWORKSPACE;
+    if (chunk < B) chunk &= ~63L;
+    const Prepared P = prepared_view(prepared, N, K, D);
+    const int pack = (out_u8 != nullptr && K == 16 && N >= 2) ? 2 : 1;
+    const int first_keep = (N == 1) ? 1 : k_cutoff(K, 1);
+
+    for (long lo = 0; lo < B; lo += chunk) {
+        const long Bc = (B - lo < chunk) ? (B - lo) : chunk;
+        const Workspace w = carve(workspace, Bc, N, K, Dp);
+        const float *xc = x + lo * D;
+        int rc;
+        if (prof) prof->begin();
+        rc = launch_gemm<MODE_LOGITS>(K, P.W, xc, nullptr, lscale, P.bias, nullptr, nullptr, Bc, N, D, Dp, w.idx,
+                                      nullptr, st);
+        if (rc) return rc;
+        if (prof) prof->end(CAT_LOGITS);
+        for (int it = 0; it < iters; ++it) {
+            if (prof) prof->begin();
+            hipLaunchKernelGGL(k_residual, dim3((unsigned)((Bc + 3) / 4)), dim3(256), 0, st, xc, w.idx, P.C, Bc, N, K,
+                               D, Dp, w.xerr, w.E, w.R);
+            MCQ_LAUNCH_CHECK();
+            if (prof) { prof->end(CAT_RESIDUAL); prof->begin(); }
+            rc = launch_gemm<MODE_STAGE0>(K, P.C, w.xerr, w.idx, 0.f, nullptr, w.R, P.Q, Bc, N, D, Dp, nullptr, w.S0,
+                                          st);
+            if (rc) return rc;
+            if (prof) { prof->end(CAT_STAGE0); prof->begin(); }
+            rc = launch_prune0(K, w.S0, Bc * N, first_keep, w.tup[0], w.S[0], (N == 1) ? w.idx : nullptr, st);
+            if (rc) return rc;
+            if (prof) prof->end(CAT_PRUNE0);
+            int G = N, L = 1, KI = first_keep, cur = 0, stage = 0;
+            while (G > 1) {
+                const int Gout = G / 2;
+                const int keep = (Gout == 1) ? 1 : k_cutoff(K, 2 * L);
+                if (prof) prof->begin();
+                rc = launch_pair(L, KI, P.C, w.idx, w.E, w.tup[cur], w.S[cur], Bc, N, K, Dp, Gout, keep,
+                                 w.tup[cur ^ 1], w.S[cur ^ 1], (Gout == 1) ? w.idx : nullptr, st);
+                if (rc) return rc;
+                if (prof) prof->end(CAT_PAIR0 + stage);
+                G = Gout; L *= 2; KI = keep; cur ^= 1; ++stage;
+            }
+        }
+        const long outn = (out_i64 != nullptr) ? Bc * N : Bc * (N / pack);
+        hipLaunchKernelGGL(k_finalize, dim3((unsigned)((outn + 255) / 256)), dim3(256), 0, st, w.idx, Bc, N, pack,
+                           out_u8 ? out_u8 + lo * (N / pack) : nullptr, out_i64 ? out_i64 + lo * N : nullptr);
+        MCQ_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mcq_abi_version(void) { return MCQ_ABI_VERSION; }
+
+int mcq_padded_dim(int D) { return round_up16(D); }
+
+size_t mcq_prepared_bytes(int N, int K, int D) {
+    if (N <= 0 || K <= 0 || D <= 0) return 0;
+    return prepared_layout(N, K, D).total;
+}
+
+int mcq_prepare(const float *centers, float cscale_exp, const float *weight, const float *bias, int N, int K, int D,
+                void *prepared, void *stream) {
+    if (!domain_ok(N, K, D)) return (K < 16 || K > 256 || N > 64) ? MCQ_EUNSUPPORTED : MCQ_EINVAL;
+    if (!centers || !prepared || ((weight == nullptr) != (bias == nullptr))) return MCQ_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const PreparedLayout l = prepared_layout(N, K, D);
+    char *b = static_cast<char *>(prepared);
+    const long rows = (long)N * K;
+    const int Dp = round_up16(D);
+    const unsigned grid = (unsigned)((rows + 3) / 4);
+    hipLaunchKernelGGL(k_prepare_rows, dim3(grid), dim3(256), 0, st, centers, cscale_exp, 1, rows, D, Dp,
+                       reinterpret_cast<float *>(b + l.offC), reinterpret_cast<float *>(b + l.offQ));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    if (weight) {
+        hipLaunchKernelGGL(k_prepare_rows, dim3(grid), dim3(256), 0, st, weight, 1.0f, 0, rows, D, Dp,
+                           reinterpret_cast<float *>(b + l.offW), static_cast<float *>(nullptr));
+        e = hipGetLastError();
+        if (e != hipSuccess) return (int)e;
+        e = hipMemcpyAsync(b + l.offBias, bias, (size_t)rows * 4, hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return (int)e;
+    }
+    return 0;
+}
+
+size_t mcq_encode_workspace_bytes(long B, int N, int K, int D) {
+    if (B <= 0 || N <= 0 || K <= 0 || D <= 0) return kWorkspaceSlack;
+    const long chunk = B < kDefaultChunk ? B : kDefaultChunk;
+    return kWorkspaceSlack + workspace_per_vector(N, K, round_up16(D)) * (size_t)chunk;
+}
+
+int mcq_encode(const float *x, long B, const void *prepared, float lscale_exp, int N, int K, int D, int refine_iters,
+               uint8_t *out_u8, int64_t *out_i64, void *workspace, size_t workspace_bytes, void *stream) {
+    return run_encode(x, B, prepared, lscale_exp, N, K, D, refine_iters, out_u8, out_i64, workspace,
+                      workspace_bytes, static_cast<hipStream_t>(stream), nullptr);
+}
+
+int mcq_decode(const void *codes, int code_bytes, int codes_per_row, long B, const void *prepared, int N, int K, int D,
+               float *out, void *stream) {
+    if (!domain_ok(N, K, D)) return (K < 16 || K > 256 || N > 64) ? MCQ_EUNSUPPORTED : MCQ_EINVAL;
+    if (B < 0 || codes_per_row <= 0 || N % codes_per_row != 0) return MCQ_EINVAL;
+    const int rep = N / codes_per_row;
+    if (!(rep == 1 || rep == 2 || rep == 4 || rep == 8 || rep == 16)) return MCQ_EINVAL;
+    if (code_bytes != 1 && code_bytes != 8) return MCQ_EINVAL;
+    if (B == 0) return 0;
+    if (!codes || !prepared || !out) return MCQ_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const Prepared P = prepared_view(prepared, N, K, D);
+    const int Dp = round_up16(D);
+    const unsigned grid = (unsigned)((B + 3) / 4);
+    if (code_bytes == 1)
+        hipLaunchKernelGGL((k_decode<uint8_t>), dim3(grid), dim3(256), 0, st, static_cast<const uint8_t *>(codes),
+                           codes_per_row, B, P.C, N, K, D, Dp, out);
+    else
+        hipLaunchKernelGGL((k_decode<int64_t>), dim3(grid), dim3(256), 0, st, static_cast<const int64_t *>(codes),
+                           codes_per_row, B, P.C, N, K, D, Dp, out);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+int mcq_logits(const float *x, long B, const void *prepared, float lscale_exp, int N, int K, int D, float *out,
+               void *stream) {
+    if (!domain_ok(N, K, D)) return MCQ_EUNSUPPORTED;
+    if (B == 0) return 0;
+    if (!x || !prepared || !out || B < 0) return MCQ_EINVAL;
+    const Prepared P = prepared_view(prepared, N, K, D);
+    return launch_gemm<MODE_LOGITS_OUT>(K, P.W, x, nullptr, lscale_exp, P.bias, nullptr, nullptr, B, N, D,
+                                        round_up16(D), nullptr, out, static_cast<hipStream_t>(stream));
+}
+
+int mcq_last_encode_launches(void) { return g_last_launches; }
+
+int mcq_profile_encode(const float *x, long B, const void *prepared, float lscale_exp, int N, int K, int D,
+                       int refine_iters, void *workspace, size_t workspace_bytes, void *stream, float *ms_out,
+                       int ms_cap) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    Prof prof;
+    prof.stream = st;
+    // results go to the head of S0's neighbour: reuse the tail of the workspace as a dummy output
+    const size_t need = (size_t)B * N;
+    uint8_t *dummy = nullptr;
+    if (hipMalloc(reinterpret_cast<void **>(&dummy), need ? need : 1) != hipSuccess) return MCQ_EINVAL;
+    int rc = run_encode(x, B, prepared, lscale_exp, N, K, D, refine_iters, dummy, nullptr, workspace, workspace_bytes,
+                        st, &prof);
+    (void)hipStreamSynchronize(st);
+    int ncat = 0;
+    if (rc == 0) {
+        for (int c : prof.cat) ncat = c + 1 > ncat ? c + 1 : ncat;
+        for (int i = 0; i < ms_cap; ++i) ms_out[i] = 0.f;
+        for (size_t i = 0; i < prof.cat.size(); ++i) {
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, prof.ev[2 * i], prof.ev[2 * i + 1]);
+            if (prof.cat[i] < ms_cap) ms_out[prof.cat[i]] += ms;
+        }
+    }
+    for (hipEvent_t e : prof.ev) (void)hipEventDestroy(e);
+    (void)hipFree(dummy);
+    return rc == 0 ? ncat : rc;
+}
+
+}  // extern "C"

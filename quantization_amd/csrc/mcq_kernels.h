@@ -1,0 +1,605 @@
+// mcq_kernels.h -- gfx950 (CDNA4, wave64) kernels of the multi-codebook quantizer.
+//
+// Numeric contract (identical to oracle/mcq_oracle.c, which restates
+// /root/reference/quantization/quantization.py:277-547):
+//   * every contraction over the feature axis is ONE v_mfma_f32_16x16x4_f32
+//     accumulation chain per output, accumulator starting at +0, consuming k in
+//     the order  for blk: for i in 0..3: for g in 0..3: k = 16*blk + 4*g + i
+//     (lane (r, g) of the wave holds the float4 at 16*blk + 4*g of row r and
+//     feeds component i to MFMA number 4*blk + i of the chain);
+//   * every sum of squares is 64 per-lane fmaf chains over the float4 groups
+//     q = lane, lane+64, ... followed by the xor butterfly 32,16,8,4,2,1;
+//   * everything else is a single IEEE fp32 operation in the reference's order;
+//   * selections order candidates by (value, position), lowest position on ties.
+// Compile with -ffp-contract=off: only explicit fmaf()/MFMA fuse.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mcq {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kWave = 64;
+constexpr int kBigPos = 0x7fffffff;
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// ---------------------------------------------------------------- reductions
+__device__ __forceinline__ float wave_sum_butterfly(float p) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) p = p + __shfl_xor(p, m, 64);
+    return p;
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int x) {
+    return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xf, 0xf, true);
+}
+
+// (v, p) := min((v, p), (ov, op)) in (value, position) order
+__device__ __forceinline__ void lexmin(float &v, int &p, float ov, int op) {
+    const bool take = (ov < v) || (ov == v && op < p);
+    v = take ? ov : v;
+    p = take ? op : p;
+}
+
+// wave-wide lexicographic minimum; result uniform in every lane
+__device__ __forceinline__ void wave_lexmin(float &v, int &p) {
+    lexmin(v, p, dpp_f<0xB1>(v), dpp_i<0xB1>(p));    // quad_perm [1,0,3,2]  (xor 1)
+    lexmin(v, p, dpp_f<0x4E>(v), dpp_i<0x4E>(p));    // quad_perm [2,3,0,1]  (xor 2)
+    lexmin(v, p, dpp_f<0x141>(v), dpp_i<0x141>(p));  // row_half_mirror      (xor 7)
+    lexmin(v, p, dpp_f<0x140>(v), dpp_i<0x140>(p));  // row_mirror           (xor 15)
+    float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    int p0 = __builtin_amdgcn_readlane(p, 0), p1 = __builtin_amdgcn_readlane(p, 16);
+    int p2 = __builtin_amdgcn_readlane(p, 32), p3 = __builtin_amdgcn_readlane(p, 48);
+    lexmin(r0, p0, r1, p1);
+    lexmin(r2, p2, r3, p3);
+    lexmin(r0, p0, r2, p2);
+    v = r0;
+    p = p0;
+}
+
+// The `cnt` smallest of the wave's VPL*64 keys (v[i], p[i]) in ascending
+// (value, position) order; lane j (< cnt <= 64) receives the j-th.  Mirrors
+// select_smallest() of the oracle, including its treatment of non-finite keys.
+template <int VPL>
+__device__ __forceinline__ void wave_select(const float (&v)[VPL], const int (&p)[VPL], int cnt, int M,
+                                            float &out_v, int &out_p) {
+    float pv = -INFINITY;
+    int pp = -1;
+    const int lane = lane_id();
+    out_v = INFINITY;
+    out_p = M - 1;
+    for (int j = 0; j < cnt; ++j) {
+        float bv = INFINITY;
+        int bp = kBigPos;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const bool gt = (v[i] > pv) || (v[i] == pv && p[i] > pp);
+            const bool lt = (v[i] < bv) || (v[i] == bv && p[i] < bp);
+            if (gt && lt) { bv = v[i]; bp = p[i]; }
+        }
+        wave_lexmin(bv, bp);
+        if (bp > M - 1) bp = M - 1;  // only reachable with NaN keys
+        if (lane == j) { out_v = bv; out_p = bp; }
+        pv = bv;
+        pp = bp;
+    }
+}
+
+// ------------------------------------------------------------------- prepare
+// One wave per row: dst[row][0..Dp) = scale * src[row][0..D) zero padded; Q[row] = sumsq64.
+// (get_centers(), quantization.py:77-79; all_centers_sumsq, :411)
+__global__ void k_prepare_rows(const float *__restrict__ src, float scale, int apply_scale, long rows, int D,
+                               int Dp, float *__restrict__ dst, float *__restrict__ Q) {
+    const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = lane_id();
+    const float *s = src + row * D;
+    float *d = dst + row * Dp;
+    float part = 0.f;
+    for (int q = lane; q < Dp / 4; q += 64) {
+        f32x4 o;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int k = 4 * q + c;
+            float val = (k < D) ? s[k] : 0.f;
+            if (apply_scale) val = scale * val;
+            o[c] = val;
+            part = fmaf(val, val, part);
+        }
+        *reinterpret_cast<f32x4 *>(d + 4 * q) = o;
+    }
+    part = wave_sum_butterfly(part);
+    if (Q != nullptr && lane == 0) Q[row] = part;
+}
+
+// ------------------------------------------------------------------ residual
+// One wave per vector (quantization.py:338-340, :401-409):
+//   xerr[b] = (old_0 + old_1 + ... ) - x[b];  E[b] = sumsq64(xerr);
+//   R[b][n] = sumsq64(xerr - old_n),  old_n = C[n][idx[b][n]].
+__global__ void k_residual(const float *__restrict__ x, const uint8_t *__restrict__ idx,
+                           const float *__restrict__ C, long B, int N, int K, int D, int Dp,
+                           float *__restrict__ xerr, float *__restrict__ E, float *__restrict__ R) {
+    const long b = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int lane = lane_id();
+    const uint8_t *id = idx + b * N;
+    const float *xb = x + b * D;
+    float *xe = xerr + b * Dp;
+    const bool vec_ok = ((D & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+    float pe = 0.f;
+    for (int q = lane; q < Dp / 4; q += 64) {
+        f32x4 t = *reinterpret_cast<const f32x4 *>(C + ((long)id[0]) * Dp + 4 * q);
+        for (int n = 1; n < N; ++n)
+            t = t + *reinterpret_cast<const f32x4 *>(C + ((long)n * K + id[n]) * Dp + 4 * q);
+        f32x4 xv;
+        if (vec_ok && 4 * q + 3 < D) {
+            xv = *reinterpret_cast<const f32x4 *>(xb + 4 * q);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) xv[c] = (4 * q + c < D) ? xb[4 * q + c] : 0.f;
+        }
+        t = t - xv;
+        *reinterpret_cast<f32x4 *>(xe + 4 * q) = t;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) pe = fmaf(t[c], t[c], pe);
+    }
+    pe = wave_sum_butterfly(pe);
+    if (lane == 0) E[b] = pe;
+    for (int n = 0; n < N; ++n) {
+        const float *o = C + ((long)n * K + id[n]) * Dp;
+        float pr = 0.f;
+        for (int q = lane; q < Dp / 4; q += 64) {
+            // this lane wrote xe[4q..4q+3] above
+            f32x4 t = *reinterpret_cast<const f32x4 *>(xe + 4 * q) - *reinterpret_cast<const f32x4 *>(o + 4 * q);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) pr = fmaf(t[c], t[c], pr);
+        }
+        pr = wave_sum_butterfly(pr);
+        if (lane == 0) R[b * N + n] = pr;
+    }
+}
+
+// ---------------------------------------------------------------------- GEMM
+// out[b][n][k] = dot16(Bm[n][k][:], A_n[b][:]) for a 64-vector tile and one
+// codebook n per workgroup (4 waves, wave w owns vectors 16w..16w+15 and all
+// K = 16*T entries).  MFMA rows = codebook entries, columns = vectors, so the K
+// scores of one vector live in the 4 lanes {c, c+16, c+32, c+48}.
+//   MODE_LOGITS : A_n[b] = lscale * x[b]            (quantization.py:278)
+//                 epilogue: + bias, first-max argmax over k  (:279, :301)
+//   MODE_STAGE0 : A_n[b] = xerr[b] - C[n][idx[b][n]] (:403)
+//                 epilogue: S = (R + Q) + 2*dot      (:418), stored to S0
+//   MODE_LOGITS_OUT: as MODE_LOGITS but stores the logits (test hook)
+enum { MODE_LOGITS = 0, MODE_STAGE0 = 1, MODE_LOGITS_OUT = 2 };
+
+constexpr int kGemmVec = 64;  // vectors per workgroup
+constexpr int kGemmBK = 32;   // floats of the feature axis per LDS stage (2 k-blocks)
+
+// LDS image of a [rows][32 floats] stage: 16-byte units at
+//   kb*4*rows + g*rows + (row ^ (g | kb<<2))      kb in {0,1}, g in 0..3
+// conflict-free for the fragment ds_read_b128 (lane (r,g) reads row base+r, unit g)
+// and for the staging ds_write_b128 (8 consecutive lanes write one row's 8 units).
+__device__ __forceinline__ int lds_unit(int rows, int row, int kb, int g) {
+    return kb * 4 * rows + g * rows + (row ^ (g | (kb << 2)));
+}
+
+template <int T, int MODE>
+__global__ void __launch_bounds__(256, 2)
+k_gemm(const float *__restrict__ Bm /*[N][K][Dp]*/, const float *__restrict__ xin /*x [B][D] or xerr [B][Dp]*/,
+       const uint8_t *__restrict__ idx_in, float lscale, const float *__restrict__ bias,
+       const float *__restrict__ Rin, const float *__restrict__ Qin, long B, int N, int D, int Dp,
+       uint8_t *__restrict__ idx_out, float *__restrict__ out) {
+    constexpr int K = 16 * T;
+    constexpr int A_UNITS = K * 8;           // 16-byte units of the entries tile per stage
+    constexpr int B_UNITS = kGemmVec * 8;
+    constexpr int A_PER_THREAD = (A_UNITS + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4 *ldsA = reinterpret_cast<f32x4 *>(smem);
+    f32x4 *ldsB = ldsA + A_UNITS;
+
+    const int n = blockIdx.x % N;
+    const long b0 = (long)(blockIdx.x / N) * kGemmVec;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+
+    const float *Bn = Bm + (long)n * K * Dp;
+    const int xstride = (MODE == MODE_STAGE0) ? Dp : D;
+    const bool x_vec = (MODE == MODE_STAGE0) || (((D & 3) == 0) && ((reinterpret_cast<uintptr_t>(xin) & 15) == 0));
+
+    // staging assignment: unit f -> (row = f / 8, c = f % 8 -> kb = c / 4, g = c % 4)
+    const float *oldrow[2] = {nullptr, nullptr};
+    long brow[2];
+    bool bvalid[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int row = (tid + 256 * s) >> 3;
+        brow[s] = b0 + row;
+        bvalid[s] = brow[s] < B;
+        if (MODE == MODE_STAGE0 && bvalid[s])
+            oldrow[s] = Bm + ((long)n * K + idx_in[brow[s] * N + n]) * Dp;
+    }
+
+    f32x4 acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    f32x4 stA[A_PER_THREAD], stB[2];
+    const int nkb = Dp / 16;
+    const int nsteps = (nkb + 1) / 2;
+
+    auto load_stage = [&](int step) {
+        const int k0 = step * kGemmBK;
+#pragma unroll
+        for (int s = 0; s < A_PER_THREAD; ++s) {
+            const int f = tid + 256 * s;
+            const int row = f >> 3, c = f & 7;
+            const int k = k0 + 4 * c;
+            if (f < A_UNITS && k < Dp) stA[s] = *reinterpret_cast<const f32x4 *>(Bn + (long)row * Dp + k);
+            else stA[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int c = (tid + 256 * s) & 7;
+            const int k = k0 + 4 * c;
+            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (bvalid[s] && k < Dp) {
+                const float *xr = xin + brow[s] * xstride;
+                if (x_vec && k + 3 < xstride) {
+                    v = *reinterpret_cast<const f32x4 *>(xr + k);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (k + e < xstride) ? xr[k + e] : 0.f;
+                }
+                if (MODE == MODE_STAGE0) v = v - *reinterpret_cast<const f32x4 *>(oldrow[s] + k);
+                else v = v * lscale;
+            }
+            stB[s] = v;
+        }
+    };
+
+    load_stage(0);
+    for (int step = 0; step < nsteps; ++step) {
+#pragma unroll
+        for (int s = 0; s < A_PER_THREAD; ++s) {
+            const int f = tid + 256 * s;
+            if (f < A_UNITS) ldsA[lds_unit(K, f >> 3, (f & 7) >> 2, f & 3)] = stA[s];
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int f = tid + 256 * s;
+            ldsB[lds_unit(kGemmVec, f >> 3, (f & 7) >> 2, f & 3)] = stB[s];
+        }
+        __syncthreads();
+        if (step + 1 < nsteps) load_stage(step + 1);
+        const int kbs = (2 * step + 1 < nkb) ? 2 : 1;
+        for (int kb = 0; kb < kbs; ++kb) {
+            const f32x4 bf = ldsB[lds_unit(kGemmVec, 16 * wave + r, kb, g)];
+            f32x4 af[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) af[t] = ldsA[lds_unit(K, 16 * t + r, kb, g)];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int t = 0; t < T; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t][i], bf[i], acc[t], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // epilogue: lane holds, for vector b0 + 16*wave + r, entries k = 16t + 4g + v
+    const long b = b0 + 16 * wave + r;
+    if (MODE == MODE_STAGE0) {
+        if (b < B) {
+            const float Rv = Rin[b * N + n];
+            float *o = out + (b * N + n) * (long)K;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const f32x4 q = *reinterpret_cast<const f32x4 *>(Qin + (long)n * K + 16 * t + 4 * g);
+                f32x4 s;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) s[v] = (Rv + q[v]) + 2.0f * acc[t][v];
+                *reinterpret_cast<f32x4 *>(o + 16 * t + 4 * g) = s;
+            }
+        }
+    } else {
+        float best = -INFINITY;
+        int bk = 0;
+        bool first = true;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const f32x4 bi = *reinterpret_cast<const f32x4 *>(bias + (long)n * K + 16 * t + 4 * g);
+            f32x4 lv;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                lv[v] = acc[t][v] + bi[v];
+                const int k = 16 * t + 4 * g + v;
+                if (first || lv[v] > best) { best = lv[v]; bk = k; first = false; }
+            }
+            if (MODE == MODE_LOGITS_OUT && b < B)
+                *reinterpret_cast<f32x4 *>(out + (b * N + n) * (long)K + 16 * t + 4 * g) = lv;
+        }
+        if (MODE == MODE_LOGITS) {
+            // combine the 4 lanes of this vector: first maximum = greatest value, lowest k on ties
+#pragma unroll
+            for (int m = 16; m <= 32; m <<= 1) {
+                const float ov = __shfl_xor(best, m, 64);
+                const int ok = __shfl_xor(bk, m, 64);
+                const bool take = (ov > best) || (ov == best && ok < bk);
+                best = take ? ov : best;
+                bk = take ? ok : bk;
+            }
+            if (g == 0 && b < B) idx_out[b * N + n] = (uint8_t)bk;
+        }
+    }
+}
+
+// -------------------------------------------------------------------- prune0
+// First sort-and-truncate (quantization.py:470-503 at L = 1): one wave per (b, n)
+// keeps the `keep` smallest of S0[b][n][0..K).  keep == 1 happens only for N == 1,
+// where the kept entry IS the new index (:468-469).
+template <int K>
+__global__ void k_prune0(const float *__restrict__ S0, long BN, int keep, uint8_t *__restrict__ tup_out,
+                         float *__restrict__ S_out, uint8_t *__restrict__ idx_final) {
+    constexpr int VPL = (K >= 64) ? K / 64 : 1;
+    const long w = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (w >= BN) return;
+    const int lane = lane_id();
+    float v[VPL];
+    int p[VPL];
+    const float *s = S0 + w * K;
+    if (K >= 256) {
+        const f32x4 t = *reinterpret_cast<const f32x4 *>(s + 4 * lane);
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) { v[i] = t[i & 3]; p[i] = VPL * lane + i; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int pos = VPL * lane + i;
+            const bool ok = pos < K;
+            v[i] = ok ? s[ok ? pos : 0] : INFINITY;
+            p[i] = ok ? pos : kBigPos;
+        }
+    }
+    float ov;
+    int op;
+    wave_select<VPL>(v, p, keep, K, ov, op);
+    if (lane < keep) {
+        if (idx_final != nullptr) {
+            idx_final[w] = (uint8_t)op;
+        } else {
+            tup_out[w * keep + lane] = (uint8_t)op;
+            S_out[w * keep + lane] = ov;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------- pair
+// One combine + sort-and-truncate step (quantization.py:504-547 then :470-503):
+// one wave per (vector b, output group go).  Input groups e = 2*go, o = 2*go + 1
+// each hold KI candidates: a tuple of L codebook entries (codebooks e*L .. e*L+L-1)
+// and a score.  delta(candidate) is rebuilt from the tuple as the reference built
+// it: leaves c - old (:436-439) summed pairwise up the combine tree (:538-541).
+//   S'[a*KI + b] = ((Se[a] + So[b]) - E) + 2 * dot16(delta_e[a], delta_o[b])
+// The `keep` smallest (value, position) survive; their tuples are concatenated.
+// MFMA rows = even-group candidates a, columns = odd-group candidates b.
+template <int L>
+struct TupleRegs {
+    static constexpr int WORDS = (L + 3) / 4;
+    uint32_t w[WORDS];
+    __device__ __forceinline__ int get(int j) const { return (w[j >> 2] >> (8 * (j & 3))) & 0xff; }
+};
+
+template <int L, bool OLD_LDS>
+struct DeltaBuilder {
+    // delta over leaves [j0, j0 + LL) of one candidate, for float offset `koff`
+    template <int LL>
+    static __device__ __forceinline__ f32x4 build(const float *__restrict__ C, const uint32_t *coff /*[L]*/,
+                                                  const float *oldbase, const uint32_t *ooff /*[L]*/, int j0,
+                                                  int koff) {
+        if constexpr (LL == 1) {
+            const f32x4 c = *reinterpret_cast<const f32x4 *>(C + coff[j0] + koff);
+            const f32x4 o = *reinterpret_cast<const f32x4 *>(oldbase + ooff[j0] + koff);
+            return c - o;
+        } else {
+            const f32x4 lo = build<LL / 2>(C, coff, oldbase, ooff, j0, koff);
+            const f32x4 hi = build<LL / 2>(C, coff, oldbase, ooff, j0 + LL / 2, koff);
+            return lo + hi;
+        }
+    }
+};
+
+template <int L, int KI, bool OLD_LDS>
+__global__ void __launch_bounds__(256)
+k_pair(const float *__restrict__ C, const uint8_t *__restrict__ idx, const float *__restrict__ E,
+       const uint8_t *__restrict__ tup_in /*[B][Gin][KI][L]*/, const float *__restrict__ S_in /*[B][Gin][KI]*/,
+       long B, int N, int K, int Dp, int Gout, int keep, uint8_t *__restrict__ tup_out /*[B][Gout][keep][2L]*/,
+       float *__restrict__ S_out, uint8_t *__restrict__ idx_final) {
+    constexpr int TI = (KI + 15) / 16;
+    constexpr int VPL = TI * TI * 4;
+    constexpr int M = KI * KI;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    const int wpb = blockDim.x >> 6;
+    const long w = (long)blockIdx.x * wpb + wave;
+    const bool active = w < B * Gout;
+    const long b = active ? w / Gout : 0;
+    const int go = active ? (int)(w % Gout) : 0;
+    const int r = lane & 15, g = lane >> 4;
+    const int Gin = 2 * Gout;
+    const int ge = 2 * go, gd = 2 * go + 1;
+
+    // old rows of the 2L codebooks this pair of groups covers: codebooks (2*go)*L .. +2L-1
+    const int n0 = ge * L;
+    float *old_lds = reinterpret_cast<float *>(smem) + (size_t)wave * 2 * L * Dp;
+    if (OLD_LDS) {
+        if (active) {
+            for (int j = 0; j < 2 * L; ++j) {
+                const float *src = C + ((long)(n0 + j) * K + idx[b * N + n0 + j]) * Dp;
+                for (int q = lane; q < Dp / 4; q += 64)
+                    *reinterpret_cast<f32x4 *>(old_lds + (size_t)j * Dp + 4 * q) =
+                        *reinterpret_cast<const f32x4 *>(src + 4 * q);
+            }
+        }
+        __syncthreads();
+    }
+    if (!active) return;
+
+    // per-lane operand rows: candidate 16*ti + r of the even group (MFMA A) and of the odd group (B)
+    uint32_t coffA[TI][L], coffB[TI][L], ooffA[L], ooffB[L];
+    bool validA[TI], validB[TI];
+    const uint8_t *te = tup_in + ((b * Gin + ge) * KI) * (long)L;
+    const uint8_t *to = tup_in + ((b * Gin + gd) * KI) * (long)L;
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+        if (OLD_LDS) {
+            ooffA[j] = (uint32_t)(j * Dp + 4 * g);
+            ooffB[j] = (uint32_t)((L + j) * Dp + 4 * g);
+        } else {
+            ooffA[j] = (uint32_t)(((n0 + j) * K + idx[b * N + n0 + j]) * Dp + 4 * g);
+            ooffB[j] = (uint32_t)(((n0 + L + j) * K + idx[b * N + n0 + L + j]) * Dp + 4 * g);
+        }
+    }
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti) {
+        const int cand = 16 * ti + r;
+        validA[ti] = validB[ti] = cand < KI;
+        const int cc = cand < KI ? cand : 0;
+#pragma unroll
+        for (int j = 0; j < L; ++j) {
+            coffA[ti][j] = (uint32_t)(((n0 + j) * K + te[cc * L + j]) * Dp + 4 * g);
+            coffB[ti][j] = (uint32_t)(((n0 + L + j) * K + to[cc * L + j]) * Dp + 4 * g);
+        }
+    }
+    const float *oldbase = OLD_LDS ? old_lds : C;
+
+    f32x4 acc[TI][TI];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nkb = Dp / 16;
+    for (int kb = 0; kb < nkb; ++kb) {
+        const int koff = 16 * kb;
+        f32x4 da[TI], db[TI];
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti) {
+            da[ti] = DeltaBuilder<L, OLD_LDS>::template build<L>(C, coffA[ti], oldbase, ooffA, 0, koff);
+            db[ti] = DeltaBuilder<L, OLD_LDS>::template build<L>(C, coffB[ti], oldbase, ooffB, 0, koff);
+            if (KI < 16) {  // padded rows of an 8-candidate group contribute nothing
+                if (!validA[ti]) da[ti] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (!validB[ti]) db[ti] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < TI; ++tj)
+                    acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(da[ti][i], db[tj][i], acc[ti][tj], 0, 0, 0);
+    }
+
+    // scores: lane holds rows a = 16*ti + 4*g + v, column bcol = 16*tj + r
+    const float Eb = E[b];
+    const float *Se = S_in + (b * Gin + ge) * (long)KI;
+    const float *So = S_in + (b * Gin + gd) * (long)KI;
+    float sv[VPL];
+    int sp[VPL];
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < TI; ++tj) {
+            const int bcol = 16 * tj + r;
+            const float sob = (bcol < KI) ? So[bcol < KI ? bcol : 0] : 0.f;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int a = 16 * ti + 4 * g + v;
+                const bool ok = (a < KI) && (bcol < KI);
+                const float sea = ok ? Se[ok ? a : 0] : 0.f;
+                const float val = ((sea + sob) - Eb) + 2.0f * acc[ti][tj][v];
+                const int slot = (ti * TI + tj) * 4 + v;
+                sv[slot] = ok ? val : INFINITY;
+                sp[slot] = ok ? a * KI + bcol : kBigPos;
+            }
+        }
+    float ov;
+    int op;
+    wave_select<VPL>(sv, sp, keep, M, ov, op);
+    if (lane < keep) {
+        const int a = op / KI, bb = op % KI;
+        if (idx_final != nullptr) {
+            // last step (one group, keep == 1): the tuple is the new index vector (:468-469)
+            uint8_t *o = idx_final + b * N;
+            for (int j = 0; j < L; ++j) { o[j] = te[a * L + j]; o[L + j] = to[bb * L + j]; }
+        } else {
+            uint8_t *o = tup_out + ((b * Gout + go) * (long)keep + lane) * (2 * L);
+            for (int j = 0; j < L; ++j) { o[j] = te[a * L + j]; o[L + j] = to[bb * L + j]; }
+            S_out[(b * Gout + go) * (long)keep + lane] = ov;
+        }
+    }
+}
+
+// -------------------------------------------------------------------- output
+// encode tail (quantization.py:266-275): uint8 with nibble packing when K == 16
+// (low nibble = even codebook, :269), or int64 indexes.
+__global__ void k_finalize(const uint8_t *__restrict__ idx, long B, int N, int pack, uint8_t *__restrict__ out_u8,
+                           int64_t *__restrict__ out_i64) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (out_i64 != nullptr) {
+        if (i < B * N) out_i64[i] = idx[i];
+    } else {
+        const int per = N / pack;
+        if (i < B * per) {
+            if (pack == 1) out_u8[i] = idx[i];
+            else out_u8[i] = (uint8_t)(idx[2 * i] + 16 * idx[2 * i + 1]);
+        }
+    }
+}
+
+// -------------------------------------------------------------------- decode
+// out[b][:] = sum_n C[n][index(b, n)][:D], n ascending (quantization.py:131-148).
+// One wave per vector; codes are uint8 or int64, optionally packed r digits per code
+// (least significant first, _maybe_separate_indexes :551-573).
+template <typename CodeT>
+__global__ void k_decode(const CodeT *__restrict__ codes, int per_row, long B, const float *__restrict__ C, int N,
+                         int K, int D, int Dp, float *__restrict__ out) {
+    const long b = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int lane = lane_id();
+    const int rep = N / per_row;
+    const CodeT *cb = codes + b * per_row;
+    float *ob = out + b * D;
+    const bool vec_ok = ((D & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+    for (int q = lane; q < Dp / 4; q += 64) {
+        f32x4 t = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int n = 0; n < N; ++n) {
+            long code = (long)cb[n / rep];
+            int digit = n % rep;
+            for (int d = 0; d < digit; ++d) code /= K;
+            const int k = (int)(code % K) & (K - 1);
+            const f32x4 c = *reinterpret_cast<const f32x4 *>(C + ((long)n * K + k) * Dp + 4 * q);
+            t = (n == 0) ? c : t + c;
+        }
+        if (vec_ok && 4 * q + 3 < D) {
+            *reinterpret_cast<f32x4 *>(ob + 4 * q) = t;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (4 * q + c < D) ob[4 * q + c] = t[c];
+        }
+    }
+}
+
+}  // namespace mcq

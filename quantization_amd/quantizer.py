@@ -1,0 +1,310 @@
+"""Host-side mirror of `quantization.Quantizer` (reference:
+/root/reference/quantization/quantization.py:16-573) over the MI355X kernels.
+
+Same constructor, parameters, state-dict layout and method names, so a reference
+checkpoint loads unchanged and callers switch by changing the import.  The index
+search (`encode`, `_compute_indexes`) and the inference `decode` run in
+libmcq_hip.so (include/mcq.h); torch is used for device memory, streams and the
+differentiable parts of `compute_loss`.  There is no CPU fallback.
+"""
+import binascii
+import ctypes
+import math
+import os
+
+import torch
+from torch import Tensor, nn
+
+from . import _lib
+
+
+def _is_pow2(n: int) -> bool:
+    return n > 0 and (n & (n - 1)) == 0
+
+
+def _scale_exp(scale: Tensor, speed: float) -> float:
+    """exp(scale * speed) as the reference forms it on the host (fp32 multiply, fp32
+    exp; quantization.py:78, :278) -- evaluated on CPU so that the derived state is
+    the same on every machine regardless of the device's exp()."""
+    return float((scale.detach().to("cpu", torch.float32) * speed).exp())
+
+
+class Quantizer(nn.Module):
+    """Trainable direct-sum (multi-codebook) vector quantizer; quantization.py:16-55."""
+
+    def __init__(self, dim: int, codebook_size: int, num_codebooks: int):
+        super().__init__()
+        assert _is_pow2(codebook_size)      # quantization.py:35
+        assert _is_pow2(num_codebooks)      # quantization.py:36
+        self.dim = dim
+        self.codebook_size = codebook_size
+        self.num_codebooks = num_codebooks
+        self.to_logits = nn.Linear(dim, codebook_size * num_codebooks)
+        # centers start as a copy of the classifier weights (quantization.py:41-42)
+        self.centers = nn.Parameter(
+            self.to_logits.weight.detach().clone().reshape(num_codebooks, codebook_size, dim))
+        self.logits_scale = nn.Parameter(torch.zeros(()))
+        self.centers_scale = nn.Parameter(torch.zeros(()))
+        self.scale_speed = 10.0
+        id_bytes = binascii.b2a_hex(os.urandom(4))           # quantization.py:53-55
+        self.id_str = id_bytes.decode("utf-8")
+        self.register_buffer("id_buf", torch.tensor(list(id_bytes), dtype=torch.uint8))
+        self._prep = None       # (key, device buffer) of derived state for the kernels
+        self._ws = None         # cached encode workspace (device uint8 tensor)
+
+    # ------------------------------------------------------------ bookkeeping
+    def load_state_dict(self, *args, **kwargs):
+        ret = super().load_state_dict(*args, **kwargs)
+        self.id_str = bytes(self.id_buf.tolist()).decode("utf-8")   # quantization.py:57-59
+        self._prep = None
+        return ret
+
+    def get_id(self) -> str:
+        return self.id_str
+
+    def show_init_invocation(self) -> str:
+        return (f"quantization.Quantizer(dim={self.dim}, codebook_size={self.codebook_size}, "
+                f"num_codebooks={self.num_codebooks})")
+
+    def get_centers(self) -> Tensor:
+        return (self.centers_scale * self.scale_speed).exp() * self.centers   # quantization.py:77-79
+
+    def get_data_mean(self) -> Tensor:
+        return self.get_centers().mean(dim=1).sum(dim=0).detach()             # quantization.py:67-75
+
+    # --------------------------------------------------------- derived state
+    def _prepared(self) -> Tensor:
+        """Device blob consumed by mcq_encode / mcq_decode; rebuilt only when a parameter changed."""
+        ps = (self.centers, self.centers_scale, self.logits_scale, self.to_logits.weight, self.to_logits.bias)
+        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in ps)
+        if self._prep is not None and self._prep[0] == key:
+            return self._prep[1]
+        dev = self.centers.device
+        if dev.type != "cuda":
+            raise _lib.McqError("quantization_amd.Quantizer runs on a HIP device only: move the module with "
+                                ".to('cuda') (the CPU oracle under oracle/ is test infrastructure)")
+        L = _lib.lib()
+        N, K, D = self.num_codebooks, self.codebook_size, self.dim
+        blob = torch.empty(L.mcq_prepared_bytes(N, K, D), dtype=torch.uint8, device=dev)
+        centers = self.centers.detach().to(torch.float32).contiguous()
+        weight = self.to_logits.weight.detach().to(torch.float32).contiguous()
+        bias = self.to_logits.bias.detach().to(torch.float32).contiguous()
+        self._cscale_exp = _scale_exp(self.centers_scale, self.scale_speed)
+        self._lscale_exp = _scale_exp(self.logits_scale, self.scale_speed)
+        with torch.cuda.device(dev):
+            st = torch.cuda.current_stream(dev).cuda_stream
+            rc = L.mcq_prepare(centers.data_ptr(), self._cscale_exp, weight.data_ptr(), bias.data_ptr(), N, K, D,
+                               blob.data_ptr(), st)
+        _lib.check(rc, "mcq_prepare")
+        # the inputs above may be temporaries: the stream orders their reuse after the kernel
+        self._prep = (key, blob)
+        return blob
+
+    def _check_domain(self):
+        assert 16 <= self.codebook_size <= 256, (
+            "the index search needs 16 <= codebook_size <= 256 (the reference itself fails below 16, "
+            "quantization.py:506, and needs <= 256 for byte codes, :271)")
+        assert self.num_codebooks <= 64
+
+    def _workspace(self, B: int, dev) -> Tensor:
+        L = _lib.lib()
+        need = L.mcq_encode_workspace_bytes(B, self.num_codebooks, self.codebook_size, self.dim)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        return self._ws
+
+    def _search(self, x2d: Tensor, iters: int, as_bytes: bool) -> Tensor:
+        """x2d (B, dim) on the HIP device -> uint8 codes or int64 indexes via mcq_encode."""
+        self._check_domain()
+        if not x2d.is_cuda:
+            raise _lib.McqError("quantization_amd: the index search runs on a HIP device tensor only "
+                                "(no CPU fallback)")
+        L = _lib.lib()
+        N, K, D = self.num_codebooks, self.codebook_size, self.dim
+        x2d = x2d.detach().to(torch.float32).contiguous()
+        B = x2d.shape[0]
+        dev = x2d.device
+        blob = self._prepared()
+        pack = 2 if (as_bytes and K == 16 and N >= 2) else 1
+        if as_bytes:
+            out = torch.empty((B, N // pack), dtype=torch.uint8, device=dev)
+        else:
+            out = torch.empty((B, N), dtype=torch.int64, device=dev)
+        if B == 0:
+            return out
+        ws = self._workspace(B, dev)
+        with torch.cuda.device(dev):
+            st = torch.cuda.current_stream(dev).cuda_stream
+            rc = L.mcq_encode(x2d.data_ptr(), B, blob.data_ptr(), self._lscale_exp, N, K, D, int(iters),
+                              out.data_ptr() if as_bytes else None, None if as_bytes else out.data_ptr(),
+                              ws.data_ptr(), ws.numel(), st)
+        _lib.check(rc, "mcq_encode")
+        return out
+
+    # ------------------------------------------------------------ public API
+    def encode(self, x: Tensor, refine_indexes_iters: int = 5, as_bytes: bool = True) -> Tensor:
+        """x (*, dim) -> uint8 (*, num_codebooks) [packed two per byte when codebook_size == 16],
+        or int64 (*, num_codebooks) with as_bytes=False.  quantization.py:244-275."""
+        x2d = x.reshape(-1, self.dim)
+        if as_bytes:
+            assert self.codebook_size <= 256                              # quantization.py:271
+        codes = self._search(x2d, refine_indexes_iters, as_bytes)
+        return codes.reshape(*x.shape[:-1], -1)
+
+    def _compute_indexes(self, x: Tensor, refine_indexes_iters: int = 3) -> Tensor:
+        """x (B, dim) -> int64 (B, num_codebooks).  quantization.py:281-305."""
+        assert x.ndim == 2 and x.shape[1] == self.dim                     # quantization.py:293
+        return self._search(x, refine_indexes_iters, as_bytes=False)
+
+    def _logits(self, x: Tensor) -> Tensor:
+        x = (self.logits_scale * self.scale_speed).exp() * x              # quantization.py:277-279
+        return self.to_logits(x)
+
+    def _maybe_separate_indexes(self, indexes: Tensor) -> Tensor:
+        """Undo the byte packing of encode(); quantization.py:551-573 (torch ops; the kernel
+        path of decode() unpacks in-kernel)."""
+        B = indexes.shape[0]
+        if indexes.shape[-1] != self.num_codebooks:
+            n = indexes.shape[-1]
+            rep = self.num_codebooks // n
+            assert rep in [2, 4, 8, 16] and self.num_codebooks == n * rep   # quantization.py:566
+            div = self.codebook_size ** torch.arange(rep, device=indexes.device)
+            indexes = (indexes.unsqueeze(2).expand(B, n, rep) // div) % self.codebook_size
+            indexes = indexes.reshape(B, self.num_codebooks)
+        assert indexes.shape == (B, self.num_codebooks)
+        return indexes
+
+    def decode(self, indexes: Tensor) -> Tensor:
+        """codes (*, num_codebooks) or packed (*, num_codebooks / r), any integer dtype ->
+        fp32 (*, dim) sum of the chosen scaled centers.  quantization.py:117-148.
+        Differentiable w.r.t. centers / centers_scale when autograd is recording."""
+        lead = indexes.shape[:-1]
+        per_row = indexes.shape[-1]
+        flat = indexes.reshape(-1, per_row)
+        rep = self.num_codebooks // per_row if per_row else 0
+        assert per_row * rep == self.num_codebooks and rep in [1, 2, 4, 8, 16]   # quantization.py:566
+        needs_grad = torch.is_grad_enabled() and (self.centers.requires_grad or self.centers_scale.requires_grad)
+        if needs_grad:
+            return _DecodeFn.apply(self, flat, self.centers, self.centers_scale).reshape(*lead, self.dim)
+        return self._decode_kernel(flat).reshape(*lead, self.dim)
+
+    def _decode_kernel(self, flat: Tensor) -> Tensor:
+        self._check_domain()
+        if not flat.is_cuda:
+            raise _lib.McqError("quantization_amd: decode runs on a HIP device tensor only (no CPU fallback)")
+        L = _lib.lib()
+        N, K, D = self.num_codebooks, self.codebook_size, self.dim
+        if flat.dtype not in (torch.uint8, torch.int64):
+            flat = flat.to(torch.int64)
+        flat = flat.contiguous()
+        B, per_row = flat.shape
+        out = torch.empty((B, D), dtype=torch.float32, device=flat.device)
+        if B == 0:
+            return out
+        blob = self._prepared()
+        with torch.cuda.device(flat.device):
+            st = torch.cuda.current_stream(flat.device).cuda_stream
+            rc = L.mcq_decode(flat.data_ptr(), 1 if flat.dtype == torch.uint8 else 8, per_row, B, blob.data_ptr(),
+                              N, K, D, out.data_ptr(), st)
+        _lib.check(rc, "mcq_decode")
+        return out
+
+    def logits_kernel(self, x: Tensor) -> Tensor:
+        """Logits as the index-search kernel forms them (test hook; mcq_logits)."""
+        L = _lib.lib()
+        x2d = x.reshape(-1, self.dim).detach().to(torch.float32).contiguous()
+        N, K, D = self.num_codebooks, self.codebook_size, self.dim
+        out = torch.empty((x2d.shape[0], N * K), dtype=torch.float32, device=x2d.device)
+        blob = self._prepared()
+        with torch.cuda.device(x2d.device):
+            st = torch.cuda.current_stream(x2d.device).cuda_stream
+            rc = L.mcq_logits(x2d.data_ptr(), x2d.shape[0], blob.data_ptr(), self._lscale_exp, N, K, D,
+                              out.data_ptr(), st)
+        _lib.check(rc, "mcq_logits")
+        return out
+
+    # -------------------------------------------------------------- training
+    def compute_loss(self, x: Tensor, refine_indexes_iters: int = 0):
+        """(rel_reconstruction_loss, logprob_loss, logits_entropy_loss, index_entropy_loss);
+        quantization.py:184-242.  The (non-differentiable) index search runs in the HIP
+        kernels; the losses are torch autograd ops on the same device."""
+        x = x.reshape(-1, self.dim)
+        B = x.shape[0]
+        N, K = self.num_codebooks, self.codebook_size
+        indexes = self._compute_indexes(x, refine_indexes_iters)
+        x_approx = self.decode(indexes)
+        tot_error = x_approx - x
+        rel_reconstruction_loss = (tot_error ** 2).sum() / (((x - self.get_data_mean()) ** 2).sum() + 1.0e-20)
+
+        logprobs = self._logits(x).reshape(B, N, K).log_softmax(dim=2)
+        logprob_loss = -torch.gather(logprobs, dim=2, index=indexes.unsqueeze(2)).mean()
+
+        counts = torch.zeros(B, N, K, device=x.device)
+        counts.scatter_(dim=2, index=indexes.unsqueeze(2), src=torch.ones(1, 1, 1, device=x.device).expand(B, N, K))
+        avg_counts = counts.mean(dim=0) + 1.0e-20
+        index_entropy = -(avg_counts * avg_counts.log()).sum(dim=1).mean()
+
+        probs = logprobs.exp().mean(dim=0) + 1.0e-20
+        logits_entropy = -(probs * probs.log()).sum(dim=1).mean()
+        ref_entropy = math.log(K)
+        logits_entropy_loss = (ref_entropy - logits_entropy) / ref_entropy
+        index_entropy_loss = (ref_entropy - index_entropy) / ref_entropy
+        return rel_reconstruction_loss, logprob_loss, logits_entropy_loss, index_entropy_loss
+
+    def compute_codebook_correlations(self) -> Tensor:
+        """(N, N) subspace-sharing diagnostic; quantization.py:150-181."""
+        centers = self.get_centers().detach()
+        centers = centers - centers.mean(dim=1, keepdim=True)
+        var = torch.matmul(centers.transpose(1, 2), centers).reshape(self.num_codebooks, self.dim * self.dim)
+        cross = torch.matmul(var, var.t())
+        norm = cross.diag() ** -0.5
+        return cross * (norm.unsqueeze(0) * norm.unsqueeze(1))
+
+    def get_product_quantizer(self) -> "Quantizer":
+        """codebook_size**2 entries, half the codebooks: entry k1*K + k2 of new codebook c is
+        the sum of entry k1 of codebook 2c and entry k2 of codebook 2c+1, for the centers and
+        for the classifier rows and biases alike.  quantization.py:81-112."""
+        K, N, D = self.codebook_size, self.num_codebooks, self.dim
+        ans = Quantizer(D, K * K, N // 2).to(self.centers.device)
+        with torch.no_grad():
+            ans.logits_scale.fill_(self.logits_scale.item())
+            ans.centers_scale.fill_(self.centers_scale.item())
+            ans.scale_speed = self.scale_speed
+
+            def pair_sum(t):  # t: (N, K, ...) -> (N/2, K*K, ...), k_out = k1*K + k2
+                even, odd = t[0::2], t[1::2]
+                s = even.unsqueeze(2) + odd.unsqueeze(1)
+                return s.reshape(N // 2, K * K, *t.shape[2:])
+
+            ans.to_logits.weight.copy_(pair_sum(self.to_logits.weight.reshape(N, K, D)).reshape(-1, D))
+            ans.to_logits.bias.copy_(pair_sum(self.to_logits.bias.reshape(N, K)).reshape(-1))
+            ans.centers.copy_(pair_sum(self.centers))
+        return ans
+
+
+class _DecodeFn(torch.autograd.Function):
+    """decode() under autograd: forward in the HIP kernel, backward = the scatter-add of
+    d(out) into the chosen rows (what torch.gather/sum differentiate to, quantization.py:142-147)."""
+
+    @staticmethod
+    def forward(ctx, module, flat, centers, centers_scale):
+        out = module._decode_kernel(flat)
+        idx = module._maybe_separate_indexes(flat.to(torch.int64))
+        ctx.module = module
+        ctx.save_for_backward(idx, centers, centers_scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        idx, centers, centers_scale = ctx.saved_tensors
+        m = ctx.module
+        N, K, D = centers.shape
+        scale = (centers_scale.detach() * m.scale_speed).exp()
+        # d/d(scaled centers): rows receive the sum of grad_out over the vectors that chose them
+        g = torch.zeros(N * K, D, dtype=grad_out.dtype, device=grad_out.device)
+        rows = (idx + torch.arange(N, device=idx.device) * K).reshape(-1)
+        g.index_add_(0, rows, grad_out.unsqueeze(1).expand(-1, N, -1).reshape(-1, D))
+        g = g.reshape(N, K, D)
+        g_centers = g * scale
+        g_scale = (g * centers.detach()).sum() * scale * m.scale_speed
+        return None, None, g_centers, g_scale

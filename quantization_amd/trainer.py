@@ -1,0 +1,173 @@
+"""Host-side mirror of `quantization.QuantizerTrainer`
+(/root/reference/quantization/quantization.py:577-742)."""
+import logging
+import random
+import time
+
+import torch
+
+from .quantizer import Quantizer
+
+
+class QuantizerTrainer(object):
+    """Two-phase trainer: codebook_size 16 with 2*bytes_per_frame codebooks for
+    `phase_one_iters` steps, then the product quantizer (codebook_size 256,
+    bytes_per_frame codebooks) for `phase_two_iters` more.  quantization.py:578-631.
+
+    Extension (not in the reference, which is single-process): `process_group`.
+    When given (or when torch.distributed is initialised and `data_parallel=True`),
+    every rank steps on its own shard of the batch and the gradients are summed with
+    one all-reduce per step so that all ranks hold the parameters a single process
+    would have computed on the concatenated batch (multi-GPU)."""
+
+    def __init__(self, dim: int, bytes_per_frame: int, device: torch.device, phase_one_iters: int = 10000,
+                 phase_two_iters: int = 10000, lr: float = 0.005, process_group=None, data_parallel: bool = False):
+        super().__init__()
+        assert bytes_per_frame in [1, 2, 4, 8, 16, 32]                   # quantization.py:614
+        self.phase_one_iters = phase_one_iters
+        self.phase_two_iters = phase_two_iters
+        self.cur_iter = 0
+        self.lr = lr
+        self.two_iter_prob = 0.5
+        self.quantizer = Quantizer(dim=dim, codebook_size=16, num_codebooks=bytes_per_frame * 2).to(device)
+        self.start_time = time.time()
+        self.process_group = process_group
+        self.data_parallel = data_parallel or process_group is not None
+        if self.data_parallel:
+            self._broadcast_parameters()
+        self._init_optimizer()
+
+    # ------------------------------------------------------------ data parallel
+    def _dist(self):
+        import torch.distributed as dist
+        return dist
+
+    def _world(self) -> int:
+        if not self.data_parallel:
+            return 1
+        dist = self._dist()
+        return dist.get_world_size(self.process_group) if dist.is_initialized() else 1
+
+    def _broadcast_parameters(self):
+        """All ranks start from rank 0's random initialisation."""
+        if self._world() == 1:
+            return
+        dist = self._dist()
+        src = dist.get_global_rank(self.process_group, 0) if self.process_group is not None else 0
+        for t in list(self.quantizer.parameters()) + list(self.quantizer.buffers()):
+            dist.broadcast(t.data, src=src, group=self.process_group)
+        self.quantizer.id_str = bytes(self.quantizer.id_buf.tolist()).decode("utf-8")
+
+    def _all_reduce_flat(self, tensors):
+        """One flat-bucket sum all-reduce (RCCL over xGMI on the GPU node; gloo in CPU tests)."""
+        dist = self._dist()
+        flat = torch.cat([t.reshape(-1) for t in tensors])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.process_group)
+        off = 0
+        for t in tensors:
+            n = t.numel()
+            t.copy_(flat[off:off + n].reshape(t.shape))
+            off += n
+
+    # ----------------------------------------------------------------- API
+    def done(self) -> bool:
+        ans = self.cur_iter > self.phase_one_iters + self.phase_two_iters   # quantization.py:633-639
+        if ans:
+            elapsed_time = time.time() - self.start_time
+            logging.info(f"Elapsed time, training model of dim={self.quantizer.dim}, "
+                         f"num_codebooks={self.quantizer.num_codebooks}, "
+                         f"codebook_size={self.quantizer.codebook_size}, is: {elapsed_time:.2f} seconds.")
+        return ans
+
+    def step(self, x: torch.Tensor) -> None:
+        """One optimisation step on frames x (*, dim).  quantization.py:641-719."""
+        x = x.reshape(-1, self.quantizer.dim)
+        num_iters = 2 if random.random() < self.two_iter_prob else 1          # quantization.py:651
+        if self._world() > 1:
+            losses = self._dp_losses(x, num_iters)
+        else:
+            losses = self.quantizer.compute_loss(x, num_iters)
+        reconstruction_loss, logprob_loss, logits_entropy_loss, index_entropy_loss = losses
+
+        if self.cur_iter % 200 == 0:                                        # quantization.py:656-671
+            det_losses = [float("%.3f" % self.quantizer.compute_loss(x, j)[0].item()) for j in range(6)]
+            phase = 1 if self.cur_iter <= self.phase_one_iters else 2
+            i = self.cur_iter - self.phase_one_iters if phase > 1 else self.cur_iter
+            logging.info(f"phase={phase}/2, iter={i}, "
+                         f"dim,nc,csz={self.quantizer.dim},{self.quantizer.num_codebooks},"
+                         f"{self.quantizer.codebook_size}, loss_per_iter={det_losses}, "
+                         f"logprob_loss={logprob_loss.item():.3f}, "
+                         f"logits_entropy_loss={logits_entropy_loss.item():.3f}, "
+                         f"index_entropy_loss={index_entropy_loss.item():.3f}")
+        if self.cur_iter % 2000 == 0 and self.cur_iter > 0:                 # quantization.py:673-675
+            logging.info(f"correlations = {self.quantizer.compute_codebook_correlations()}")
+
+        entropy_scale = 0.01                                                # quantization.py:682
+        tot_loss = reconstruction_loss + logprob_loss + logits_entropy_loss * entropy_scale
+        self.last_losses = tuple(float(v.detach()) for v in losses)
+        tot_loss.backward()
+        if self._world() > 1:
+            self._all_reduce_flat([p.grad for p in self.quantizer.parameters()])
+        self.optim.step()
+        self.optim.zero_grad()
+        self.scheduler.step()
+        if self.cur_iter == self.phase_one_iters:                           # quantization.py:717-718
+            self._begin_second_phase()
+        self.cur_iter += 1
+
+    def _dp_losses(self, x, num_iters):
+        """compute_loss on this rank's shard, arranged so that SUMMING the ranks' gradients gives
+        the gradient of the loss on the concatenated batch (quantization.py:211-242 on B_total
+        frames).  Every term of that loss is a ratio or a function of batch sums, so the sums
+        are all-reduced in the forward pass and re-enter the graph as constants plus the local
+        term (gradient of the global sum w.r.t. local parameters uses the local part only)."""
+        import math
+        q = self.quantizer
+        B = x.shape[0]
+        N, K = q.num_codebooks, q.codebook_size
+        indexes = q._compute_indexes(x, num_iters)
+        x_approx = q.decode(indexes)
+        num_local = ((x_approx - x) ** 2).sum()
+        den_local = ((x - q.get_data_mean()) ** 2).sum()
+        logprobs = q._logits(x).reshape(B, N, K).log_softmax(dim=2)
+        chosen_local = torch.gather(logprobs, dim=2, index=indexes.unsqueeze(2)).sum()
+        probs_local = logprobs.exp().sum(dim=0)                              # (N, K)
+        counts_local = torch.zeros(N, K, device=x.device)
+        counts_local.scatter_add_(1, indexes.t().contiguous(), torch.ones(N, B, device=x.device))
+        stats = [num_local.detach().clone().reshape(1), den_local.detach().clone().reshape(1),
+                 chosen_local.detach().clone().reshape(1), probs_local.detach().clone(),
+                 counts_local.clone(), torch.tensor([float(B)], device=x.device)]
+        self._all_reduce_flat(stats)
+        num_g, den_g, chosen_g, probs_g, counts_g, Bg = stats
+        Bt = Bg.item()
+
+        def with_local_grad(global_value, local):   # value = global, gradient = d(local)
+            return global_value + (local - local.detach())
+
+        rel = with_local_grad(num_g.squeeze(0), num_local) / (den_g.squeeze(0) + 1.0e-20)
+        logprob_loss = -with_local_grad(chosen_g.squeeze(0), chosen_local) / (Bt * N)
+        probs = with_local_grad(probs_g, probs_local) / Bt + 1.0e-20
+        logits_entropy = -(probs * probs.log()).sum(dim=1).mean()
+        avg_counts = counts_g / Bt + 1.0e-20
+        index_entropy = -(avg_counts * avg_counts.log()).sum(dim=1).mean()
+        ref_entropy = math.log(K)
+        return (rel, logprob_loss, (ref_entropy - logits_entropy) / ref_entropy,
+                (ref_entropy - index_entropy) / ref_entropy)
+
+    def _init_optimizer(self):
+        # quantization.py:722-730
+        self.optim = torch.optim.Adam(self.quantizer.parameters(), lr=self.lr, betas=(0.9, 0.98), eps=1e-9,
+                                      weight_decay=1.0e-06)
+        self.scheduler = torch.optim.lr_scheduler.StepLR(
+            self.optim, step_size=(self.phase_one_iters if self.cur_iter == 0 else self.phase_two_iters) / 4,
+            gamma=0.5)
+
+    def _begin_second_phase(self):
+        # quantization.py:732-738
+        self.quantizer = self.quantizer.get_product_quantizer()
+        self.lr *= 0.5
+        self._init_optimizer()
+
+    def get_quantizer(self) -> Quantizer:
+        assert self.cur_iter >= self.phase_one_iters + self.phase_two_iters   # quantization.py:740-742
+        return self.quantizer

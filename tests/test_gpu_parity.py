@@ -1,0 +1,156 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle and with the
+fixtures captured from the reference.  Run on the MI355X: pytest -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+from golden import fixtures, gen
+from oracle.oracle import OracleQuantizer
+
+pytestmark = pytest.mark.gpu
+
+ALL = fixtures.names()
+
+
+def load_quantizer(state, D, K, N, device="cuda:0"):
+    from quantization_amd import Quantizer
+    q = Quantizer(D, K, N)
+    sd = q.state_dict()
+    for k, v in state.items():
+        sd[k] = torch.from_numpy(np.asarray(v))
+    q.load_state_dict(sd)
+    return q.to(device)
+
+
+def oracle_of(state):
+    return OracleQuantizer(state["centers"], float(state["centers_scale"]), state["to_logits.weight"],
+                           state["to_logits.bias"], float(state["logits_scale"]))
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_codes_bit_exact_vs_oracle_and_reference(name):
+    fx = fixtures.load(name)
+    q = load_quantizer(fx["state"], fx["D"], fx["K"], fx["N"])
+    o = oracle_of(fx["state"])
+    x = torch.from_numpy(fx["x"]).cuda()
+    for it in fx["iters"]:
+        got = q.encode(x, it, as_bytes=False)
+        assert got.dtype == torch.int64 and tuple(got.shape) == (fx["B"], fx["N"])
+        got = got.cpu().numpy()
+        want = o.compute_indexes(fx["x"], it)
+        nbad = int((got != want).any(axis=1).sum())
+        assert nbad == 0, f"{name} iters={it}: {nbad} vectors differ from the oracle"
+        fixtures.check_codes(fx, it, got, f"{name} iters={it} (HIP vs reference fixture)")
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_bytes_and_decode(name):
+    fx = fixtures.load(name)
+    q = load_quantizer(fx["state"], fx["D"], fx["K"], fx["N"])
+    o = oracle_of(fx["state"])
+    it = fx["iters"][-1]
+    x = torch.from_numpy(fx["x"]).cuda()
+    b = q.encode(x, it)  # as_bytes=True
+    assert b.dtype == torch.uint8
+    assert np.array_equal(b.cpu().numpy(), o.encode(fx["x"], it))
+    ref_bytes = torch.from_numpy(fx[f"bytes_it{it}"]).cuda()
+    ref_codes = torch.from_numpy(fx[f"codes_it{it}"].astype(np.int64)).cuda()
+    y = q.decode(ref_bytes)
+    assert y.dtype == torch.float32 and tuple(y.shape) == (fx["B"], fx["D"])
+    y = y.cpu().numpy()
+    assert np.array_equal(y, o.decode(fx[f"bytes_it{it}"]))            # bit-exact vs the oracle
+    assert np.array_equal(y, q.decode(ref_codes).cpu().numpy())        # packed == unpacked int64
+    head = fx["decode_head"]
+    scale = np.abs(head).max()
+    assert np.abs(y[:16] - head).max() <= 1e-5 * scale                 # 1e-5 relative vs the reference
+    assert np.allclose((y.astype(np.float64) ** 2).sum(axis=1), fx["decode_rowsumsq"], rtol=1e-5)
+    # int32 codes and a leading batch shape, as decode accepts any integer dtype / (*, N)
+    y2 = q.decode(ref_codes.to(torch.int32).reshape(-1, 2, fx["N"])[:4])
+    assert tuple(y2.shape) == (4, 2, fx["D"])
+    assert np.array_equal(y2.reshape(-1, fx["D"]).cpu().numpy(), y[:8])
+
+
+def test_logits_bit_exact_vs_oracle():
+    fx = fixtures.load("trained_d64_b8_p2")
+    q = load_quantizer(fx["state"], fx["D"], fx["K"], fx["N"])
+    o = oracle_of(fx["state"])
+    x = fx["x"][:200]
+    got = q.logits_kernel(torch.from_numpy(x).cuda()).cpu().numpy()
+    assert np.array_equal(got, o.logits(x))
+
+
+def test_shapes_ragged_and_empty():
+    fx = fixtures.load("synth_d40_k64_n8")
+    q = load_quantizer(fx["state"], fx["D"], fx["K"], fx["N"])
+    o = oracle_of(fx["state"])
+    x = fx["x"]
+    for B in (1, 3, 63, 64, 65, 130):
+        got = q.encode(torch.from_numpy(x[:B]).cuda(), 2).cpu().numpy()
+        assert np.array_equal(got, o.encode(x[:B], 2)), B
+    e = q.encode(torch.zeros(0, fx["D"]).cuda(), 2)
+    assert tuple(e.shape) == (0, fx["N"]) and e.dtype == torch.uint8
+    assert tuple(q.decode(e).shape) == (0, fx["D"])
+    lead = q.encode(torch.from_numpy(x[:24]).cuda().reshape(2, 3, 4, fx["D"]), 1)
+    assert tuple(lead.shape) == (2, 3, 4, fx["N"])
+    assert np.array_equal(lead.reshape(24, -1).cpu().numpy(), o.encode(x[:24], 1))
+
+
+def test_exact_ties_and_degenerate_inputs():
+    N, K, D = 4, 16, 16
+    centers = np.zeros((N, K, D), np.float32)
+    centers[:, :, 0] = 1.0
+    state = {"centers": centers, "centers_scale": np.float32(0), "logits_scale": np.float32(0),
+             "to_logits.weight": np.zeros((N * K, D), np.float32), "to_logits.bias": np.zeros(N * K, np.float32)}
+    q = load_quantizer(state, D, K, N)
+    o = oracle_of(state)
+    x = np.zeros((5, D), np.float32)
+    got = q.encode(torch.from_numpy(x).cuda(), 2, as_bytes=False).cpu().numpy()
+    assert np.array_equal(got, o.compute_indexes(x, 2)) and (got == 0).all()
+    # duplicated codebook entries with real data: ties everywhere between the twins
+    sd = gen.synthetic_state(5, 32, 32, 4)
+    sd["centers"][:, 16:] = sd["centers"][:, :16]
+    sd["to_logits.weight"] = sd["to_logits.weight"].reshape(4, 32, 32)
+    sd["to_logits.weight"][:, 16:] = sd["to_logits.weight"][:, :16]
+    sd["to_logits.weight"] = sd["to_logits.weight"].reshape(128, 32)
+    sd["to_logits.bias"].reshape(4, 32)[:, 16:] = sd["to_logits.bias"].reshape(4, 32)[:, :16]
+    q = load_quantizer(sd, 32, 32, 4)
+    o = oracle_of(sd)
+    x = gen.make_gaussian(3, 300, 32)
+    got = q.encode(torch.from_numpy(x).cuda(), 3, as_bytes=False).cpu().numpy()
+    assert np.array_equal(got, o.compute_indexes(x, 3))
+    assert (got < 16).all()
+
+
+def test_full_size_properties_config_b():
+    """BASELINE config B (dim 512, 8 bytes, B = 65,536): size-independent properties."""
+    D, K, N, B = 512, 256, 8, 65536
+    sd = gen.synthetic_state(103, D, K, N)
+    q = load_quantizer(sd, D, K, N)
+    o = oracle_of(sd)
+    x = gen.make_gaussian(1234, B, D)
+    xd = torch.from_numpy(x).cuda()
+    codes = q.encode(xd, 5)
+    assert tuple(codes.shape) == (B, N) and codes.dtype == torch.uint8
+    # (1) a random sample of rows against the oracle, bit-exact
+    rows = np.random.RandomState(0).choice(B, 768, replace=False)
+    assert np.array_equal(codes.cpu().numpy()[rows], o.encode(x[rows], 5))
+    # (2) the result does not depend on how the batch is cut (chunk independence)
+    part = torch.cat([q.encode(xd[:1000], 5), q.encode(xd[1000:4099], 5)])
+    assert torch.equal(part, codes[:4099])
+    # (3) encode(decode(c)) reproduces... decode is exact, and refinement does not increase the error much:
+    y5 = q.decode(codes)
+    y0 = q.decode(q.encode(xd, 0))
+    e5 = ((y5 - xd) ** 2).sum(dim=1)
+    e0 = ((y0 - xd) ** 2).sum(dim=1)
+    assert float(e5.sum()) < float(e0.sum())
+    assert float((e5 <= e0 * (1 + 1e-5)).float().mean()) > 0.98
+    # (4) decode is linear in the one-hot selection: sum of single-codebook decodes
+    rel = float(e5.sum() / (xd ** 2).sum())
+    assert 0.0 < rel < 1.0
+
+
+def test_cpu_tensor_is_rejected_loudly():
+    fx = fixtures.load("synth_d32_k256_n2")
+    q = load_quantizer(fx["state"], fx["D"], fx["K"], fx["N"])
+    with pytest.raises(Exception):
+        q.encode(torch.from_numpy(fx["x"][:4]), 1)
