@@ -149,7 +149,7 @@ class Quantizer(nn.Module):
         if as_bytes:
             assert self.codebook_size <= 256                              # quantization.py:271
         codes = self._search(x2d, refine_indexes_iters, as_bytes)
-        return codes.reshape(*x.shape[:-1], -1)
+        return codes.reshape(*x.shape[:-1], codes.shape[-1])
 
     def _compute_indexes(self, x: Tensor, refine_indexes_iters: int = 3) -> Tensor:
         """x (B, dim) -> int64 (B, num_codebooks).  quantization.py:281-305."""

@@ -9,6 +9,13 @@ from oracle.oracle import OracleQuantizer
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True)
+def _no_grad():
+    # like the reference, decode() is differentiable unless autograd is off (test_quantization.py uses no_grad)
+    with torch.no_grad():
+        yield
+
 ALL = fixtures.names()
 
 
