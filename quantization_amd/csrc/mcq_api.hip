@@ -136,11 +136,11 @@ int launch_prune0(int K, const float *S0, long BN, int keep, uint8_t *tup, float
                   hipStream_t st) {
     const unsigned grid = (unsigned)((BN + 3) / 4);
     switch (K) {
-        case 16: hipLaunchKernelGGL((k_prune0<16>), dim3(grid), dim3(256), 0, st, S0, BN, keep, tup, S, idx_final); break;
-        case 32: hipLaunchKernelGGL((k_prune0<32>), dim3(grid), dim3(256), 0, st, S0, BN, keep, tup, S, idx_final); break;
-        case 64: hipLaunchKernelGGL((k_prune0<64>), dim3(grid), dim3(256), 0, st, S0, BN, keep, tup, S, idx_final); break;
-        case 128: hipLaunchKernelGGL((k_prune0<128>), dim3(grid), dim3(256), 0, st, S0, BN, keep, tup, S, idx_final); break;
-        case 256: hipLaunchKernelGGL((k_prune0<256>), dim3(grid), dim3(256), 0, st, S0, BN, keep, tup, S, idx_final); break;
+        case 16: hipLaunchKernelGGL((k_prune0<16>), dim3(grid), dim3(256), 4 * kSelectLdsU64 * 8, st, S0, BN, keep, tup, S, idx_final); break;
+        case 32: hipLaunchKernelGGL((k_prune0<32>), dim3(grid), dim3(256), 4 * kSelectLdsU64 * 8, st, S0, BN, keep, tup, S, idx_final); break;
+        case 64: hipLaunchKernelGGL((k_prune0<64>), dim3(grid), dim3(256), 4 * kSelectLdsU64 * 8, st, S0, BN, keep, tup, S, idx_final); break;
+        case 128: hipLaunchKernelGGL((k_prune0<128>), dim3(grid), dim3(256), 4 * kSelectLdsU64 * 8, st, S0, BN, keep, tup, S, idx_final); break;
+        case 256: hipLaunchKernelGGL((k_prune0<256>), dim3(grid), dim3(256), 4 * kSelectLdsU64 * 8, st, S0, BN, keep, tup, S, idx_final); break;
         default: return MCQ_EUNSUPPORTED;
     }
     MCQ_LAUNCH_CHECK();
@@ -152,19 +152,19 @@ int launch_pair_t(const float *C, const uint8_t *idx, const float *E, const uint
                   long B, int N, int K, int Dp, int Gout, int keep, uint8_t *tup_out, float *S_out,
                   uint8_t *idx_final, hipStream_t st) {
     const size_t per_wave = (size_t)2 * L * Dp * 4;
+    const size_t scratch = (size_t)kSelectLdsU64 * 8;
     int wpb = 4;
     bool old_lds = true;
-    if (per_wave * 4 <= 65536) wpb = 4;
-    else if (per_wave * 2 <= 65536) wpb = 2;
-    else if (per_wave <= 65536) wpb = 1;
+    if ((per_wave + scratch) * 4 <= 65536) wpb = 4;
+    else if ((per_wave + scratch) * 2 <= 65536) wpb = 2;
+    else if (per_wave + scratch <= 65536) wpb = 1;
     else { wpb = 4; old_lds = false; }
-    const long waves = B * Gout;
-    const unsigned grid = (unsigned)((waves + wpb - 1) / wpb);
+    const unsigned grid = (unsigned)(((B + wpb - 1) / wpb) * Gout);
     if (old_lds)
-        hipLaunchKernelGGL((k_pair<L, KI, true>), dim3(grid), dim3(64 * wpb), per_wave * wpb, st, C, idx, E, tup_in,
+        hipLaunchKernelGGL((k_pair<L, KI, true>), dim3(grid), dim3(64 * wpb), (per_wave + scratch) * wpb, st, C, idx, E, tup_in,
                            S_in, B, N, K, Dp, Gout, keep, tup_out, S_out, idx_final);
     else
-        hipLaunchKernelGGL((k_pair<L, KI, false>), dim3(grid), dim3(64 * wpb), 0, st, C, idx, E, tup_in, S_in, B, N,
+        hipLaunchKernelGGL((k_pair<L, KI, false>), dim3(grid), dim3(64 * wpb), scratch * wpb, st, C, idx, E, tup_in, S_in, B, N,
                            K, Dp, Gout, keep, tup_out, S_out, idx_final);
     MCQ_LAUNCH_CHECK();
     return 0;

@@ -15,6 +15,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace mcq {
 
@@ -93,6 +94,106 @@ __device__ __forceinline__ void wave_select(const float (&v)[VPL], const int (&p
         pv = bv;
         pp = bp;
     }
+}
+
+// ---- fast selection -----------------------------------------------------------
+// Same result as wave_select() for finite scores, ~5x fewer instructions: every
+// candidate becomes one unique 64-bit key (order-preserving map of the fp32 score in
+// the high word, position in the low word), a ballot-driven quickselect finds the
+// cnt-th smallest key T, the cnt keys <= T are compacted through LDS and ranked
+// against each other.  Scores are never -0 (sums of squares and x - x are +0), so
+// integer order of the keys equals (value, position) order.
+typedef unsigned long long u64;
+constexpr u64 kKeyMax = ~0ull;
+constexpr int kSelectLdsU64 = 128;  // per-wave LDS scratch of wave_select_fast, in u64
+
+__device__ __forceinline__ uint32_t ord32(float v) {
+    const uint32_t b = __float_as_uint(v);
+    return b ^ ((uint32_t)((int32_t)b >> 31) | 0x80000000u);
+}
+__device__ __forceinline__ float unord32(uint32_t o) {
+    return __uint_as_float((o & 0x80000000u) ? (o ^ 0x80000000u) : ~o);
+}
+__device__ __forceinline__ u64 readlane_u64(u64 x, int l) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, l);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), l);
+    return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int VPL>
+__device__ __forceinline__ void wave_select_fast(const float (&v)[VPL], const int (&p)[VPL], int cnt, int M,
+                                                 u64 *lds /* kSelectLdsU64 per wave */, float &out_v, int &out_p) {
+    if (cnt == 1) {  // plain arg-min
+        wave_select<VPL>(v, p, 1, M, out_v, out_p);
+        return;
+    }
+    const int lane = lane_id();
+    u64 key[VPL];
+    bool cand[VPL];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        cand[i] = p[i] != kBigPos;
+        key[i] = cand[i] ? (((u64)ord32(v[i]) << 32) | (uint32_t)p[i]) : kKeyMax;
+    }
+    // quickselect: find the key T with exactly cnt - 1 keys below it
+    const int target = cnt - 1;
+    u64 T = 0;
+    for (int guard = 0; guard < 64 * VPL + 1; ++guard) {
+        u64 lk = kKeyMax;
+        bool any_l = false;
+#pragma unroll
+        for (int i = VPL - 1; i >= 0; --i) {
+            lk = cand[i] ? key[i] : lk;
+            any_l = any_l || cand[i];
+        }
+        const u64 anym = __ballot(any_l);
+        const int pl = __ffsll((long long)anym) - 1;
+        const u64 kp = readlane_u64(lk, pl < 0 ? 0 : pl);
+        bool lt[VPL];
+        int r = 0;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            lt[i] = key[i] < kp;
+            r += __popcll(__ballot(lt[i]));
+        }
+        if (r == target || anym == 0) { T = kp; break; }
+        if (r > target) {
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) cand[i] = cand[i] && lt[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) cand[i] = cand[i] && (key[i] > kp);
+        }
+    }
+    // compact the cnt selected keys to lds[0..cnt)
+    u64 *ldsA = lds, *ldsB = lds + 64;
+    int base = 0;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const bool sel = key[i] <= T;
+        const u64 m = __ballot(sel);
+        const int dst = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+        if (sel && dst < 64) ldsA[dst] = key[i];
+        base += __popcll(m);
+    }
+    wave_lds_fence();
+    const u64 k = (lane < cnt) ? ldsA[lane] : kKeyMax;
+    int rnk = 0;
+    for (int j = 0; j < cnt; ++j) rnk += (ldsA[j] < k) ? 1 : 0;
+    if (lane < cnt) ldsB[rnk] = k;
+    wave_lds_fence();
+    out_v = INFINITY;
+    out_p = M - 1;
+    if (lane < cnt) {
+        const u64 o = ldsB[lane];
+        out_p = (int)(uint32_t)o;
+        out_v = unord32((uint32_t)(o >> 32));
+    }
+    wave_lds_fence();
 }
 
 // ------------------------------------------------------------------- prepare
@@ -372,7 +473,9 @@ __global__ void k_prune0(const float *__restrict__ S0, long BN, int keep, uint8_
     }
     float ov;
     int op;
-    wave_select<VPL>(v, p, keep, K, ov, op);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u64 *scratch = reinterpret_cast<u64 *>(smem) + (size_t)(threadIdx.x >> 6) * kSelectLdsU64;
+    wave_select_fast<VPL>(v, p, keep, K, scratch, ov, op);
     if (lane < keep) {
         if (idx_final != nullptr) {
             idx_final[w] = (uint8_t)op;
@@ -431,31 +534,60 @@ k_pair(const float *__restrict__ C, const uint8_t *__restrict__ idx, const float
 
     const int wave = threadIdx.x >> 6, lane = lane_id();
     const int wpb = blockDim.x >> 6;
-    const long w = (long)blockIdx.x * wpb + wave;
-    const bool active = w < B * Gout;
-    const long b = active ? w / Gout : 0;
-    const int go = active ? (int)(w % Gout) : 0;
+    // all waves of a workgroup work on the SAME output group for consecutive vectors, and
+    // workgroup id mod Gout picks the group: workgroups land on XCD (id mod 8), so each XCD's
+    // L2 only ever sees the codebooks of the groups congruent to it (2L*K rows instead of N*K).
+    const int go = (int)(blockIdx.x % (unsigned)Gout);
+    const long b_raw = (long)(blockIdx.x / (unsigned)Gout) * wpb + wave;
+    const bool active = b_raw < B;
+    const long b = active ? b_raw : 0;
     const int r = lane & 15, g = lane >> 4;
     const int Gin = 2 * Gout;
     const int ge = 2 * go, gd = 2 * go + 1;
 
     // old rows of the 2L codebooks this pair of groups covers: codebooks (2*go)*L .. +2L-1
     const int n0 = ge * L;
-    float *old_lds = reinterpret_cast<float *>(smem) + (size_t)wave * 2 * L * Dp;
+    float *old_lds = reinterpret_cast<float *>(smem) + (size_t)wpb * kSelectLdsU64 * 2 + (size_t)wave * 2 * L * Dp;
+    u64 *scratch = reinterpret_cast<u64 *>(smem) + (size_t)wave * kSelectLdsU64;
     if (OLD_LDS) {
         if (active) {
-            for (int j = 0; j < 2 * L; ++j) {
-                const float *src = C + ((long)(n0 + j) * K + idx[b * N + n0 + j]) * Dp;
-                for (int q = lane; q < Dp / 4; q += 64)
-                    *reinterpret_cast<f32x4 *>(old_lds + (size_t)j * Dp + 4 * q) =
-                        *reinterpret_cast<const f32x4 *>(src + 4 * q);
+            // 2L rows of Dp floats; loads of JB rows x 2 float4 per lane are issued before any store
+            const int per_row = Dp / 4;
+            constexpr int JB = (2 * L < 8) ? 2 * L : 8;
+            for (int j0 = 0; j0 < 2 * L; j0 += JB) {
+                uint32_t rb[JB];
+#pragma unroll
+                for (int u = 0; u < JB; ++u)
+                    rb[u] = (uint32_t)(((n0 + j0 + u) * K + idx[b * N + n0 + j0 + u]) * Dp);
+                for (int q = lane; q < per_row; q += 128) {
+                    const int q2 = q + 64;
+                    const bool v2 = q2 < per_row;
+                    const int q2c = v2 ? q2 : q;
+                    f32x4 t0[JB], t1[JB];
+#pragma unroll
+                    for (int u = 0; u < JB; ++u) {
+                        t0[u] = *reinterpret_cast<const f32x4 *>(C + rb[u] + 4 * q);
+                        t1[u] = *reinterpret_cast<const f32x4 *>(C + rb[u] + 4 * q2c);
+                    }
+#pragma unroll
+                    for (int u = 0; u < JB; ++u) {
+                        float *dst = old_lds + (size_t)(j0 + u) * Dp;
+                        *reinterpret_cast<f32x4 *>(dst + 4 * q) = t0[u];
+                        if (v2) *reinterpret_cast<f32x4 *>(dst + 4 * q2) = t1[u];
+                    }
+                }
             }
         }
         __syncthreads();
     }
     if (!active) return;
 
-    // per-lane operand rows: candidate 16*ti + r of the even group (MFMA A) and of the odd group (B)
+    // Operand rows are LOADED in a coalescing-friendly lane order -- lane 4*rs + ps reads the
+    // ps-th float4 of the k-block of candidate row rs, so each quad of lanes covers 64 contiguous
+    // bytes (16 cache accesses per wave-load instead of 64) -- and moved to the MFMA operand
+    // order (lane 16*g + r holds row r, float4 g) with four ds_bpermute per float4.
+    const int rs = lane >> 2, ps = lane & 3;
+    const int perm_addr = (4 * r + g) << 2;   // byte address of the source lane for this lane
     uint32_t coffA[TI][L], coffB[TI][L], ooffA[L], ooffB[L];
     bool validA[TI], validB[TI];
     const uint8_t *te = tup_in + ((b * Gin + ge) * KI) * (long)L;
@@ -463,24 +595,31 @@ k_pair(const float *__restrict__ C, const uint8_t *__restrict__ idx, const float
 #pragma unroll
     for (int j = 0; j < L; ++j) {
         if (OLD_LDS) {
-            ooffA[j] = (uint32_t)(j * Dp + 4 * g);
-            ooffB[j] = (uint32_t)((L + j) * Dp + 4 * g);
+            ooffA[j] = (uint32_t)(j * Dp + 4 * ps);
+            ooffB[j] = (uint32_t)((L + j) * Dp + 4 * ps);
         } else {
-            ooffA[j] = (uint32_t)(((n0 + j) * K + idx[b * N + n0 + j]) * Dp + 4 * g);
-            ooffB[j] = (uint32_t)(((n0 + L + j) * K + idx[b * N + n0 + L + j]) * Dp + 4 * g);
+            ooffA[j] = (uint32_t)(((n0 + j) * K + idx[b * N + n0 + j]) * Dp + 4 * ps);
+            ooffB[j] = (uint32_t)(((n0 + L + j) * K + idx[b * N + n0 + L + j]) * Dp + 4 * ps);
         }
     }
 #pragma unroll
     for (int ti = 0; ti < TI; ++ti) {
-        const int cand = 16 * ti + r;
-        validA[ti] = validB[ti] = cand < KI;
+        validA[ti] = validB[ti] = (16 * ti + r) < KI;
+        const int cand = 16 * ti + rs;
         const int cc = cand < KI ? cand : 0;
 #pragma unroll
         for (int j = 0; j < L; ++j) {
-            coffA[ti][j] = (uint32_t)(((n0 + j) * K + te[cc * L + j]) * Dp + 4 * g);
-            coffB[ti][j] = (uint32_t)(((n0 + L + j) * K + to[cc * L + j]) * Dp + 4 * g);
+            coffA[ti][j] = (uint32_t)(((n0 + j) * K + te[cc * L + j]) * Dp + 4 * ps);
+            coffB[ti][j] = (uint32_t)(((n0 + L + j) * K + to[cc * L + j]) * Dp + 4 * ps);
         }
     }
+    auto to_mfma_order = [&](f32x4 v) {
+        f32x4 o;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            o[c] = __int_as_float(__builtin_amdgcn_ds_bpermute(perm_addr, __float_as_int(v[c])));
+        return o;
+    };
     const float *oldbase = OLD_LDS ? old_lds : C;
 
     f32x4 acc[TI][TI];
@@ -490,26 +629,40 @@ k_pair(const float *__restrict__ C, const uint8_t *__restrict__ idx, const float
         for (int j = 0; j < TI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nkb = Dp / 16;
-    for (int kb = 0; kb < nkb; ++kb) {
-        const int koff = 16 * kb;
-        f32x4 da[TI], db[TI];
+    // UN k-blocks per batch: every operand load of the batch is issued before the first MFMA
+    auto chunk = [&](int kb0, auto un_tag) {
+        constexpr int UN = decltype(un_tag)::value;
+        f32x4 da[UN][TI], db[UN][TI];
 #pragma unroll
-        for (int ti = 0; ti < TI; ++ti) {
-            da[ti] = DeltaBuilder<L, OLD_LDS>::template build<L>(C, coffA[ti], oldbase, ooffA, 0, koff);
-            db[ti] = DeltaBuilder<L, OLD_LDS>::template build<L>(C, coffB[ti], oldbase, ooffB, 0, koff);
-            if (KI < 16) {  // padded rows of an 8-candidate group contribute nothing
-                if (!validA[ti]) da[ti] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (!validB[ti]) db[ti] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < UN; ++u) {
+            const int koff = 16 * (kb0 + u);
+#pragma unroll
+            for (int ti = 0; ti < TI; ++ti) {
+                da[u][ti] = to_mfma_order(
+                    DeltaBuilder<L, OLD_LDS>::template build<L>(C, coffA[ti], oldbase, ooffA, 0, koff));
+                db[u][ti] = to_mfma_order(
+                    DeltaBuilder<L, OLD_LDS>::template build<L>(C, coffB[ti], oldbase, ooffB, 0, koff));
+                if (KI < 16) {  // padded rows of an 8-candidate group contribute nothing
+                    if (!validA[ti]) da[u][ti] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (!validB[ti]) db[u][ti] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
             }
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int u = 0; u < UN; ++u)
 #pragma unroll
-            for (int ti = 0; ti < TI; ++ti)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int tj = 0; tj < TI; ++tj)
-                    acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(da[ti][i], db[tj][i], acc[ti][tj], 0, 0, 0);
-    }
+                for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+                    for (int tj = 0; tj < TI; ++tj)
+                        acc[ti][tj] =
+                            __builtin_amdgcn_mfma_f32_16x16x4f32(da[u][ti][i], db[u][tj][i], acc[ti][tj], 0, 0, 0);
+    };
+    constexpr int UNR = (16 / (L * TI)) >= 8 ? 8 : ((16 / (L * TI)) >= 1 ? (16 / (L * TI)) : 1);
+    int kb = 0;
+    for (; kb + UNR <= nkb; kb += UNR) chunk(kb, std::integral_constant<int, UNR>{});
+    for (; kb < nkb; ++kb) chunk(kb, std::integral_constant<int, 1>{});
 
     // scores: lane holds rows a = 16*ti + 4*g + v, column bcol = 16*tj + r
     const float Eb = E[b];
@@ -536,7 +689,7 @@ k_pair(const float *__restrict__ C, const uint8_t *__restrict__ idx, const float
         }
     float ov;
     int op;
-    wave_select<VPL>(sv, sp, keep, M, ov, op);
+    wave_select_fast<VPL>(sv, sp, keep, M, scratch, ov, op);
     if (lane < keep) {
         const int a = op / KI, bb = op % KI;
         if (idx_final != nullptr) {
