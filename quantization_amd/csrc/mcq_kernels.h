@@ -504,18 +504,17 @@ struct TupleRegs {
 
 template <int L, bool OLD_LDS>
 struct DeltaBuilder {
-    // delta over leaves [j0, j0 + LL) of one candidate, for float offset `koff`
+    // delta over leaves [j0, j0 + LL) of one candidate from its preloaded codebook pieces `raw`
+    // and the old-row pieces at float offset `koff`: leaves c - old, summed pairwise up the tree
     template <int LL>
-    static __device__ __forceinline__ f32x4 build(const float *__restrict__ C, const uint32_t *coff /*[L]*/,
-                                                  const float *oldbase, const uint32_t *ooff /*[L]*/, int j0,
-                                                  int koff) {
+    static __device__ __forceinline__ f32x4 build(const f32x4 *raw /*[L]*/, const float *oldbase,
+                                                  const uint32_t *ooff /*[L]*/, int j0, int koff) {
         if constexpr (LL == 1) {
-            const f32x4 c = *reinterpret_cast<const f32x4 *>(C + coff[j0] + koff);
             const f32x4 o = *reinterpret_cast<const f32x4 *>(oldbase + ooff[j0] + koff);
-            return c - o;
+            return raw[j0] - o;
         } else {
-            const f32x4 lo = build<LL / 2>(C, coff, oldbase, ooff, j0, koff);
-            const f32x4 hi = build<LL / 2>(C, coff, oldbase, ooff, j0 + LL / 2, koff);
+            const f32x4 lo = build<LL / 2>(raw, oldbase, ooff, j0, koff);
+            const f32x4 hi = build<LL / 2>(raw, oldbase, ooff, j0 + LL / 2, koff);
             return lo + hi;
         }
     }
@@ -586,8 +585,10 @@ k_pair(const float *__restrict__ C, const uint8_t *__restrict__ idx, const float
     // ps-th float4 of the k-block of candidate row rs, so each quad of lanes covers 64 contiguous
     // bytes (16 cache accesses per wave-load instead of 64) -- and moved to the MFMA operand
     // order (lane 16*g + r holds row r, float4 g) with four ds_bpermute per float4.
-    const int rs = lane >> 2, ps = lane & 3;
-    const int perm_addr = (4 * r + g) << 2;   // byte address of the source lane for this lane
+    // (quads 8..15 hold their four parts rotated by two so that the 32 lanes of a bpermute
+    // half-wave pull from 32 distinct LDS-crossbar banks)
+    const int rs = lane >> 2, ps = (lane & 3) ^ ((lane >> 5) << 1);
+    const int perm_addr = (4 * r + (g ^ ((r >> 3) << 1))) << 2;   // byte address of this lane's source lane
     uint32_t coffA[TI][L], coffB[TI][L], ooffA[L], ooffB[L];
     bool validA[TI], validB[TI];
     const uint8_t *te = tup_in + ((b * Gin + ge) * KI) * (long)L;
@@ -629,40 +630,95 @@ k_pair(const float *__restrict__ C, const uint8_t *__restrict__ idx, const float
         for (int j = 0; j < TI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nkb = Dp / 16;
-    // UN k-blocks per batch: every operand load of the batch is issued before the first MFMA
-    auto chunk = [&](int kb0, auto un_tag) {
-        constexpr int UN = decltype(un_tag)::value;
-        f32x4 da[UN][TI], db[UN][TI];
+    // Batches of UNR k-blocks.  For the light shapes (L*TI <= 2) a two-deep software pipeline:
+    // the gathers of batch c+1 are issued (pinned by sched_barrier) before the arithmetic of batch
+    // c, so their latency hides under this wave's own MFMAs as well as under the other waves of
+    // the SIMD.  Inside the steady-state loop every load is unconditional, so the compiler's
+    // vmcnt bookkeeping is exact and the waits are counted, not drains.
+    constexpr bool PIPE = (L * TI) <= 2;
+    constexpr int UNR = PIPE ? 4 / (L * TI) : ((8 / (L * TI)) >= 1 ? (8 / (L * TI)) : 1);
+    auto load_batch = [&](f32x4 (&ra)[UNR][TI][L], f32x4 (&rb)[UNR][TI][L], int kb0) {
 #pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const int koff = 16 * (kb0 + u);
+        for (int u = 0; u < UNR; ++u)
 #pragma unroll
-            for (int ti = 0; ti < TI; ++ti) {
-                da[u][ti] = to_mfma_order(
-                    DeltaBuilder<L, OLD_LDS>::template build<L>(C, coffA[ti], oldbase, ooffA, 0, koff));
-                db[u][ti] = to_mfma_order(
-                    DeltaBuilder<L, OLD_LDS>::template build<L>(C, coffB[ti], oldbase, ooffB, 0, koff));
-                if (KI < 16) {  // padded rows of an 8-candidate group contribute nothing
-                    if (!validA[ti]) da[u][ti] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    if (!validB[ti]) db[u][ti] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+                for (int j = 0; j < L; ++j) {
+                    ra[u][ti][j] = *reinterpret_cast<const f32x4 *>(C + coffA[ti][j] + 16 * (kb0 + u));
+                    rb[u][ti][j] = *reinterpret_cast<const f32x4 *>(C + coffB[ti][j] + 16 * (kb0 + u));
                 }
+    };
+    auto compute_one = [&](const f32x4 (&ra)[TI][L], const f32x4 (&rb)[TI][L], int kbi) {
+        const int koff = 16 * kbi;
+        f32x4 da[TI], db[TI];
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti) {
+            da[ti] = to_mfma_order(DeltaBuilder<L, OLD_LDS>::template build<L>(ra[ti], oldbase, ooffA, 0, koff));
+            db[ti] = to_mfma_order(DeltaBuilder<L, OLD_LDS>::template build<L>(rb[ti], oldbase, ooffB, 0, koff));
+            if (KI < 16) {  // padded rows of an 8-candidate group contribute nothing
+                if (!validA[ti]) da[ti] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (!validB[ti]) db[ti] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
         }
 #pragma unroll
-        for (int u = 0; u < UN; ++u)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
-                for (int ti = 0; ti < TI; ++ti)
-#pragma unroll
-                    for (int tj = 0; tj < TI; ++tj)
-                        acc[ti][tj] =
-                            __builtin_amdgcn_mfma_f32_16x16x4f32(da[u][ti][i], db[u][tj][i], acc[ti][tj], 0, 0, 0);
+                for (int tj = 0; tj < TI; ++tj)
+                    acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(da[ti][i], db[tj][i], acc[ti][tj], 0, 0, 0);
     };
-    constexpr int UNR = (16 / (L * TI)) >= 8 ? 8 : ((16 / (L * TI)) >= 1 ? (16 / (L * TI)) : 1);
-    int kb = 0;
-    for (; kb + UNR <= nkb; kb += UNR) chunk(kb, std::integral_constant<int, UNR>{});
-    for (; kb < nkb; ++kb) chunk(kb, std::integral_constant<int, 1>{});
+    auto compute_batch = [&](const f32x4 (&ra)[UNR][TI][L], const f32x4 (&rb)[UNR][TI][L], int kb0) {
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) compute_one(ra[u], rb[u], kb0 + u);
+    };
+    const int nb = nkb / UNR;   // whole batches; the nkb % UNR leftover k-blocks follow one by one
+    if constexpr (PIPE) {
+        f32x4 r0a[UNR][TI][L], r0b[UNR][TI][L], r1a[UNR][TI][L], r1b[UNR][TI][L];
+        int c = 0;
+        if (nb > 0) {
+            load_batch(r0a, r0b, 0);
+            while (c + 2 < nb) {
+                load_batch(r1a, r1b, (c + 1) * UNR);
+                __builtin_amdgcn_sched_barrier(0);
+                compute_batch(r0a, r0b, c * UNR);
+                __builtin_amdgcn_sched_barrier(0);
+                load_batch(r0a, r0b, (c + 2) * UNR);
+                __builtin_amdgcn_sched_barrier(0);
+                compute_batch(r1a, r1b, (c + 1) * UNR);
+                __builtin_amdgcn_sched_barrier(0);
+                c += 2;
+            }
+            if (nb - c == 2) {
+                load_batch(r1a, r1b, (c + 1) * UNR);
+                __builtin_amdgcn_sched_barrier(0);
+                compute_batch(r0a, r0b, c * UNR);
+                __builtin_amdgcn_sched_barrier(0);
+                compute_batch(r1a, r1b, (c + 1) * UNR);
+            } else {
+                compute_batch(r0a, r0b, c * UNR);
+            }
+        }
+    } else {
+        f32x4 ra[UNR][TI][L], rb[UNR][TI][L];
+        for (int c = 0; c < nb; ++c) {
+            load_batch(ra, rb, c * UNR);
+            __builtin_amdgcn_sched_barrier(0);
+            compute_batch(ra, rb, c * UNR);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    for (int kbi = nb * UNR; kbi < nkb; ++kbi) {
+        f32x4 ta[TI][L], tb[TI][L];
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+            for (int j = 0; j < L; ++j) {
+                ta[ti][j] = *reinterpret_cast<const f32x4 *>(C + coffA[ti][j] + 16 * kbi);
+                tb[ti][j] = *reinterpret_cast<const f32x4 *>(C + coffB[ti][j] + 16 * kbi);
+            }
+        compute_one(ta, tb, kbi);
+    }
 
     // scores: lane holds rows a = 16*ti + 4*g + v, column bcol = 16*tj + r
     const float Eb = E[b];
