@@ -165,6 +165,13 @@ class QuantizerTrainer(object):
     def _begin_second_phase(self):
         # quantization.py:732-738
         self.quantizer = self.quantizer.get_product_quantizer()
+        if self._world() > 1:
+            # the product quantizer is a deterministic function of (identical) parameters; only
+            # its fresh random id differs between ranks
+            dist = self._dist()
+            src = dist.get_global_rank(self.process_group, 0) if self.process_group is not None else 0
+            dist.broadcast(self.quantizer.id_buf, src=src, group=self.process_group)
+            self.quantizer.id_str = bytes(self.quantizer.id_buf.tolist()).decode("utf-8")
         self.lr *= 0.5
         self._init_optimizer()
 
