@@ -14,7 +14,9 @@ NEAR_TIE = 2e-6
 
 
 def names(prefix=""):
-    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(HERE, prefix + "*.npz")))
+    """encode/decode fixtures (the trainer trajectory fixture has its own loader)"""
+    return sorted(n for n in (os.path.basename(p)[:-4] for p in glob.glob(os.path.join(HERE, prefix + "*.npz")))
+                  if not n.startswith("trainer_"))
 
 
 def load(name):
