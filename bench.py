@@ -216,6 +216,21 @@ def main():
                      "avg_launch_ms": round(float(dom_ms), 4)},
         "kernels": kernels,
     }
+    # ---- decode (HBM-write-bound gather-sum), secondary figure
+    with torch.no_grad():
+        for _ in range(2):
+            y = q.decode(codes)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            y = q.decode(codes)
+        e1.record()
+        torch.cuda.synchronize()
+        dec_ms = e0.elapsed_time(e1) / 10
+    out["decode"] = {"vectors_per_s": round(B / (dec_ms * 1e-3), 1), "ms": round(dec_ms, 4),
+                     "hbm_gb_per_s": round(B * (N + 4 * D) / (dec_ms * 1e-3) / 1e9, 1), "peak_gb_per_s": 8000.0,
+                     "note": "torch current stream; algorithmic bytes = N + 4*D per vector"}
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(state, D)
     print(json.dumps(out), flush=True)
