@@ -316,24 +316,27 @@ k_gemm(const float *__restrict__ Bm /*[N][K][Dp]*/, const float *__restrict__ xi
     const int xstride = (MODE == MODE_STAGE0) ? Dp : D;
     const bool x_vec = (MODE == MODE_STAGE0) || (((D & 3) == 0) && ((reinterpret_cast<uintptr_t>(xin) & 15) == 0));
 
-    // staging assignment: unit f -> (row = f / 8, c = f % 8 -> kb = c / 4, g = c % 4)
-    const float *oldrow[2] = {nullptr, nullptr};
+    // staging assignment: unit f -> (row = f / 8, c = f % 8 -> kb = c / 4, g = c % 4).
+    // Every staging load is UNCONDITIONAL (row and k indices are clamped into range instead of
+    // guarded): a guarded load costs a branch and a full vmcnt(0) drain each.  Clamped loads fetch
+    // data that is never used: rows past the batch are dropped in the epilogue, the k-block past Dp
+    // of an odd tail is skipped by the MFMA loop.
+    const float *oldrow[2] = {Bm, Bm};
     long brow[2];
-    bool bvalid[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-        const int row = (tid + 256 * s) >> 3;
-        brow[s] = b0 + row;
-        bvalid[s] = brow[s] < B;
-        if (MODE == MODE_STAGE0 && bvalid[s])
-            oldrow[s] = Bm + ((long)n * K + idx_in[brow[s] * N + n]) * Dp;
+        const long row = b0 + ((tid + 256 * s) >> 3);
+        brow[s] = row < B ? row : B - 1;
+        if (MODE == MODE_STAGE0) oldrow[s] = Bm + ((long)n * K + idx_in[brow[s] * N + n]) * Dp;
     }
+    // the x rows of the logits pass are unpadded: vector loads only when D is already a multiple of 16
+    const bool fast = (MODE == MODE_STAGE0) || (x_vec && D == Dp);
 
     f32x4 acc[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    f32x4 stA[A_PER_THREAD], stB[2];
+    f32x4 stA[A_PER_THREAD], stB[2], stO[2];
     const int nkb = Dp / 16;
     const int nsteps = (nkb + 1) / 2;
 
@@ -342,28 +345,32 @@ k_gemm(const float *__restrict__ Bm /*[N][K][Dp]*/, const float *__restrict__ xi
 #pragma unroll
         for (int s = 0; s < A_PER_THREAD; ++s) {
             const int f = tid + 256 * s;
-            const int row = f >> 3, c = f & 7;
-            const int k = k0 + 4 * c;
-            if (f < A_UNITS && k < Dp) stA[s] = *reinterpret_cast<const f32x4 *>(Bn + (long)row * Dp + k);
-            else stA[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            int row = f >> 3;
+            row = row < K ? row : K - 1;
+            int k = k0 + 4 * (f & 7);
+            k = k < Dp ? k : Dp - 4;
+            stA[s] = *reinterpret_cast<const f32x4 *>(Bn + (long)row * Dp + k);
         }
+        if (fast) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int c = (tid + 256 * s) & 7;
-            const int k = k0 + 4 * c;
-            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (bvalid[s] && k < Dp) {
-                const float *xr = xin + brow[s] * xstride;
-                if (x_vec && k + 3 < xstride) {
-                    v = *reinterpret_cast<const f32x4 *>(xr + k);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = (k + e < xstride) ? xr[k + e] : 0.f;
-                }
-                if (MODE == MODE_STAGE0) v = v - *reinterpret_cast<const f32x4 *>(oldrow[s] + k);
-                else v = v * lscale;
+            for (int s = 0; s < 2; ++s) {
+                int k = k0 + 4 * ((tid + 256 * s) & 7);
+                k = k < Dp ? k : Dp - 4;
+                // raw loads only: the subtraction / scaling happens when the stage is stored to LDS, so
+                // these loads stay in flight under the MFMAs of the current stage
+                stB[s] = *reinterpret_cast<const f32x4 *>(xin + brow[s] * xstride + k);
+                if (MODE == MODE_STAGE0) stO[s] = *reinterpret_cast<const f32x4 *>(oldrow[s] + k);
             }
-            stB[s] = v;
+        } else {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int k = k0 + 4 * ((tid + 256 * s) & 7);
+                const float *xr = xin + brow[s] * xstride;
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (k + e < xstride) ? xr[k + e] : 0.f;
+                stB[s] = v;
+            }
         }
     };
 
@@ -377,7 +384,8 @@ k_gemm(const float *__restrict__ Bm /*[N][K][Dp]*/, const float *__restrict__ xi
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int f = tid + 256 * s;
-            ldsB[lds_unit(kGemmVec, f >> 3, (f & 7) >> 2, f & 3)] = stB[s];
+            const f32x4 v = (MODE == MODE_STAGE0) ? (stB[s] - stO[s]) : (stB[s] * lscale);
+            ldsB[lds_unit(kGemmVec, f >> 3, (f & 7) >> 2, f & 3)] = v;
         }
         __syncthreads();
         if (step + 1 < nsteps) load_stage(step + 1);
