@@ -3,6 +3,7 @@
 #include "../../include/mcq.h"
 #include "mcq_kernels.h"
 
+#include <cstdlib>
 #include <vector>
 
 using namespace mcq;
@@ -151,21 +152,28 @@ template <int L, int KI>
 int launch_pair_t(const float *C, const uint8_t *idx, const float *E, const uint8_t *tup_in, const float *S_in,
                   long B, int N, int K, int Dp, int Gout, int keep, uint8_t *tup_out, float *S_out,
                   uint8_t *idx_final, hipStream_t st) {
-    const size_t per_wave = (size_t)2 * L * Dp * 4;
+    // each wave stages its 2L old rows in a private LDS window: whole rows while that stays <= 32 KB
+    // per wave (measured best), otherwise `win` floats at a time in windows of <= 16 KB
     const size_t scratch = (size_t)kSelectLdsU64 * 8;
-    int wpb = 4;
-    bool old_lds = true;
-    if ((per_wave + scratch) * 4 <= 65536) wpb = 4;
-    else if ((per_wave + scratch) * 2 <= 65536) wpb = 2;
-    else if (per_wave + scratch <= 65536) wpb = 1;
-    else { wpb = 4; old_lds = false; }
+    int win = Dp;
+    if ((size_t)2 * L * Dp * 4 > 32768 - scratch) {
+        const int limit = (int)(16384 / (8 * L));
+        const int lim64 = (limit / 64) * 64 > 64 ? (limit / 64) * 64 : 64;
+        const int nwin = (Dp + lim64 - 1) / lim64;
+        win = (((Dp + nwin - 1) / nwin) + 63) / 64 * 64;
+    }
+    if (const char *e = getenv("MCQ_PAIR_WIN")) { const int v = atoi(e); if (v >= 64 && L >= 4) win = v < Dp ? v : Dp; }   // tuning hook
+    const size_t per_wave = (size_t)2 * L * win * 4 + scratch;
+    // one wave per workgroup: the waves share nothing (private LDS, no barrier), and single-wave
+    // workgroups measured fastest (finer-grained dispatch, LDS released per wave)
+    int wpb = 1;
+    if (const char *e = getenv("MCQ_PAIR_WPB")) {   // tuning hook
+        const int v = atoi(e);
+        if (v >= 1 && v <= 4 && per_wave * v <= 65536) wpb = v;
+    }
     const unsigned grid = (unsigned)(((B + wpb - 1) / wpb) * Gout);
-    if (old_lds)
-        hipLaunchKernelGGL((k_pair<L, KI, true>), dim3(grid), dim3(64 * wpb), (per_wave + scratch) * wpb, st, C, idx, E, tup_in,
-                           S_in, B, N, K, Dp, Gout, keep, tup_out, S_out, idx_final);
-    else
-        hipLaunchKernelGGL((k_pair<L, KI, false>), dim3(grid), dim3(64 * wpb), scratch * wpb, st, C, idx, E, tup_in, S_in, B, N,
-                           K, Dp, Gout, keep, tup_out, S_out, idx_final);
+    hipLaunchKernelGGL((k_pair<L, KI>), dim3(grid), dim3(64 * wpb), per_wave * wpb, st, C, idx, E, tup_in, S_in, B, N, K,
+                       Dp, Gout, keep, win, tup_out, S_out, idx_final);
     MCQ_LAUNCH_CHECK();
     return 0;
 }

@@ -503,40 +503,36 @@ __global__ void k_prune0(const float *__restrict__ S0, long BN, int keep, uint8_
 //   S'[a*KI + b] = ((Se[a] + So[b]) - E) + 2 * dot16(delta_e[a], delta_o[b])
 // The `keep` smallest (value, position) survive; their tuples are concatenated.
 // MFMA rows = even-group candidates a, columns = odd-group candidates b.
+// delta of one candidate from its L preloaded codebook pieces: leaves c - old (:436-439) summed
+// pairwise up the combine tree (:538-541).  `old` pieces come from the wave's LDS window.
 template <int L>
-struct TupleRegs {
-    static constexpr int WORDS = (L + 3) / 4;
-    uint32_t w[WORDS];
-    __device__ __forceinline__ int get(int j) const { return (w[j >> 2] >> (8 * (j & 3))) & 0xff; }
-};
-
-template <int L, bool OLD_LDS>
 struct DeltaBuilder {
-    // delta over leaves [j0, j0 + LL) of one candidate from its preloaded codebook pieces `raw`
-    // and the old-row pieces at float offset `koff`: leaves c - old, summed pairwise up the tree
     template <int LL>
-    static __device__ __forceinline__ f32x4 build(const f32x4 *raw /*[L]*/, const float *oldbase,
-                                                  const uint32_t *ooff /*[L]*/, int j0, int koff) {
+    static __device__ __forceinline__ f32x4 build(const f32x4 *raw /*[L]*/, const float *oldwin, int win, int j0,
+                                                  int off /* float offset of this lane's piece in the window */) {
         if constexpr (LL == 1) {
-            const f32x4 o = *reinterpret_cast<const f32x4 *>(oldbase + ooff[j0] + koff);
+            const f32x4 o = *reinterpret_cast<const f32x4 *>(oldwin + j0 * win + off);
             return raw[j0] - o;
         } else {
-            const f32x4 lo = build<LL / 2>(raw, oldbase, ooff, j0, koff);
-            const f32x4 hi = build<LL / 2>(raw, oldbase, ooff, j0 + LL / 2, koff);
+            const f32x4 lo = build<LL / 2>(raw, oldwin, win, j0, off);
+            const f32x4 hi = build<LL / 2>(raw, oldwin, win, j0 + LL / 2, off);
             return lo + hi;
         }
     }
 };
 
-template <int L, int KI, bool OLD_LDS>
+template <int L, int KI>
 __global__ void __launch_bounds__(256)
 k_pair(const float *__restrict__ C, const uint8_t *__restrict__ idx, const float *__restrict__ E,
        const uint8_t *__restrict__ tup_in /*[B][Gin][KI][L]*/, const float *__restrict__ S_in /*[B][Gin][KI]*/,
-       long B, int N, int K, int Dp, int Gout, int keep, uint8_t *__restrict__ tup_out /*[B][Gout][keep][2L]*/,
-       float *__restrict__ S_out, uint8_t *__restrict__ idx_final) {
+       long B, int N, int K, int Dp, int Gout, int keep, int win /* floats of each old row staged per window */,
+       uint8_t *__restrict__ tup_out /*[B][Gout][keep][2L]*/, float *__restrict__ S_out,
+       uint8_t *__restrict__ idx_final) {
     constexpr int TI = (KI + 15) / 16;
     constexpr int VPL = TI * TI * 4;
     constexpr int M = KI * KI;
+    constexpr bool SMALL = L <= 4;            // row offsets precomputed in registers
+    constexpr int TW = (L + 3) / 4;           // packed tuple words per candidate (large L)
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int wave = threadIdx.x >> 6, lane = lane_id();
@@ -545,49 +541,15 @@ k_pair(const float *__restrict__ C, const uint8_t *__restrict__ idx, const float
     // workgroup id mod Gout picks the group: workgroups land on XCD (id mod 8), so each XCD's
     // L2 only ever sees the codebooks of the groups congruent to it (2L*K rows instead of N*K).
     const int go = (int)(blockIdx.x % (unsigned)Gout);
-    const long b_raw = (long)(blockIdx.x / (unsigned)Gout) * wpb + wave;
-    const bool active = b_raw < B;
-    const long b = active ? b_raw : 0;
+    const long b = (long)(blockIdx.x / (unsigned)Gout) * wpb + wave;
+    if (b >= B) return;   // no workgroup-wide barrier below: every LDS region is private to its wave
     const int r = lane & 15, g = lane >> 4;
     const int Gin = 2 * Gout;
     const int ge = 2 * go, gd = 2 * go + 1;
+    const int n0 = ge * L;   // codebooks n0 .. n0 + 2L - 1 belong to this pair of groups
 
-    // old rows of the 2L codebooks this pair of groups covers: codebooks (2*go)*L .. +2L-1
-    const int n0 = ge * L;
-    float *old_lds = reinterpret_cast<float *>(smem) + (size_t)wpb * kSelectLdsU64 * 2 + (size_t)wave * 2 * L * Dp;
     u64 *scratch = reinterpret_cast<u64 *>(smem) + (size_t)wave * kSelectLdsU64;
-    if (OLD_LDS) {
-        if (active) {
-            // 2L rows of Dp floats; loads of JB rows x 2 float4 per lane are issued before any store
-            const int per_row = Dp / 4;
-            constexpr int JB = (2 * L < 8) ? 2 * L : 8;
-            for (int j0 = 0; j0 < 2 * L; j0 += JB) {
-                uint32_t rb[JB];
-#pragma unroll
-                for (int u = 0; u < JB; ++u)
-                    rb[u] = (uint32_t)(((n0 + j0 + u) * K + idx[b * N + n0 + j0 + u]) * Dp);
-                for (int q = lane; q < per_row; q += 128) {
-                    const int q2 = q + 64;
-                    const bool v2 = q2 < per_row;
-                    const int q2c = v2 ? q2 : q;
-                    f32x4 t0[JB], t1[JB];
-#pragma unroll
-                    for (int u = 0; u < JB; ++u) {
-                        t0[u] = *reinterpret_cast<const f32x4 *>(C + rb[u] + 4 * q);
-                        t1[u] = *reinterpret_cast<const f32x4 *>(C + rb[u] + 4 * q2c);
-                    }
-#pragma unroll
-                    for (int u = 0; u < JB; ++u) {
-                        float *dst = old_lds + (size_t)(j0 + u) * Dp;
-                        *reinterpret_cast<f32x4 *>(dst + 4 * q) = t0[u];
-                        if (v2) *reinterpret_cast<f32x4 *>(dst + 4 * q2) = t1[u];
-                    }
-                }
-            }
-        }
-        __syncthreads();
-    }
-    if (!active) return;
+    float *oldwin = reinterpret_cast<float *>(smem) + (size_t)wpb * kSelectLdsU64 * 2 + (size_t)wave * 2 * L * win;
 
     // Operand rows are LOADED in a coalescing-friendly lane order -- lane 4*rs + ps reads the
     // ps-th float4 of the k-block of candidate row rs, so each quad of lanes covers 64 contiguous
@@ -597,31 +559,39 @@ k_pair(const float *__restrict__ C, const uint8_t *__restrict__ idx, const float
     // half-wave pull from 32 distinct LDS-crossbar banks)
     const int rs = lane >> 2, ps = (lane & 3) ^ ((lane >> 5) << 1);
     const int perm_addr = (4 * r + (g ^ ((r >> 3) << 1))) << 2;   // byte address of this lane's source lane
-    uint32_t coffA[TI][L], coffB[TI][L], ooffA[L], ooffB[L];
-    bool validA[TI], validB[TI];
     const uint8_t *te = tup_in + ((b * Gin + ge) * KI) * (long)L;
     const uint8_t *to = tup_in + ((b * Gin + gd) * KI) * (long)L;
-#pragma unroll
-    for (int j = 0; j < L; ++j) {
-        if (OLD_LDS) {
-            ooffA[j] = (uint32_t)(j * Dp + 4 * ps);
-            ooffB[j] = (uint32_t)((L + j) * Dp + 4 * ps);
-        } else {
-            ooffA[j] = (uint32_t)(((n0 + j) * K + idx[b * N + n0 + j]) * Dp + 4 * ps);
-            ooffB[j] = (uint32_t)(((n0 + L + j) * K + idx[b * N + n0 + L + j]) * Dp + 4 * ps);
-        }
-    }
+    bool validA[TI], validB[TI];
+    // side 0 = even group (MFMA A / rows), side 1 = odd group (MFMA B / columns)
+    uint32_t coff[2][TI][SMALL ? L : 1];
+    uint32_t tw[2][TI][SMALL ? 1 : TW];
 #pragma unroll
     for (int ti = 0; ti < TI; ++ti) {
         validA[ti] = validB[ti] = (16 * ti + r) < KI;
         const int cand = 16 * ti + rs;
         const int cc = cand < KI ? cand : 0;
+        if constexpr (SMALL) {
 #pragma unroll
-        for (int j = 0; j < L; ++j) {
-            coffA[ti][j] = (uint32_t)(((n0 + j) * K + te[cc * L + j]) * Dp + 4 * ps);
-            coffB[ti][j] = (uint32_t)(((n0 + L + j) * K + to[cc * L + j]) * Dp + 4 * ps);
+            for (int j = 0; j < L; ++j) {
+                coff[0][ti][j] = (uint32_t)(((n0 + j) * K + te[cc * L + j]) * Dp + 4 * ps);
+                coff[1][ti][j] = (uint32_t)(((n0 + L + j) * K + to[cc * L + j]) * Dp + 4 * ps);
+            }
+        } else {
+#pragma unroll
+            for (int w = 0; w < TW; ++w) {   // tuples of L >= 8 bytes are 4-byte aligned
+                tw[0][ti][w] = *reinterpret_cast<const uint32_t *>(te + cc * L + 4 * w);
+                tw[1][ti][w] = *reinterpret_cast<const uint32_t *>(to + cc * L + 4 * w);
+            }
         }
     }
+    auto row_off = [&](int side, int ti, int j) -> uint32_t {   // side, ti, j are compile-time at every call
+        if constexpr (SMALL) {
+            return coff[side][ti][j];
+        } else {
+            const uint32_t e = (tw[side][ti][j >> 2] >> (8 * (j & 3))) & 0xffu;
+            return (uint32_t)(((n0 + side * L + j) * K + (int)e) * Dp + 4 * ps);
+        }
+    };
     auto to_mfma_order = [&](f32x4 v) {
         f32x4 o;
 #pragma unroll
@@ -629,7 +599,35 @@ k_pair(const float *__restrict__ C, const uint8_t *__restrict__ idx, const float
             o[c] = __int_as_float(__builtin_amdgcn_ds_bpermute(perm_addr, __float_as_int(v[c])));
         return o;
     };
-    const float *oldbase = OLD_LDS ? old_lds : C;
+
+    // stage floats [w0, w0 + wlen) of the 2L old rows into this wave's LDS window
+    auto stage_old = [&](int w0, int wlen) {
+        const int per_row = wlen / 4;
+        constexpr int JB = (2 * L < 8) ? 2 * L : 8;
+        for (int j0 = 0; j0 < 2 * L; j0 += JB) {
+            uint32_t rb[JB];
+#pragma unroll
+            for (int u = 0; u < JB; ++u)
+                rb[u] = (uint32_t)(((n0 + j0 + u) * K + idx[b * N + n0 + j0 + u]) * Dp + w0);
+            for (int q = lane; q < per_row; q += 128) {
+                const int q2 = q + 64;
+                const bool v2 = q2 < per_row;
+                const int q2c = v2 ? q2 : q;
+                f32x4 t0[JB], t1[JB];
+#pragma unroll
+                for (int u = 0; u < JB; ++u) {
+                    t0[u] = *reinterpret_cast<const f32x4 *>(C + rb[u] + 4 * q);
+                    t1[u] = *reinterpret_cast<const f32x4 *>(C + rb[u] + 4 * q2c);
+                }
+#pragma unroll
+                for (int u = 0; u < JB; ++u) {
+                    float *dst = oldwin + (size_t)(j0 + u) * win;
+                    *reinterpret_cast<f32x4 *>(dst + 4 * q) = t0[u];
+                    if (v2) *reinterpret_cast<f32x4 *>(dst + 4 * q2) = t1[u];
+                }
+            }
+        }
+    };
 
     f32x4 acc[TI][TI];
 #pragma unroll
@@ -637,37 +635,7 @@ k_pair(const float *__restrict__ C, const uint8_t *__restrict__ idx, const float
 #pragma unroll
         for (int j = 0; j < TI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nkb = Dp / 16;
-    // Batches of UNR k-blocks.  For the light shapes (L*TI <= 2) a two-deep software pipeline:
-    // the gathers of batch c+1 are issued (pinned by sched_barrier) before the arithmetic of batch
-    // c, so their latency hides under this wave's own MFMAs as well as under the other waves of
-    // the SIMD.  Inside the steady-state loop every load is unconditional, so the compiler's
-    // vmcnt bookkeeping is exact and the waits are counted, not drains.
-    constexpr bool PIPE = (L * TI) <= 2;
-    constexpr int UNR = PIPE ? 4 / (L * TI) : ((8 / (L * TI)) >= 1 ? (8 / (L * TI)) : 1);
-    auto load_batch = [&](f32x4 (&ra)[UNR][TI][L], f32x4 (&rb)[UNR][TI][L], int kb0) {
-#pragma unroll
-        for (int u = 0; u < UNR; ++u)
-#pragma unroll
-            for (int ti = 0; ti < TI; ++ti)
-#pragma unroll
-                for (int j = 0; j < L; ++j) {
-                    ra[u][ti][j] = *reinterpret_cast<const f32x4 *>(C + coffA[ti][j] + 16 * (kb0 + u));
-                    rb[u][ti][j] = *reinterpret_cast<const f32x4 *>(C + coffB[ti][j] + 16 * (kb0 + u));
-                }
-    };
-    auto compute_one = [&](const f32x4 (&ra)[TI][L], const f32x4 (&rb)[TI][L], int kbi) {
-        const int koff = 16 * kbi;
-        f32x4 da[TI], db[TI];
-#pragma unroll
-        for (int ti = 0; ti < TI; ++ti) {
-            da[ti] = to_mfma_order(DeltaBuilder<L, OLD_LDS>::template build<L>(ra[ti], oldbase, ooffA, 0, koff));
-            db[ti] = to_mfma_order(DeltaBuilder<L, OLD_LDS>::template build<L>(rb[ti], oldbase, ooffB, 0, koff));
-            if (KI < 16) {  // padded rows of an 8-candidate group contribute nothing
-                if (!validA[ti]) da[ti] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (!validB[ti]) db[ti] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
-        }
+    auto mfma_block = [&](const f32x4 (&da)[TI], const f32x4 (&db)[TI]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -676,56 +644,152 @@ k_pair(const float *__restrict__ C, const uint8_t *__restrict__ idx, const float
                 for (int tj = 0; tj < TI; ++tj)
                     acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(da[ti][i], db[tj][i], acc[ti][tj], 0, 0, 0);
     };
-    auto compute_batch = [&](const f32x4 (&ra)[UNR][TI][L], const f32x4 (&rb)[UNR][TI][L], int kb0) {
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) compute_one(ra[u], rb[u], kb0 + u);
+    auto finish_operand = [&](f32x4 d, bool valid) {
+        d = to_mfma_order(d);
+        if (KI < 16 && !valid) d = (f32x4){0.f, 0.f, 0.f, 0.f};  // padded rows of an 8-candidate group
+        return d;
     };
-    const int nb = nkb / UNR;   // whole batches; the nkb % UNR leftover k-blocks follow one by one
-    if constexpr (PIPE) {
-        f32x4 r0a[UNR][TI][L], r0b[UNR][TI][L], r1a[UNR][TI][L], r1b[UNR][TI][L];
-        int c = 0;
-        if (nb > 0) {
-            load_batch(r0a, r0b, 0);
-            while (c + 2 < nb) {
-                load_batch(r1a, r1b, (c + 1) * UNR);
-                __builtin_amdgcn_sched_barrier(0);
-                compute_batch(r0a, r0b, c * UNR);
-                __builtin_amdgcn_sched_barrier(0);
-                load_batch(r0a, r0b, (c + 2) * UNR);
-                __builtin_amdgcn_sched_barrier(0);
-                compute_batch(r1a, r1b, (c + 1) * UNR);
-                __builtin_amdgcn_sched_barrier(0);
-                c += 2;
+
+    constexpr bool PIPE = (L * TI) <= 2;
+    constexpr int UNR = PIPE ? 4 / (L * TI) : 1;
+
+    for (int w0 = 0; w0 < Dp; w0 += win) {
+        const int wlen = (Dp - w0 < win) ? (Dp - w0) : win;
+        if (w0 > 0) wave_lds_fence();      // every read of the previous window has been issued
+        stage_old(w0, wlen);
+        wave_lds_fence();
+        const int kb_lo = w0 / 16, nkb = wlen / 16;   // k-blocks of this window
+        const float *oldp = oldwin + 4 * ps;          // this lane's piece within a k-block of the window
+
+        if constexpr (PIPE) {
+            // Two-deep software pipeline over batches of UNR k-blocks: the gathers of batch c+1 are
+            // issued (pinned by sched_barrier) before the arithmetic of batch c.  Inside the
+            // steady-state loop every load is unconditional, so the compiler's vmcnt bookkeeping is
+            // exact and the waits are counted, not drains.
+            auto load_batch = [&](f32x4 (&ra)[UNR][TI][L], f32x4 (&rb)[UNR][TI][L], int kb0) {
+#pragma unroll
+                for (int u = 0; u < UNR; ++u)
+#pragma unroll
+                    for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+                        for (int j = 0; j < L; ++j) {
+                            ra[u][ti][j] = *reinterpret_cast<const f32x4 *>(C + row_off(0, ti, j) + 16 * (kb_lo + kb0 + u));
+                            rb[u][ti][j] = *reinterpret_cast<const f32x4 *>(C + row_off(1, ti, j) + 16 * (kb_lo + kb0 + u));
+                        }
+            };
+            auto compute_batch = [&](const f32x4 (&ra)[UNR][TI][L], const f32x4 (&rb)[UNR][TI][L], int kb0) {
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    f32x4 da[TI], db[TI];
+#pragma unroll
+                    for (int ti = 0; ti < TI; ++ti) {
+                        da[ti] = finish_operand(DeltaBuilder<L>::template build<L>(ra[u][ti], oldp, win, 0, 16 * (kb0 + u)), validA[ti]);
+                        db[ti] = finish_operand(DeltaBuilder<L>::template build<L>(rb[u][ti], oldp + L * win, win, 0, 16 * (kb0 + u)), validB[ti]);
+                    }
+                    mfma_block(da, db);
+                }
+            };
+            const int nb = nkb / UNR;   // whole batches; the nkb % UNR leftover k-blocks follow one by one
+            f32x4 r0a[UNR][TI][L], r0b[UNR][TI][L], r1a[UNR][TI][L], r1b[UNR][TI][L];
+            int c = 0;
+            if (nb > 0) {
+                load_batch(r0a, r0b, 0);
+                while (c + 2 < nb) {
+                    load_batch(r1a, r1b, (c + 1) * UNR);
+                    __builtin_amdgcn_sched_barrier(0);
+                    compute_batch(r0a, r0b, c * UNR);
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_batch(r0a, r0b, (c + 2) * UNR);
+                    __builtin_amdgcn_sched_barrier(0);
+                    compute_batch(r1a, r1b, (c + 1) * UNR);
+                    __builtin_amdgcn_sched_barrier(0);
+                    c += 2;
+                }
+                if (nb - c == 2) {
+                    load_batch(r1a, r1b, (c + 1) * UNR);
+                    __builtin_amdgcn_sched_barrier(0);
+                    compute_batch(r0a, r0b, c * UNR);
+                    __builtin_amdgcn_sched_barrier(0);
+                    compute_batch(r1a, r1b, (c + 1) * UNR);
+                } else {
+                    compute_batch(r0a, r0b, c * UNR);
+                }
             }
-            if (nb - c == 2) {
-                load_batch(r1a, r1b, (c + 1) * UNR);
+            for (int kbi = nb * UNR; kbi < nkb; ++kbi) {
+                f32x4 ta[TI][L], tb[TI][L];
+#pragma unroll
+                for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+                    for (int j = 0; j < L; ++j) {
+                        ta[ti][j] = *reinterpret_cast<const f32x4 *>(C + row_off(0, ti, j) + 16 * (kb_lo + kbi));
+                        tb[ti][j] = *reinterpret_cast<const f32x4 *>(C + row_off(1, ti, j) + 16 * (kb_lo + kbi));
+                    }
+                f32x4 da[TI], db[TI];
+#pragma unroll
+                for (int ti = 0; ti < TI; ++ti) {
+                    da[ti] = finish_operand(DeltaBuilder<L>::template build<L>(ta[ti], oldp, win, 0, 16 * kbi), validA[ti]);
+                    db[ti] = finish_operand(DeltaBuilder<L>::template build<L>(tb[ti], oldp + L * win, win, 0, 16 * kbi), validB[ti]);
+                }
+                mfma_block(da, db);
+            }
+        } else if constexpr (L * TI <= 8) {
+            // Medium shapes: all 2*TI*L gathers of a k-block are in flight together (the other waves of
+            // the SIMD cover their latency; deeper per-wave prefetch measured slower here: the stage is
+            // bound by L1 tag throughput, not by latency).
+            f32x4 ra[TI][L], rb[TI][L];
+            auto load_all = [&](int kbi) {
+#pragma unroll
+                for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+                    for (int j = 0; j < L; ++j) {
+                        ra[ti][j] = *reinterpret_cast<const f32x4 *>(C + row_off(0, ti, j) + 16 * (kb_lo + kbi));
+                        rb[ti][j] = *reinterpret_cast<const f32x4 *>(C + row_off(1, ti, j) + 16 * (kb_lo + kbi));
+                    }
+            };
+            for (int kbi = 0; kbi < nkb; ++kbi) {
+                load_all(kbi);
                 __builtin_amdgcn_sched_barrier(0);
-                compute_batch(r0a, r0b, c * UNR);
+                f32x4 da[TI], db[TI];
+#pragma unroll
+                for (int ti = 0; ti < TI; ++ti) {
+                    da[ti] = finish_operand(DeltaBuilder<L>::template build<L>(ra[ti], oldp, win, 0, 16 * kbi), validA[ti]);
+                    db[ti] = finish_operand(DeltaBuilder<L>::template build<L>(rb[ti], oldp + L * win, win, 0, 16 * kbi), validB[ti]);
+                }
+                mfma_block(da, db);
                 __builtin_amdgcn_sched_barrier(0);
-                compute_batch(r1a, r1b, (c + 1) * UNR);
-            } else {
-                compute_batch(r0a, r0b, c * UNR);
+            }
+        } else {
+            // Heavy shapes (L*TI > 8): the 2*TI operand tiles of a k-block stream through two
+            // rotating L-leaf register buffers (tile t+1 is gathered while tile t is summed), and
+            // tile 0 of the NEXT k-block is gathered before this k-block's MFMAs.
+            auto load_tile = [&](f32x4 (&buf)[L], int side, int ti, int kbi) {
+#pragma unroll
+                for (int j = 0; j < L; ++j)
+                    buf[j] = *reinterpret_cast<const f32x4 *>(C + row_off(side, ti, j) + 16 * (kb_lo + kbi));
+            };
+            f32x4 bufA[L], bufB[L];
+            load_tile(bufA, 0, 0, 0);
+            for (int kbi = 0; kbi < nkb; ++kbi) {
+                f32x4 da[TI], db[TI];
+                const int nxt = (kbi + 1 < nkb) ? kbi + 1 : kbi;   // clamped: the last prefetch is a harmless re-read
+#pragma unroll
+                for (int t = 0; t < 2 * TI; ++t) {
+                    // tiles in the order A0, B0, A1, B1, ...; even t lives in bufA, odd t in bufB
+                    const int side = t & 1, ti = t >> 1;
+                    if (t + 1 < 2 * TI) {
+                        if (((t + 1) & 1) == 0) load_tile(bufA, 0, (t + 1) >> 1, kbi);
+                        else load_tile(bufB, 1, (t + 1) >> 1, kbi);
+                    } else {
+                        load_tile(bufA, 0, 0, nxt);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (side == 0) da[ti] = finish_operand(DeltaBuilder<L>::template build<L>(bufA, oldp, win, 0, 16 * kbi), validA[ti]);
+                    else db[ti] = finish_operand(DeltaBuilder<L>::template build<L>(bufB, oldp + L * win, win, 0, 16 * kbi), validB[ti]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                mfma_block(da, db);
             }
         }
-    } else {
-        f32x4 ra[UNR][TI][L], rb[UNR][TI][L];
-        for (int c = 0; c < nb; ++c) {
-            load_batch(ra, rb, c * UNR);
-            __builtin_amdgcn_sched_barrier(0);
-            compute_batch(ra, rb, c * UNR);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    for (int kbi = nb * UNR; kbi < nkb; ++kbi) {
-        f32x4 ta[TI][L], tb[TI][L];
-#pragma unroll
-        for (int ti = 0; ti < TI; ++ti)
-#pragma unroll
-            for (int j = 0; j < L; ++j) {
-                ta[ti][j] = *reinterpret_cast<const f32x4 *>(C + coffA[ti][j] + 16 * kbi);
-                tb[ti][j] = *reinterpret_cast<const f32x4 *>(C + coffB[ti][j] + 16 * kbi);
-            }
-        compute_one(ta, tb, kbi);
     }
 
     // scores: lane holds rows a = 16*ti + 4*g + v, column bcol = 16*tj + r
