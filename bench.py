@@ -196,6 +196,16 @@ def main():
     dom_ms = acc[dom] / (1 if dom == 0 else iters)
     achieved = dom_fl / (dom_ms * 1e-3) / 1e12 if dom_fl > 0 else 0.0
 
+    # HBM-side traffic of the dominant kernel: from the committed rocprofv3 --pmc passes of this same
+    # workload (counters cannot be collected from inside the timed process); null for other shapes
+    traffic, traffic_note = None, None
+    pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if (D, N, K, B, iters) == (512, 8, 256, 65536, 5) and os.path.exists(pmc_file):
+        pmc = json.load(open(pmc_file))
+        if dom_name in pmc:
+            traffic = pmc[dom_name]["traffic_bytes"]
+            traffic_note = "bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from profiles/r01_pmc_traffic.json"
+
     fpv = total_flops_per_vector(D, N, K, iters)
     value = world * B * args.steps / dt
     out = {
@@ -212,7 +222,8 @@ def main():
                          "frac_of_f32_mfma_peak": round(value / world * fpv / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
         "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2),
                      "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                     "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
+                     "gflop_per_launch": round(dom_fl / 1e9, 2),
                      "avg_launch_ms": round(float(dom_ms), 4)},
         "kernels": kernels,
     }
