@@ -70,6 +70,13 @@ int mcq_encode(const float *x, long B, const void *prepared, float lscale_exp, i
                int refine_iters, uint8_t *out_u8, int64_t *out_i64, void *workspace,
                size_t workspace_bytes, void *stream);
 
+/* Replaces Quantizer._refine_indexes (:308-547) applied `refine_iters` times to caller-supplied
+ * indexes: idx_in int64 [B][N] with entries in [0, K) -> idx_out int64 [B][N] (may alias idx_in).
+ * Same workspace as mcq_encode.                                                               */
+int mcq_refine_indexes(const float *x, long B, const void *prepared, int N, int K, int D, int refine_iters,
+                       const int64_t *idx_in, int64_t *idx_out, void *workspace, size_t workspace_bytes,
+                       void *stream);
+
 /* ---- decode ----------------------------------------------------------------
  * Replaces Quantizer.decode + _maybe_separate_indexes (:117-148, :551-573).
  * codes: [B][codes_per_row] of uint8 (code_bytes == 1) or int64 (code_bytes == 8);

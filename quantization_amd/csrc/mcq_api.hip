@@ -205,7 +205,7 @@ enum { CAT_LOGITS = 0, CAT_RESIDUAL = 1, CAT_STAGE0 = 2, CAT_PRUNE0 = 3, CAT_PAI
 
 int run_encode(const float *x, long B, const void *prepared, float lscale, int N, int K, int D, int iters,
                uint8_t *out_u8, int64_t *out_i64, void *workspace, size_t workspace_bytes, hipStream_t st,
-               Prof *prof) {
+               Prof *prof, const int64_t *init_idx = nullptr) {
     g_last_launches = 0;
     if (!domain_ok(N, K, D)) return (K < 16 || K > 256 || N > 64) ? MCQ_EUNSUPPORTED : MCQ_EINVAL;
     if (B < 0 || iters < 0 || (out_u8 == nullptr) == (out_i64 == nullptr)) return MCQ_EINVAL;
@@ -227,11 +227,17 @@ int run_encode(const float *x, long B, const void *prepared, float lscale, int N
         const Workspace w = carve(workspace, Bc, N, K, Dp);
         const float *xc = x + lo * D;
         int rc;
-        if (prof) prof->begin();
-        rc = launch_gemm<MODE_LOGITS>(K, P.W, xc, nullptr, lscale, P.bias, nullptr, nullptr, Bc, N, D, Dp, w.idx,
-                                      nullptr, st);
-        if (rc) return rc;
-        if (prof) prof->end(CAT_LOGITS);
+        if (init_idx != nullptr) {
+            hipLaunchKernelGGL(k_import_indexes, dim3((unsigned)((Bc * N + 255) / 256)), dim3(256), 0, st,
+                               init_idx + lo * N, Bc * N, K, w.idx);
+            MCQ_LAUNCH_CHECK();
+        } else {
+            if (prof) prof->begin();
+            rc = launch_gemm<MODE_LOGITS>(K, P.W, xc, nullptr, lscale, P.bias, nullptr, nullptr, Bc, N, D, Dp, w.idx,
+                                          nullptr, st);
+            if (rc) return rc;
+            if (prof) prof->end(CAT_LOGITS);
+        }
         for (int it = 0; it < iters; ++it) {
             if (prof) prof->begin();
             hipLaunchKernelGGL(k_residual, dim3((unsigned)((Bc + 3) / 4)), dim3(256), 0, st, xc, w.idx, P.C, Bc, N, K,
@@ -313,6 +319,14 @@ int mcq_encode(const float *x, long B, const void *prepared, float lscale_exp, i
                uint8_t *out_u8, int64_t *out_i64, void *workspace, size_t workspace_bytes, void *stream) {
     return run_encode(x, B, prepared, lscale_exp, N, K, D, refine_iters, out_u8, out_i64, workspace,
                       workspace_bytes, static_cast<hipStream_t>(stream), nullptr);
+}
+
+int mcq_refine_indexes(const float *x, long B, const void *prepared, int N, int K, int D, int refine_iters,
+                       const int64_t *idx_in, int64_t *idx_out, void *workspace, size_t workspace_bytes,
+                       void *stream) {
+    if (B > 0 && (!idx_in || !idx_out)) return MCQ_EINVAL;
+    return run_encode(x, B, prepared, 1.0f, N, K, D, refine_iters, nullptr, idx_out, workspace, workspace_bytes,
+                      static_cast<hipStream_t>(stream), nullptr, B > 0 ? idx_in : nullptr);
 }
 
 int mcq_decode(const void *codes, int code_bytes, int codes_per_row, long B, const void *prepared, int N, int K, int D,

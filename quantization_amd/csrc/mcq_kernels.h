@@ -849,6 +849,16 @@ __global__ void k_finalize(const uint8_t *__restrict__ idx, long B, int N, int p
     }
 }
 
+// int64 indexes supplied by the caller -> the uint8 working copy of the search (values clamped to K-1)
+__global__ void k_import_indexes(const int64_t *__restrict__ in, long n, int K, uint8_t *__restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        long v = in[i];
+        v = v < 0 ? 0 : (v > K - 1 ? K - 1 : v);
+        out[i] = (uint8_t)v;
+    }
+}
+
 // -------------------------------------------------------------------- decode
 // out[b][:] = sum_n C[n][index(b, n)][:D], n ascending (quantization.py:131-148).
 // One wave per vector; codes are uint8 or int64, optionally packed r digits per code

@@ -156,6 +156,30 @@ class Quantizer(nn.Module):
         assert x.ndim == 2 and x.shape[1] == self.dim                     # quantization.py:293
         return self._search(x, refine_indexes_iters, as_bytes=False)
 
+    def _refine_indexes(self, x: Tensor, indexes: Tensor) -> Tensor:
+        """One refinement pass from the given indexes: x (B, dim), indexes (B, num_codebooks) ->
+        int64 (B, num_codebooks).  quantization.py:308-547."""
+        self._check_domain()
+        if not x.is_cuda:
+            raise _lib.McqError("quantization_amd: the index search runs on a HIP device tensor only")
+        L = _lib.lib()
+        N, K, D = self.num_codebooks, self.codebook_size, self.dim
+        x2d = x.detach().to(torch.float32).contiguous()
+        B = x2d.shape[0]
+        idx = indexes.to(device=x2d.device, dtype=torch.int64).contiguous()
+        assert idx.shape == (B, N)
+        out = torch.empty_like(idx)
+        if B == 0:
+            return out
+        blob = self._prepared()
+        ws = self._workspace(B, x2d.device)
+        with torch.cuda.device(x2d.device):
+            st = torch.cuda.current_stream(x2d.device).cuda_stream
+            rc = L.mcq_refine_indexes(x2d.data_ptr(), B, blob.data_ptr(), N, K, D, 1, idx.data_ptr(), out.data_ptr(),
+                                      ws.data_ptr(), ws.numel(), st)
+        _lib.check(rc, "mcq_refine_indexes")
+        return out
+
     def _logits(self, x: Tensor) -> Tensor:
         x = (self.logits_scale * self.scale_speed).exp() * x              # quantization.py:277-279
         return self.to_logits(x)

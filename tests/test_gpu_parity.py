@@ -160,3 +160,21 @@ def test_cpu_tensor_is_rejected_loudly():
     q = load_quantizer(fx["state"], fx["D"], fx["K"], fx["N"])
     with pytest.raises(Exception):
         q.encode(torch.from_numpy(fx["x"][:4]), 1)
+
+
+def test_refine_indexes_from_given_start():
+    fx = fixtures.load("trained_d64_b8_p2")
+    q = load_quantizer(fx["state"], fx["D"], fx["K"], fx["N"])
+    o = oracle_of(fx["state"])
+    x = fx["x"][:64]
+    rs = np.random.RandomState(3)
+    start = rs.randint(0, fx["K"], size=(64, fx["N"])).astype(np.int64)     # arbitrary starting indexes
+    got = q._refine_indexes(torch.from_numpy(x).cuda(), torch.from_numpy(start).cuda())
+    assert got.dtype == torch.int64
+    want = np.stack([o.refine_trace(x[i], start[i])["idx"] for i in range(64)])
+    assert np.array_equal(got.cpu().numpy(), want)
+    # iterating it from the argmax start reproduces _compute_indexes
+    idx = q._compute_indexes(torch.from_numpy(x).cuda(), 0)
+    for _ in range(2):
+        idx = q._refine_indexes(torch.from_numpy(x).cuda(), idx)
+    assert torch.equal(idx, q._compute_indexes(torch.from_numpy(x).cuda(), 2))
