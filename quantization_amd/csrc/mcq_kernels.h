@@ -139,8 +139,54 @@ __device__ __forceinline__ void wave_select_fast(const float (&v)[VPL], const in
         cand[i] = p[i] != kBigPos;
         key[i] = cand[i] ? (((u64)ord32(v[i]) << 32) | (uint32_t)p[i]) : kKeyMax;
     }
-    // quickselect: find the key T with exactly cnt - 1 keys below it
     const int target = cnt - 1;
+    u64 *ldsA = lds, *ldsB = lds + 64;
+    if (VPL > 1 && cnt * VPL <= 64) {
+        // Two-level variant (the common 256 -> 16 case).  T0 = the cnt-th smallest of the 64
+        // per-lane minima bounds the answer from above: every one of the cnt smallest keys is
+        // <= T0, and at most cnt lanes (x VPL keys) hold keys <= T0, so the survivors fit in one
+        // key per lane; they are then ranked exactly.  The quickselect runs on one key per lane.
+        u64 lmin = key[0];
+#pragma unroll
+        for (int i = 1; i < VPL; ++i) lmin = key[i] < lmin ? key[i] : lmin;
+        bool lc = lmin != kKeyMax;
+        u64 T0 = kKeyMax;
+        for (int guard = 0; guard < 65; ++guard) {
+            const u64 cm = __ballot(lc);
+            if (cm == 0) break;
+            const u64 kp = readlane_u64(lmin, __ffsll((long long)cm) - 1);
+            const bool lt = lmin < kp;
+            const int rr = __popcll(__ballot(lt));
+            if (rr == target) { T0 = kp; break; }
+            lc = lc && (rr > target ? lt : (lmin > kp));
+        }
+        int base = 0;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const bool sel = key[i] <= T0;
+            const u64 m = __ballot(sel);
+            const int dst = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+            if (sel && dst < 64) ldsA[dst] = key[i];
+            base += __popcll(m);
+        }
+        const int c0 = base < 64 ? base : 64;
+        wave_lds_fence();
+        const u64 k = (lane < c0) ? ldsA[lane] : kKeyMax;
+        int rnk = 0;
+        for (int j = 0; j < c0; ++j) rnk += (ldsA[j] < k) ? 1 : 0;
+        if (lane < c0 && rnk < cnt) ldsB[rnk] = k;
+        wave_lds_fence();
+        out_v = INFINITY;
+        out_p = M - 1;
+        if (lane < cnt) {
+            const u64 o = ldsB[lane];
+            out_p = (int)(uint32_t)o;
+            out_v = unord32((uint32_t)(o >> 32));
+        }
+        wave_lds_fence();
+        return;
+    }
+    // quickselect: find the key T with exactly cnt - 1 keys below it
     u64 T = 0;
     for (int guard = 0; guard < 64 * VPL + 1; ++guard) {
         u64 lk = kKeyMax;
@@ -170,7 +216,6 @@ __device__ __forceinline__ void wave_select_fast(const float (&v)[VPL], const in
         }
     }
     // compact the cnt selected keys to lds[0..cnt)
-    u64 *ldsA = lds, *ldsB = lds + 64;
     int base = 0;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
