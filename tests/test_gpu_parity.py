@@ -178,3 +178,40 @@ def test_refine_indexes_from_given_start():
     for _ in range(2):
         idx = q._refine_indexes(torch.from_numpy(x).cuda(), idx)
     assert torch.equal(idx, q._compute_indexes(torch.from_numpy(x).cuda(), 2))
+
+
+@pytest.mark.parametrize("D,K,N", [(1, 16, 2), (3, 32, 4), (17, 256, 2), (100, 16, 8), (130, 256, 8)])
+def test_odd_dims_vs_oracle(D, K, N):
+    sd = gen.synthetic_state(900 + D, D, K, N)
+    q = load_quantizer(sd, D, K, N)
+    o = oracle_of(sd)
+    x = gen.make_gaussian(901 + D, 257, D)
+    for it in (0, 1, 3):
+        got = q.encode(torch.from_numpy(x).cuda(), it, as_bytes=False).cpu().numpy()
+        assert np.array_equal(got, o.compute_indexes(x, it)), (D, K, N, it)
+    codes = o.encode(x, 3)
+    assert np.array_equal(q.decode(torch.from_numpy(codes).cuda()).cpu().numpy(), o.decode(codes))
+
+
+def test_small_workspace_forces_chunks_same_codes():
+    """mcq_encode cuts the batch into chunks that fit the caller's workspace; codes do not depend on it."""
+    import ctypes
+    from quantization_amd import _lib
+    fx = fixtures.load("trained_d64_b8_p2")
+    q = load_quantizer(fx["state"], fx["D"], fx["K"], fx["N"])
+    L = _lib.lib()
+    N, K, D = fx["N"], fx["K"], fx["D"]
+    x = torch.from_numpy(fx["x"][:1000]).cuda()
+    whole = q.encode(x, 2)
+    small = L.mcq_encode_workspace_bytes(130, N, K, D)         # room for ~130 vectors -> chunks of 128
+    ws = torch.empty(small, dtype=torch.uint8, device="cuda")
+    out = torch.empty((1000, N), dtype=torch.uint8, device="cuda")
+    rc = L.mcq_encode(x.data_ptr(), 1000, q._prepared().data_ptr(), q._lscale_exp, N, K, D, 2, out.data_ptr(), None,
+                      ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(out, whole)
+    # a workspace too small for 64 vectors is refused, not silently misused
+    rc = L.mcq_encode(x.data_ptr(), 1000, q._prepared().data_ptr(), q._lscale_exp, N, K, D, 2, out.data_ptr(), None,
+                      ws.data_ptr(), 4096 + 10, torch.cuda.current_stream().cuda_stream)
+    assert rc == _lib.MCQ_EWORKSPACE
