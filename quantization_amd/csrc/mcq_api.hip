@@ -115,20 +115,30 @@ int launch_gemm(int K, const float *Bm, const float *xin, const uint8_t *idx_in,
                 hipStream_t st) {
     const unsigned grid = (unsigned)(((B + kGemmVec - 1) / kGemmVec) * N);
     const size_t lds = ((size_t)K * 8 + kGemmVec * 8) * 16;
-#define MCQ_GEMM_CASE(TT)                                                                                       \
+    static const bool four_wave = getenv("MCQ_GEMM4") != nullptr;   // tuning hook: the 4-wave kernel
+    static const size_t lds_pad = getenv("MCQ_GEMM_LDSPAD") ? (size_t)atoi(getenv("MCQ_GEMM_LDSPAD")) : 0;
+    const size_t lds8 = lds + lds_pad;
+#define MCQ_GEMM8_CASE(TT)                                                                                       \
     case 16 * TT:                                                                                               \
-        hipLaunchKernelGGL((k_gemm<TT, MODE>), dim3(grid), dim3(256), lds, st, Bm, xin, idx_in, lscale, bias, R, \
-                           Q, B, N, D, Dp, idx_out, out);                                                       \
+        if (four_wave)                                                                                          \
+            hipLaunchKernelGGL((k_gemm<TT, MODE>), dim3(grid), dim3(256), lds, st, Bm, xin, idx_in, lscale, bias, \
+                               R, Q, B, N, D, Dp, idx_out, out);                                                \
+        else                                                                                                    \
+            hipLaunchKernelGGL((k_gemm8<TT, MODE>), dim3(grid), dim3(512), lds8, st, Bm, xin, idx_in, lscale, bias, \
+                               R, Q, B, N, D, Dp, idx_out, out);                                                \
         break;
     switch (K) {
-        MCQ_GEMM_CASE(1)
-        MCQ_GEMM_CASE(2)
-        MCQ_GEMM_CASE(4)
-        MCQ_GEMM_CASE(8)
-        MCQ_GEMM_CASE(16)
+        case 16:
+            hipLaunchKernelGGL((k_gemm<1, MODE>), dim3(grid), dim3(256), lds, st, Bm, xin, idx_in, lscale, bias, R, Q,
+                               B, N, D, Dp, idx_out, out);
+            break;
+        MCQ_GEMM8_CASE(2)
+        MCQ_GEMM8_CASE(4)
+        MCQ_GEMM8_CASE(8)
+        MCQ_GEMM8_CASE(16)
         default: return MCQ_EUNSUPPORTED;
     }
-#undef MCQ_GEMM_CASE
+#undef MCQ_GEMM8_CASE
     MCQ_LAUNCH_CHECK();
     return 0;
 }

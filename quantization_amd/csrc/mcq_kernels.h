@@ -497,6 +497,162 @@ k_gemm(const float *__restrict__ Bm /*[N][K][Dp]*/, const float *__restrict__ xi
     }
 }
 
+// ---- 8-wave variant (K >= 32) -------------------------------------------------
+// Same tile (64 vectors x K entries x 32-float stages) and the same numerics as k_gemm, but the
+// K entries are split over two groups of four waves: each wave owns 16 vectors x K/2 entries
+// (half the accumulators and fragments: <= 128 VGPRs), so two workgroups per CU give 4 waves per
+// SIMD and the LDS-latency bubble in front of each k-block's MFMAs is covered by the other three.
+template <int T, int MODE>
+__global__ void __launch_bounds__(512, 4)
+k_gemm8(const float *__restrict__ Bm, const float *__restrict__ xin, const uint8_t *__restrict__ idx_in,
+        float lscale, const float *__restrict__ bias, const float *__restrict__ Rin,
+        const float *__restrict__ Qin, long B, int N, int D, int Dp, uint8_t *__restrict__ idx_out,
+        float *__restrict__ out) {
+    static_assert(T >= 2 && T % 2 == 0, "k_gemm8 splits the entry tiles over two wave groups");
+    constexpr int K = 16 * T;
+    constexpr int TW = T / 2;                // entry tiles per wave
+    constexpr int NT = 512;
+    constexpr int A_UNITS = K * 8;
+    constexpr int A_PER_THREAD = (A_UNITS + NT - 1) / NT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4 *ldsA = reinterpret_cast<f32x4 *>(smem);
+    f32x4 *ldsB = ldsA + A_UNITS;
+
+    const int n = blockIdx.x % N;
+    const long b0 = (long)(blockIdx.x / N) * kGemmVec;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int vg = wave & 3, eh = wave >> 2;   // vector group, entry half
+    const int r = lane & 15, g = lane >> 4;
+    const float *Bn = Bm + (long)n * K * Dp;
+    const int xstride = (MODE == MODE_STAGE0) ? Dp : D;
+    const bool x_vec = (MODE == MODE_STAGE0) || (((D & 3) == 0) && ((reinterpret_cast<uintptr_t>(xin) & 15) == 0));
+    const bool fast = (MODE == MODE_STAGE0) || (x_vec && D == Dp);
+
+    // staging: every load unconditional, indices clamped (see k_gemm); 32-bit element offsets from
+    // wave-uniform bases keep the addressing in one VGPR per stream (the chunk is < 2^32 bytes)
+    long browl = b0 + (tid >> 3);
+    browl = browl < B ? browl : B - 1;
+    const float *xbase = xin + b0 * xstride;                       // uniform
+    const uint32_t xoff = (uint32_t)((browl - b0) * xstride);
+    uint32_t ooff = 0;
+    if (MODE == MODE_STAGE0) ooff = (uint32_t)(((long)n * K + idx_in[browl * N + n]) * Dp);
+    uint32_t aoff[A_PER_THREAD];
+#pragma unroll
+    for (int s = 0; s < A_PER_THREAD; ++s) {
+        int row = (tid + NT * s) >> 3;
+        row = row < K ? row : K - 1;
+        aoff[s] = (uint32_t)(row * Dp);
+    }
+
+    f32x4 acc[TW];
+#pragma unroll
+    for (int t = 0; t < TW; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 stA[A_PER_THREAD], stB, stO;
+    const int nkb = Dp / 16;
+    const int nsteps = (nkb + 1) / 2;
+
+    auto load_stage = [&](int step) {
+        const int k0 = step * kGemmBK;
+        int k = k0 + 4 * (tid & 7);
+        k = k < Dp ? k : Dp - 4;
+#pragma unroll
+        for (int s = 0; s < A_PER_THREAD; ++s) stA[s] = *reinterpret_cast<const f32x4 *>(Bn + (aoff[s] + (uint32_t)k));
+        if (fast) {
+            stB = *reinterpret_cast<const f32x4 *>(xbase + (xoff + (uint32_t)k));
+            if (MODE == MODE_STAGE0) stO = *reinterpret_cast<const f32x4 *>(Bm + (ooff + (uint32_t)k));
+        } else {
+            const int kk = k0 + 4 * (tid & 7);
+            const float *xr = xbase + xoff;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) stB[e] = (kk + e < xstride) ? xr[kk + e] : 0.f;
+        }
+    };
+    auto store_stage = [&]() {
+#pragma unroll
+        for (int s = 0; s < A_PER_THREAD; ++s) {
+            const int f = tid + NT * s;
+            if (f < A_UNITS) ldsA[lds_unit(K, f >> 3, (f & 7) >> 2, f & 3)] = stA[s];
+        }
+        const f32x4 v = (MODE == MODE_STAGE0) ? (stB - stO) : (stB * lscale);
+        ldsB[lds_unit(kGemmVec, tid >> 3, (tid & 7) >> 2, tid & 3)] = v;
+    };
+
+    load_stage(0);
+    for (int step = 0; step < nsteps; ++step) {
+        store_stage();
+        __syncthreads();
+        if (step + 1 < nsteps) load_stage(step + 1);
+        const int kbs = (2 * step + 1 < nkb) ? 2 : 1;
+        for (int kb = 0; kb < kbs; ++kb) {
+            const f32x4 bf = ldsB[lds_unit(kGemmVec, 16 * vg + r, kb, g)];
+            f32x4 af[TW];
+#pragma unroll
+            for (int t = 0; t < TW; ++t) af[t] = ldsA[lds_unit(K, 16 * (eh * TW + t) + r, kb, g)];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int t = 0; t < TW; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t][i], bf[i], acc[t], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: lane holds, for vector b0 + 16*vg + r, entries k = 16*(eh*TW + t) + 4g + v
+    const long b = b0 + 16 * vg + r;
+    if (MODE == MODE_STAGE0) {
+        if (b < B) {
+            const float Rv = Rin[b * N + n];
+            float *o = out + (b * N + n) * (long)K;
+#pragma unroll
+            for (int t = 0; t < TW; ++t) {
+                const int k0 = 16 * (eh * TW + t) + 4 * g;
+                const f32x4 q = *reinterpret_cast<const f32x4 *>(Qin + (long)n * K + k0);
+                f32x4 sv;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) sv[v] = (Rv + q[v]) + 2.0f * acc[t][v];
+                *reinterpret_cast<f32x4 *>(o + k0) = sv;
+            }
+        }
+    } else {
+        float best = -INFINITY;
+        int bk = 0;
+        bool first = true;
+#pragma unroll
+        for (int t = 0; t < TW; ++t) {
+            const int k0 = 16 * (eh * TW + t) + 4 * g;
+            const f32x4 bi = *reinterpret_cast<const f32x4 *>(bias + (long)n * K + k0);
+            f32x4 lv;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                lv[v] = acc[t][v] + bi[v];
+                if (first || lv[v] > best) { best = lv[v]; bk = k0 + v; first = false; }
+            }
+            if (MODE == MODE_LOGITS_OUT && b < B) *reinterpret_cast<f32x4 *>(out + (b * N + n) * (long)K + k0) = lv;
+        }
+        if (MODE == MODE_LOGITS) {
+#pragma unroll
+            for (int m = 16; m <= 32; m <<= 1) {
+                const float ov = __shfl_xor(best, m, 64);
+                const int ok = __shfl_xor(bk, m, 64);
+                const bool take = (ov > best) || (ov == best && ok < bk);
+                best = take ? ov : best;
+                bk = take ? ok : bk;
+            }
+            // combine the two entry halves through LDS (free after the last barrier of the loop)
+            float *cv = reinterpret_cast<float *>(smem);
+            int *ck = reinterpret_cast<int *>(smem) + kGemmVec;
+            if (eh == 1 && g == 0) { cv[16 * vg + r] = best; ck[16 * vg + r] = bk; }
+            __syncthreads();
+            if (eh == 0 && g == 0 && b < B) {
+                const float ov = cv[16 * vg + r];
+                const int ok = ck[16 * vg + r];
+                // the upper half only wins with a strictly greater value (first maximum)
+                idx_out[b * N + n] = (uint8_t)((ov > best) ? ok : bk);
+            }
+        }
+    }
+}
+
 // -------------------------------------------------------------------- prune0
 // First sort-and-truncate (quantization.py:470-503 at L = 1): one wave per (b, n)
 // keeps the `keep` smallest of S0[b][n][0..K).  keep == 1 happens only for N == 1,
