@@ -502,7 +502,7 @@ k_gemm(const float *__restrict__ Bm /*[N][K][Dp]*/, const float *__restrict__ xi
 // K entries are split over two groups of four waves: each wave owns 16 vectors x K/2 entries
 // (half the accumulators and fragments: <= 128 VGPRs), so two workgroups per CU give 4 waves per
 // SIMD and the LDS-latency bubble in front of each k-block's MFMAs is covered by the other three.
-template <int T, int MODE>
+template <int T, int MODE, bool DB>
 __global__ void __launch_bounds__(512, 4)
 k_gemm8(const float *__restrict__ Bm, const float *__restrict__ xin, const uint8_t *__restrict__ idx_in,
         float lscale, const float *__restrict__ bias, const float *__restrict__ Rin,
@@ -567,34 +567,54 @@ k_gemm8(const float *__restrict__ Bm, const float *__restrict__ xin, const uint8
             for (int e = 0; e < 4; ++e) stB[e] = (kk + e < xstride) ? xr[kk + e] : 0.f;
         }
     };
-    auto store_stage = [&]() {
+    constexpr int STAGE_UNITS = A_UNITS + kGemmVec * 8;
+    auto store_stage = [&](int buf) {
+        f32x4 *sa = ldsA + (size_t)buf * STAGE_UNITS, *sb = ldsB + (size_t)buf * STAGE_UNITS;
 #pragma unroll
         for (int s = 0; s < A_PER_THREAD; ++s) {
             const int f = tid + NT * s;
-            if (f < A_UNITS) ldsA[lds_unit(K, f >> 3, (f & 7) >> 2, f & 3)] = stA[s];
+            if (f < A_UNITS) sa[lds_unit(K, f >> 3, (f & 7) >> 2, f & 3)] = stA[s];
         }
         const f32x4 v = (MODE == MODE_STAGE0) ? (stB - stO) : (stB * lscale);
-        ldsB[lds_unit(kGemmVec, tid >> 3, (tid & 7) >> 2, tid & 3)] = v;
+        sb[lds_unit(kGemmVec, tid >> 3, (tid & 7) >> 2, tid & 3)] = v;
     };
-
-    load_stage(0);
-    for (int step = 0; step < nsteps; ++step) {
-        store_stage();
-        __syncthreads();
-        if (step + 1 < nsteps) load_stage(step + 1);
+    auto compute_stage = [&](int buf, int step) {
+        const f32x4 *sa = ldsA + (size_t)buf * STAGE_UNITS, *sb = ldsB + (size_t)buf * STAGE_UNITS;
         const int kbs = (2 * step + 1 < nkb) ? 2 : 1;
         for (int kb = 0; kb < kbs; ++kb) {
-            const f32x4 bf = ldsB[lds_unit(kGemmVec, 16 * vg + r, kb, g)];
+            const f32x4 bf = sb[lds_unit(kGemmVec, 16 * vg + r, kb, g)];
             f32x4 af[TW];
 #pragma unroll
-            for (int t = 0; t < TW; ++t) af[t] = ldsA[lds_unit(K, 16 * (eh * TW + t) + r, kb, g)];
+            for (int t = 0; t < TW; ++t) af[t] = sa[lds_unit(K, 16 * (eh * TW + t) + r, kb, g)];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int t = 0; t < TW; ++t)
                     acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t][i], bf[i], acc[t], 0, 0, 0);
         }
+    };
+
+    load_stage(0);
+    if constexpr (DB) {
+        // two LDS stages: the stores of stage s+1 and the loads of stage s+2 overlap the MFMAs of
+        // stage s; one barrier per stage
+        store_stage(0);
         __syncthreads();
+        if (nsteps > 1) load_stage(1);
+        for (int step = 0; step < nsteps; ++step) {
+            compute_stage(step & 1, step);
+            if (step + 1 < nsteps) store_stage((step + 1) & 1);
+            __syncthreads();
+            if (step + 2 < nsteps) load_stage(step + 2);
+        }
+    } else {
+        for (int step = 0; step < nsteps; ++step) {
+            store_stage(0);
+            __syncthreads();
+            if (step + 1 < nsteps) load_stage(step + 1);
+            compute_stage(0, step);
+            __syncthreads();
+        }
     }
 
     // epilogue: lane holds, for vector b0 + 16*vg + r, entries k = 16*(eh*TW + t) + 4g + v
