@@ -217,6 +217,31 @@ int launch_pair(int L, int KI, const float *C, const uint8_t *idx, const float *
     return MCQ_EUNSUPPORTED;
 }
 
+int launch_residual(const float *x, const uint8_t *idx, const float *C, long B, int N, int K, int D, int Dp,
+                    float *xerr, float *E, float *R, hipStream_t st) {
+    const dim3 grid((unsigned)((B + 3) / 4)), block(256);
+    const int J = (Dp / 4 + 63) / 64;
+#define MCQ_RES_CASE(NN, JJ)                                                                                   \
+    if (N == NN && J == JJ) {                                                                                  \
+        hipLaunchKernelGGL((k_residual_reg<NN, JJ>), grid, block, 0, st, x, idx, C, B, K, D, Dp, xerr, E, R);  \
+        MCQ_LAUNCH_CHECK();                                                                                    \
+        return 0;                                                                                              \
+    }
+    MCQ_RES_CASE(8, 2)
+    MCQ_RES_CASE(8, 1)
+    MCQ_RES_CASE(4, 1)
+    MCQ_RES_CASE(4, 2)
+    MCQ_RES_CASE(4, 4)
+    MCQ_RES_CASE(16, 1)
+    MCQ_RES_CASE(16, 2)
+    MCQ_RES_CASE(2, 1)
+    MCQ_RES_CASE(2, 2)
+#undef MCQ_RES_CASE
+    hipLaunchKernelGGL(k_residual, grid, block, 0, st, x, idx, C, B, N, K, D, Dp, xerr, E, R);
+    MCQ_LAUNCH_CHECK();
+    return 0;
+}
+
 // categories for profiling
 enum { CAT_LOGITS = 0, CAT_RESIDUAL = 1, CAT_STAGE0 = 2, CAT_PRUNE0 = 3, CAT_PAIR0 = 4 };
 
@@ -257,9 +282,8 @@ int run_encode(const float *x, long B, const void *prepared, float lscale, int N
         }
         for (int it = 0; it < iters; ++it) {
             if (prof) prof->begin();
-            hipLaunchKernelGGL(k_residual, dim3((unsigned)((Bc + 3) / 4)), dim3(256), 0, st, xc, w.idx, P.C, Bc, N, K,
-                               D, Dp, w.xerr, w.E, w.R);
-            MCQ_LAUNCH_CHECK();
+            rc = launch_residual(xc, w.idx, P.C, Bc, N, K, D, Dp, w.xerr, w.E, w.R, st);
+            if (rc) return rc;
             if (prof) { prof->end(CAT_RESIDUAL); prof->begin(); }
             rc = launch_gemm<MODE_STAGE0>(K, P.C, w.xerr, w.idx, 0.f, nullptr, w.R, P.Q, Bc, N, D, Dp, nullptr, w.S0,
                                           st);

@@ -315,6 +315,74 @@ __global__ void k_residual(const float *__restrict__ x, const uint8_t *__restric
     }
 }
 
+// Register-resident variant for the common small shapes: the N x J old-row float4s of a vector
+// stay in registers between the x_err pass and the R[n] pass, so every codebook row is fetched once
+// (the generic kernel re-reads them).  Same operation order, same results.
+template <int NN, int J>
+__global__ void k_residual_reg(const float *__restrict__ x, const uint8_t *__restrict__ idx,
+                               const float *__restrict__ C, long B, int K, int D, int Dp,
+                               float *__restrict__ xerr, float *__restrict__ E, float *__restrict__ R) {
+    const long b = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int lane = lane_id();
+    const uint8_t *id = idx + b * NN;
+    const float *xb = x + b * D;
+    float *xe = xerr + b * Dp;
+    const bool vec_ok = ((D & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+    const int nq = Dp / 4;
+    f32x4 rows[NN][J];
+#pragma unroll
+    for (int n = 0; n < NN; ++n) {
+        const float *o = C + ((long)n * K + id[n]) * Dp;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const int q = lane + 64 * j;
+            rows[n][j] = (q < nq) ? *reinterpret_cast<const f32x4 *>(o + 4 * (q < nq ? q : 0)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    f32x4 xev[J];
+    float pe = 0.f;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int q = lane + 64 * j;
+        f32x4 t = rows[0][j];
+#pragma unroll
+        for (int n = 1; n < NN; ++n) t = t + rows[n][j];
+        f32x4 xv = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (q < nq) {
+            if (vec_ok && 4 * q + 3 < D) {
+                xv = *reinterpret_cast<const f32x4 *>(xb + 4 * q);
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) xv[c] = (4 * q + c < D) ? xb[4 * q + c] : 0.f;
+            }
+        }
+        t = t - xv;
+        xev[j] = t;
+        if (q < nq) {
+            *reinterpret_cast<f32x4 *>(xe + 4 * q) = t;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) pe = fmaf(t[c], t[c], pe);
+        }
+    }
+    pe = wave_sum_butterfly(pe);
+    if (lane == 0) E[b] = pe;
+#pragma unroll
+    for (int n = 0; n < NN; ++n) {
+        float pr = 0.f;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            if (lane + 64 * j < nq) {
+                const f32x4 t = xev[j] - rows[n][j];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) pr = fmaf(t[c], t[c], pr);
+            }
+        }
+        pr = wave_sum_butterfly(pr);
+        if (lane == 0) R[b * NN + n] = pr;
+    }
+}
+
 // ---------------------------------------------------------------------- GEMM
 // out[b][n][k] = dot16(Bm[n][k][:], A_n[b][:]) for a 64-vector tile and one
 // codebook n per workgroup (4 waves, wave w owns vectors 16w..16w+15 and all
@@ -794,8 +862,8 @@ k_pair(const float *__restrict__ C, const uint8_t *__restrict__ idx, const float
         if constexpr (SMALL) {
 #pragma unroll
             for (int j = 0; j < L; ++j) {
-                coff[0][ti][j] = (uint32_t)(((n0 + j) * K + te[cc * L + j]) * Dp + 4 * ps);
-                coff[1][ti][j] = (uint32_t)(((n0 + L + j) * K + to[cc * L + j]) * Dp + 4 * ps);
+                coff[0][ti][j] = 4u * (uint32_t)(((n0 + j) * K + te[cc * L + j]) * Dp + 4 * ps);
+                coff[1][ti][j] = 4u * (uint32_t)(((n0 + L + j) * K + to[cc * L + j]) * Dp + 4 * ps);
             }
         } else {
 #pragma unroll
@@ -805,14 +873,15 @@ k_pair(const float *__restrict__ C, const uint8_t *__restrict__ idx, const float
             }
         }
     }
-    auto row_off = [&](int side, int ti, int j) -> uint32_t {   // side, ti, j are compile-time at every call
+    auto row_off = [&](int side, int ti, int j) -> uint32_t {   // BYTE offset; side, ti, j compile-time at every call
         if constexpr (SMALL) {
             return coff[side][ti][j];
         } else {
             const uint32_t e = (tw[side][ti][j >> 2] >> (8 * (j & 3))) & 0xffu;
-            return (uint32_t)(((n0 + side * L + j) * K + (int)e) * Dp + 4 * ps);
+            return 4u * (uint32_t)(((n0 + side * L + j) * K + (int)e) * Dp + 4 * ps);
         }
     };
+    const char *Cb = reinterpret_cast<const char *>(C);   // byte offsets (< 2^32) from the uniform base
     auto to_mfma_order = [&](f32x4 v) {
         f32x4 o;
 #pragma unroll
@@ -894,8 +963,8 @@ k_pair(const float *__restrict__ C, const uint8_t *__restrict__ idx, const float
                     for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
                         for (int j = 0; j < L; ++j) {
-                            ra[u][ti][j] = *reinterpret_cast<const f32x4 *>(C + row_off(0, ti, j) + 16 * (kb_lo + kb0 + u));
-                            rb[u][ti][j] = *reinterpret_cast<const f32x4 *>(C + row_off(1, ti, j) + 16 * (kb_lo + kb0 + u));
+                            ra[u][ti][j] = *reinterpret_cast<const f32x4 *>(Cb + (row_off(0, ti, j) + (uint32_t)(64 * (kb_lo + kb0 + u))));
+                            rb[u][ti][j] = *reinterpret_cast<const f32x4 *>(Cb + (row_off(1, ti, j) + (uint32_t)(64 * (kb_lo + kb0 + u))));
                         }
             };
             auto compute_batch = [&](const f32x4 (&ra)[UNR][TI][L], const f32x4 (&rb)[UNR][TI][L], int kb0) {
@@ -942,8 +1011,8 @@ k_pair(const float *__restrict__ C, const uint8_t *__restrict__ idx, const float
                 for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
                     for (int j = 0; j < L; ++j) {
-                        ta[ti][j] = *reinterpret_cast<const f32x4 *>(C + row_off(0, ti, j) + 16 * (kb_lo + kbi));
-                        tb[ti][j] = *reinterpret_cast<const f32x4 *>(C + row_off(1, ti, j) + 16 * (kb_lo + kbi));
+                        ta[ti][j] = *reinterpret_cast<const f32x4 *>(Cb + (row_off(0, ti, j) + (uint32_t)(64 * (kb_lo + kbi))));
+                        tb[ti][j] = *reinterpret_cast<const f32x4 *>(Cb + (row_off(1, ti, j) + (uint32_t)(64 * (kb_lo + kbi))));
                     }
                 f32x4 da[TI], db[TI];
 #pragma unroll
@@ -963,8 +1032,8 @@ k_pair(const float *__restrict__ C, const uint8_t *__restrict__ idx, const float
                 for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
                     for (int j = 0; j < L; ++j) {
-                        ra[ti][j] = *reinterpret_cast<const f32x4 *>(C + row_off(0, ti, j) + 16 * (kb_lo + kbi));
-                        rb[ti][j] = *reinterpret_cast<const f32x4 *>(C + row_off(1, ti, j) + 16 * (kb_lo + kbi));
+                        ra[ti][j] = *reinterpret_cast<const f32x4 *>(Cb + (row_off(0, ti, j) + (uint32_t)(64 * (kb_lo + kbi))));
+                        rb[ti][j] = *reinterpret_cast<const f32x4 *>(Cb + (row_off(1, ti, j) + (uint32_t)(64 * (kb_lo + kbi))));
                     }
             };
             for (int kbi = 0; kbi < nkb; ++kbi) {
@@ -986,7 +1055,7 @@ k_pair(const float *__restrict__ C, const uint8_t *__restrict__ idx, const float
             auto load_tile = [&](f32x4 (&buf)[L], int side, int ti, int kbi) {
 #pragma unroll
                 for (int j = 0; j < L; ++j)
-                    buf[j] = *reinterpret_cast<const f32x4 *>(C + row_off(side, ti, j) + 16 * (kb_lo + kbi));
+                    buf[j] = *reinterpret_cast<const f32x4 *>(Cb + (row_off(side, ti, j) + (uint32_t)(64 * (kb_lo + kbi))));
             };
             f32x4 bufA[L], bufB[L];
             load_tile(bufA, 0, 0, 0);
