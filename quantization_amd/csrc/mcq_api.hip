@@ -383,6 +383,24 @@ int mcq_decode(const void *codes, int code_bytes, int codes_per_row, long B, con
     const Prepared P = prepared_view(prepared, N, K, D);
     const int Dp = round_up16(D);
     const unsigned grid = (unsigned)((B + 3) / 4);
+    const int J = (Dp / 4 + 63) / 64;
+#define MCQ_DEC_CASE(NN, JJ)                                                                                    \
+    if (code_bytes == 1 && rep == 1 && N == NN && J == JJ) {                                                    \
+        hipLaunchKernelGGL((k_decode_reg<NN, JJ>), dim3(grid), dim3(256), 0, st, static_cast<const uint8_t *>(codes), \
+                           B, P.C, K, D, Dp, out);                                                              \
+        hipError_t e2 = hipGetLastError();                                                                      \
+        return e2 == hipSuccess ? 0 : (int)e2;                                                                  \
+    }
+    MCQ_DEC_CASE(8, 2)
+    MCQ_DEC_CASE(8, 1)
+    MCQ_DEC_CASE(4, 1)
+    MCQ_DEC_CASE(4, 2)
+    MCQ_DEC_CASE(4, 4)
+    MCQ_DEC_CASE(16, 1)
+    MCQ_DEC_CASE(16, 2)
+    MCQ_DEC_CASE(2, 1)
+    MCQ_DEC_CASE(2, 2)
+#undef MCQ_DEC_CASE
     if (code_bytes == 1)
         hipLaunchKernelGGL((k_decode<uint8_t>), dim3(grid), dim3(256), 0, st, static_cast<const uint8_t *>(codes),
                            codes_per_row, B, P.C, N, K, D, Dp, out);

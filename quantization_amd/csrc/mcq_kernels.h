@@ -1183,4 +1183,44 @@ __global__ void k_decode(const CodeT *__restrict__ codes, int per_row, long B, c
     }
 }
 
+// Fast path for unpacked uint8 codes and the common small shapes: all NN x J row pieces of a
+// vector are requested before the first add (16 gathers in flight per lane at dim 512 / 8 codebooks).
+template <int NN, int J>
+__global__ void k_decode_reg(const uint8_t *__restrict__ codes, long B, const float *__restrict__ C, int K, int D,
+                             int Dp, float *__restrict__ out) {
+    const long b = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int lane = lane_id();
+    const uint8_t *cb = codes + b * NN;
+    float *ob = out + b * D;
+    const bool vec_ok = ((D & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+    const int nq = Dp / 4;
+    f32x4 rows[NN][J];
+#pragma unroll
+    for (int n = 0; n < NN; ++n) {
+        const float *o = C + ((long)n * K + (cb[n] & (K - 1))) * Dp;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const int q = lane + 64 * j;
+            rows[n][j] = *reinterpret_cast<const f32x4 *>(o + 4 * (q < nq ? q : 0));
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int q = lane + 64 * j;
+        f32x4 t = rows[0][j];
+#pragma unroll
+        for (int n = 1; n < NN; ++n) t = t + rows[n][j];
+        if (q < nq) {
+            if (vec_ok && 4 * q + 3 < D) {
+                *reinterpret_cast<f32x4 *>(ob + 4 * q) = t;
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (4 * q + c < D) ob[4 * q + c] = t[c];
+            }
+        }
+    }
+}
+
 }  // namespace mcq
