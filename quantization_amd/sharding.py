@@ -27,7 +27,11 @@ def encode_sharded(quantizer, x: torch.Tensor, refine_indexes_iters: int = 5, as
     codes = quantizer.encode(flat[lo:hi], refine_indexes_iters, as_bytes)
     if not gather or world == 1:
         return codes
-    sizes = [shard_bounds(flat.shape[0], world, r) for r in range(world)]
-    parts = [torch.empty((b - a, codes.shape[-1]), dtype=codes.dtype, device=codes.device) for a, b in sizes]
-    dist.all_gather(parts, codes.contiguous(), group=group)
-    return torch.cat(parts, dim=0)
+    # all_gather needs equal sizes: pad every shard to the largest (sizes differ by at most one row)
+    sizes = [b - a for a, b in (shard_bounds(flat.shape[0], world, r) for r in range(world))]
+    width = max(sizes)
+    padded = torch.zeros((width, codes.shape[-1]), dtype=codes.dtype, device=codes.device)
+    padded[:codes.shape[0]] = codes
+    parts = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(parts, padded, group=group)
+    return torch.cat([p[:n] for p, n in zip(parts, sizes)], dim=0)
