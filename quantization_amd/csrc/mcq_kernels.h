@@ -747,7 +747,10 @@ k_gemm8(const float *__restrict__ Bm, const float *__restrict__ xin, const uint8
 // waits for.  Here a stage is ONE k-block (20 KB at K = 256) and there are two LDS buffers, so a
 // wave stores stage s+1 right after issuing its MFMAs of stage s while the other waves of the
 // SIMD are still computing; the loads of stage s+2 are issued after the barrier.
-__device__ __forceinline__ int lds_unit1(int rows, int row, int g) { return g * rows + (row ^ g); }
+// one k-block stage: row-major [row][4 units], unit index xor-ed with bits 1-2 of the row:
+// conflict-free for the fragment ds_read_b128 and for the staging ds_write_b128 (4 lanes per row),
+// checked by brute force in tools/lds_conflicts.py
+__device__ __forceinline__ int lds_unit1(int rows, int row, int g) { (void)rows; return row * 4 + (g ^ ((row >> 1) & 3)); }
 
 template <int T, int MODE>
 __global__ void __launch_bounds__(512, 4)
@@ -842,9 +845,12 @@ k_gemm8s(const float *__restrict__ Bm, const float *__restrict__ xin, const uint
 #pragma unroll
             for (int t = 0; t < TW; ++t)
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t][i], bf[i], acc[t], 0, 0, 0);
-        if (kb + 1 < nkb) store_stage((kb + 1) & 1);
+#ifndef MCQ_ABL
+#define MCQ_ABL 0
+#endif
+        if (!(MCQ_ABL & 2)) { if (kb + 1 < nkb) store_stage((kb + 1) & 1); }
         __syncthreads();
-        if (kb + 2 < nkb) load_stage(kb + 2);
+        if (!(MCQ_ABL & 1)) { if (kb + 2 < nkb) load_stage(kb + 2); }
     }
 
     // epilogue (identical to k_gemm8): lane holds, for vector b0 + 16*vg + r, entries 16*(eh*TW+t) + 4g + v
