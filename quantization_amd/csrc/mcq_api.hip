@@ -118,6 +118,7 @@ int launch_gemm(int K, const float *Bm, const float *xin, const uint8_t *idx_in,
     static const bool four_wave = getenv("MCQ_GEMM4") != nullptr;   // tuning hook: the 4-wave kernel
     static const bool double_buf = getenv("MCQ_GEMM_DB") != nullptr; // tuning hook: double-buffered LDS
     static const bool small_stage = getenv("MCQ_GEMM_S") != nullptr; // tuning hook: 16-float stages, 2 buffers
+    static const bool dma_stage = getenv("MCQ_GEMM_D") != nullptr;   // tuning hook: + entries tile by LDS-DMA
     static const size_t lds_pad = getenv("MCQ_GEMM_LDSPAD") ? (size_t)atoi(getenv("MCQ_GEMM_LDSPAD")) : 0;
     const size_t lds8 = lds + lds_pad;
 #define MCQ_GEMM8_CASE(TT)                                                                                       \
@@ -125,7 +126,10 @@ int launch_gemm(int K, const float *Bm, const float *xin, const uint8_t *idx_in,
         if (four_wave)                                                                                          \
             hipLaunchKernelGGL((k_gemm<TT, MODE>), dim3(grid), dim3(256), lds, st, Bm, xin, idx_in, lscale, bias, \
                                R, Q, B, N, D, Dp, idx_out, out);                                                \
-        else if (small_stage) {                                                                                 \
+        else if (dma_stage) {                                                                                   \
+            hipLaunchKernelGGL((k_gemm8d<TT, MODE>), dim3(grid), dim3(512), lds, st, Bm, xin, idx_in, lscale, bias, \
+                               R, Q, B, N, D, Dp, idx_out, out);                                                \
+        } else if (small_stage) {                                                                                 \
             hipLaunchKernelGGL((k_gemm8s<TT, MODE>), dim3(grid), dim3(512), lds, st, Bm, xin, idx_in, lscale, bias, \
                                R, Q, B, N, D, Dp, idx_out, out);                                                \
         } else if (double_buf) {                                                                                  \

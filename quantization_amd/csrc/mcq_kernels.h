@@ -908,6 +908,174 @@ k_gemm8s(const float *__restrict__ Bm, const float *__restrict__ xin, const uint
     }
 }
 
+// ---- 8-wave variant, entries tile by LDS-DMA ----------------------------------------------
+// As k_gemm8s, but the K x 16-float entries tile of each stage is written to LDS by
+// global_load_lds (no staging VGPRs, no ds_write instructions: the ablation of k_gemm8s showed the
+// ds_write_b128 stores of the A tile to be the largest single cost after the MFMAs).  The source
+// address is pre-swizzled per lane so that the linear DMA image IS the conflict-free layout.
+template <int T, int MODE>
+__global__ void __launch_bounds__(512, 4)
+k_gemm8d(const float *__restrict__ Bm, const float *__restrict__ xin, const uint8_t *__restrict__ idx_in,
+         float lscale, const float *__restrict__ bias, const float *__restrict__ Rin,
+         const float *__restrict__ Qin, long B, int N, int D, int Dp, uint8_t *__restrict__ idx_out,
+         float *__restrict__ out) {
+    static_assert(T >= 2 && T % 2 == 0, "k_gemm8d splits the entry tiles over two wave groups");
+    constexpr int K = 16 * T;
+    constexpr int TW = T / 2;
+    constexpr int NT = 512;
+    constexpr int A_UNITS = K * 4;                 // 16-byte units of one k-block of the entries tile
+    constexpr int B_UNITS = kGemmVec * 4;          // 256
+    constexpr int A_PER_THREAD = (A_UNITS + NT - 1) / NT;
+    constexpr int STAGE_UNITS = A_UNITS + B_UNITS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4 *lds = reinterpret_cast<f32x4 *>(smem);  // [2][STAGE_UNITS]
+
+    const int n = blockIdx.x % N;
+    const long b0 = (long)(blockIdx.x / N) * kGemmVec;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int vg = wave & 3, eh = wave >> 2;
+    const int r = lane & 15, g = lane >> 4;
+    const float *Bn = Bm + (long)n * K * Dp;
+    const int xstride = (MODE == MODE_STAGE0) ? Dp : D;
+    const bool x_vec = (MODE == MODE_STAGE0) || (((D & 3) == 0) && ((reinterpret_cast<uintptr_t>(xin) & 15) == 0));
+    const bool fast = (MODE == MODE_STAGE0) || (x_vec && D == Dp);
+
+    // staging: unit f -> (row = f / 4, g = f % 4); threads 0..255 also stage the vector tile
+    const bool has_b = tid < B_UNITS;
+    long browl = b0 + ((tid & (B_UNITS - 1)) >> 2);
+    browl = browl < B ? browl : B - 1;
+    const float *xbase = xin + b0 * xstride;
+    const uint32_t xoff = (uint32_t)((browl - b0) * xstride) + 4 * (tid & 3);
+    uint32_t ooff = 0;
+    if (MODE == MODE_STAGE0) ooff = (uint32_t)(((long)n * K + idx_in[browl * N + n]) * Dp) + 4 * (tid & 3);
+    // the entries tile goes global -> LDS by DMA (global_load_lds, 16 B per lane): wave-instruction
+    // (s, wave) fills the 64 consecutive units starting at (s*8 + wave)*64 of the stage; lane i
+    // fetches the element that belongs at unit u = base + i of the swizzled image: row = u/4,
+    // float4 g = (u%4) ^ ((row/2)%4)   (inverse of lds_unit1)
+    const int uwave = __builtin_amdgcn_readfirstlane(wave);
+    uint32_t asrc[A_PER_THREAD];
+#pragma unroll
+    for (int s = 0; s < A_PER_THREAD; ++s) {
+        const int u = (s * 8 + uwave) * 64 + lane;
+        int row = u >> 2;
+        row = row < K ? row : K - 1;
+        const int gg = (u & 3) ^ ((row >> 1) & 3);
+        asrc[s] = (uint32_t)(row * Dp + 4 * gg);
+    }
+    f32x4 acc[TW];
+#pragma unroll
+    for (int t = 0; t < TW; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 stB = (f32x4){0.f, 0.f, 0.f, 0.f}, stO = stB;
+    const int nkb = Dp / 16;
+
+    auto dma_stage = [&](int kb, int buf) {
+        char *stage = smem + (size_t)buf * STAGE_UNITS * 16;
+#pragma unroll
+        for (int s = 0; s < A_PER_THREAD; ++s) {
+            if ((s * 8 + uwave) * 64 < A_UNITS)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void *)(Bn + (asrc[s] + (uint32_t)(16 * kb))),
+                    (__attribute__((address_space(3))) void *)(stage + (size_t)(s * 8 + uwave) * 1024), 16, 0, 0);
+        }
+    };
+    auto load_stage = [&](int kb) {
+        const uint32_t k = (uint32_t)(16 * kb);
+        if (has_b) {
+            if (fast) {
+                stB = *reinterpret_cast<const f32x4 *>(xbase + (xoff + k));
+                if (MODE == MODE_STAGE0) stO = *reinterpret_cast<const f32x4 *>(Bm + (ooff + k));
+            } else {
+                const int kk = 16 * kb + 4 * (tid & 3);
+                const float *xr = xbase + (xoff - 4 * (tid & 3));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) stB[e] = (kk + e < xstride) ? xr[kk + e] : 0.f;
+            }
+        }
+    };
+    auto store_stage = [&](int buf) {
+        f32x4 *sb = lds + (size_t)buf * STAGE_UNITS + A_UNITS;
+        if (has_b) {
+            const f32x4 v = (MODE == MODE_STAGE0) ? (stB - stO) : (stB * lscale);
+            sb[lds_unit1(kGemmVec, tid >> 2, tid & 3)] = v;
+        }
+    };
+
+    dma_stage(0, 0);
+    load_stage(0);
+    store_stage(0);
+    __syncthreads();   // (the barrier's fence drains vmcnt: the DMA of stage 0 has landed)
+    if (nkb > 1) { dma_stage(1, 1); load_stage(1); }
+    for (int kb = 0; kb < nkb; ++kb) {
+        const f32x4 *sa = lds + (size_t)(kb & 1) * STAGE_UNITS, *sb = sa + A_UNITS;
+        const f32x4 bf = sb[lds_unit1(kGemmVec, 16 * vg + r, g)];
+        f32x4 af[TW];
+#pragma unroll
+        for (int t = 0; t < TW; ++t) af[t] = sa[lds_unit1(K, 16 * (eh * TW + t) + r, g)];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int t = 0; t < TW; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t][i], bf[i], acc[t], 0, 0, 0);
+        if (kb + 1 < nkb) store_stage((kb + 1) & 1);
+        __syncthreads();   // vmcnt(0): the DMA of stage kb+1 has landed; every wave is done with stage kb
+        if (kb + 2 < nkb) { dma_stage(kb + 2, kb & 1); load_stage(kb + 2); }
+    }
+
+    // epilogue (identical to k_gemm8): lane holds, for vector b0 + 16*vg + r, entries 16*(eh*TW+t) + 4g + v
+    const long b = b0 + 16 * vg + r;
+    if (MODE == MODE_STAGE0) {
+        if (b < B) {
+            const float Rv = Rin[b * N + n];
+            float *o = out + (b * N + n) * (long)K;
+#pragma unroll
+            for (int t = 0; t < TW; ++t) {
+                const int k0 = 16 * (eh * TW + t) + 4 * g;
+                const f32x4 q = *reinterpret_cast<const f32x4 *>(Qin + (long)n * K + k0);
+                f32x4 sv;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) sv[v] = (Rv + q[v]) + 2.0f * acc[t][v];
+                *reinterpret_cast<f32x4 *>(o + k0) = sv;
+            }
+        }
+    } else {
+        float best = -INFINITY;
+        int bk = 0;
+        bool first = true;
+#pragma unroll
+        for (int t = 0; t < TW; ++t) {
+            const int k0 = 16 * (eh * TW + t) + 4 * g;
+            const f32x4 bi = *reinterpret_cast<const f32x4 *>(bias + (long)n * K + k0);
+            f32x4 lv;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                lv[v] = acc[t][v] + bi[v];
+                if (first || lv[v] > best) { best = lv[v]; bk = k0 + v; first = false; }
+            }
+            if (MODE == MODE_LOGITS_OUT && b < B) *reinterpret_cast<f32x4 *>(out + (b * N + n) * (long)K + k0) = lv;
+        }
+        if (MODE == MODE_LOGITS) {
+#pragma unroll
+            for (int m = 16; m <= 32; m <<= 1) {
+                const float ov = __shfl_xor(best, m, 64);
+                const int ok = __shfl_xor(bk, m, 64);
+                const bool take = (ov > best) || (ov == best && ok < bk);
+                best = take ? ov : best;
+                bk = take ? ok : bk;
+            }
+            float *cv = reinterpret_cast<float *>(smem);
+            int *ck = reinterpret_cast<int *>(smem) + kGemmVec;
+            __syncthreads();   // every wave is done reading the last stage
+            if (eh == 1 && g == 0) { cv[16 * vg + r] = best; ck[16 * vg + r] = bk; }
+            __syncthreads();
+            if (eh == 0 && g == 0 && b < B) {
+                const float ov = cv[16 * vg + r];
+                const int ok = ck[16 * vg + r];
+                idx_out[b * N + n] = (uint8_t)((ov > best) ? ok : bk);
+            }
+        }
+    }
+}
+
 // -------------------------------------------------------------------- prune0
 // First sort-and-truncate (quantization.py:470-503 at L = 1): one wave per (b, n)
 // keeps the `keep` smallest of S0[b][n][0..K).  keep == 1 happens only for N == 1,
