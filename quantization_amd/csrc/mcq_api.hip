@@ -113,47 +113,34 @@ template <int MODE>
 int launch_gemm(int K, const float *Bm, const float *xin, const uint8_t *idx_in, float lscale, const float *bias,
                 const float *R, const float *Q, long B, int N, int D, int Dp, uint8_t *idx_out, float *out,
                 hipStream_t st) {
-    const unsigned grid = (unsigned)(((B + kGemmVec - 1) / kGemmVec) * N);
-    const size_t lds = ((size_t)K * 8 + kGemmVec * 8) * 16;
-    static const bool four_wave = getenv("MCQ_GEMM4") != nullptr;   // tuning hook: the 4-wave kernel
-    static const bool double_buf = getenv("MCQ_GEMM_DB") != nullptr; // tuning hook: double-buffered LDS
-    static const bool small_stage = getenv("MCQ_GEMM_S") != nullptr; // tuning hook: 16-float stages, 2 buffers
-    static const bool dma_stage = getenv("MCQ_GEMM_D") != nullptr;   // tuning hook: + entries tile by LDS-DMA
-    static const size_t lds_pad = getenv("MCQ_GEMM_LDSPAD") ? (size_t)atoi(getenv("MCQ_GEMM_LDSPAD")) : 0;
-    const size_t lds8 = lds + lds_pad;
-#define MCQ_GEMM8_CASE(TT)                                                                                       \
+    // default: k_gemm8s with 8 waves (64 vectors); tuning hooks: MCQ_GEMM_16W=1 -> 16 waves (128
+    // vectors), MCQ_GEMM4=1 -> the 4-wave 32-float-stage kernel k_gemm (always used for K == 16)
+    static const bool four_wave = getenv("MCQ_GEMM4") != nullptr;
+    static const bool big_block = getenv("MCQ_GEMM_16W") != nullptr;
+    const unsigned grid64 = (unsigned)(((B + 63) / 64) * N), grid128 = (unsigned)(((B + 127) / 128) * N);
+#define MCQ_GEMM_ARGS Bm, xin, idx_in, lscale, bias, R, Q, B, N, D, Dp, idx_out, out
+#define MCQ_GEMM_CASE(TT)                                                                                       \
     case 16 * TT:                                                                                               \
-        if (four_wave)                                                                                          \
-            hipLaunchKernelGGL((k_gemm<TT, MODE>), dim3(grid), dim3(256), lds, st, Bm, xin, idx_in, lscale, bias, \
-                               R, Q, B, N, D, Dp, idx_out, out);                                                \
-        else if (dma_stage) {                                                                                   \
-            hipLaunchKernelGGL((k_gemm8d<TT, MODE>), dim3(grid), dim3(512), lds, st, Bm, xin, idx_in, lscale, bias, \
-                               R, Q, B, N, D, Dp, idx_out, out);                                                \
-        } else if (small_stage) {                                                                                 \
-            hipLaunchKernelGGL((k_gemm8s<TT, MODE>), dim3(grid), dim3(512), lds, st, Bm, xin, idx_in, lscale, bias, \
-                               R, Q, B, N, D, Dp, idx_out, out);                                                \
-        } else if (double_buf) {                                                                                  \
-            static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm8<TT, MODE, true>), \
-                                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds)); \
-            if (attr != hipSuccess) return (int)attr;                                                           \
-            hipLaunchKernelGGL((k_gemm8<TT, MODE, true>), dim3(grid), dim3(512), 2 * lds, st, Bm, xin, idx_in, lscale, \
-                               bias, R, Q, B, N, D, Dp, idx_out, out);                                          \
-        } else                                                                                                  \
-            hipLaunchKernelGGL((k_gemm8<TT, MODE, false>), dim3(grid), dim3(512), lds8, st, Bm, xin, idx_in, lscale, \
-                               bias, R, Q, B, N, D, Dp, idx_out, out);                                          \
+        if (four_wave || TT == 1)                                                                               \
+            hipLaunchKernelGGL((k_gemm<TT, MODE>), dim3(grid64), dim3(256), ((size_t)16 * TT * 8 + 64 * 8) * 16, st, \
+                               MCQ_GEMM_ARGS);                                                                  \
+        else if (big_block)                                                                                     \
+            hipLaunchKernelGGL((k_gemm8s<(TT > 1 ? TT : 2), MODE, 8>), dim3(grid128), dim3(1024),                \
+                               (size_t)2 * (16 * TT * 4 + 128 * 4) * 16, st, MCQ_GEMM_ARGS);                    \
+        else                                                                                                    \
+            hipLaunchKernelGGL((k_gemm8s<(TT > 1 ? TT : 2), MODE, 4>), dim3(grid64), dim3(512),                  \
+                               (size_t)2 * (16 * TT * 4 + 64 * 4) * 16, st, MCQ_GEMM_ARGS);                     \
         break;
     switch (K) {
-        case 16:
-            hipLaunchKernelGGL((k_gemm<1, MODE>), dim3(grid), dim3(256), lds, st, Bm, xin, idx_in, lscale, bias, R, Q,
-                               B, N, D, Dp, idx_out, out);
-            break;
-        MCQ_GEMM8_CASE(2)
-        MCQ_GEMM8_CASE(4)
-        MCQ_GEMM8_CASE(8)
-        MCQ_GEMM8_CASE(16)
+        MCQ_GEMM_CASE(1)
+        MCQ_GEMM_CASE(2)
+        MCQ_GEMM_CASE(4)
+        MCQ_GEMM_CASE(8)
+        MCQ_GEMM_CASE(16)
         default: return MCQ_EUNSUPPORTED;
     }
-#undef MCQ_GEMM8_CASE
+#undef MCQ_GEMM_CASE
+#undef MCQ_GEMM_ARGS
     MCQ_LAUNCH_CHECK();
     return 0;
 }

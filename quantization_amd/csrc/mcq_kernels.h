@@ -565,195 +565,23 @@ k_gemm(const float *__restrict__ Bm /*[N][K][Dp]*/, const float *__restrict__ xi
     }
 }
 
-// ---- 8-wave variant (K >= 32) -------------------------------------------------
-// Same tile (64 vectors x K entries x 32-float stages) and the same numerics as k_gemm, but the
-// K entries are split over two groups of four waves: each wave owns 16 vectors x K/2 entries
-// (half the accumulators and fragments: <= 128 VGPRs), so two workgroups per CU give 4 waves per
-// SIMD and the LDS-latency bubble in front of each k-block's MFMAs is covered by the other three.
-template <int T, int MODE, bool DB>
-__global__ void __launch_bounds__(512, 4)
-k_gemm8(const float *__restrict__ Bm, const float *__restrict__ xin, const uint8_t *__restrict__ idx_in,
-        float lscale, const float *__restrict__ bias, const float *__restrict__ Rin,
-        const float *__restrict__ Qin, long B, int N, int D, int Dp, uint8_t *__restrict__ idx_out,
-        float *__restrict__ out) {
-    static_assert(T >= 2 && T % 2 == 0, "k_gemm8 splits the entry tiles over two wave groups");
-    constexpr int K = 16 * T;
-    constexpr int TW = T / 2;                // entry tiles per wave
-    constexpr int NT = 512;
-    constexpr int A_UNITS = K * 8;
-    constexpr int A_PER_THREAD = (A_UNITS + NT - 1) / NT;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    f32x4 *ldsA = reinterpret_cast<f32x4 *>(smem);
-    f32x4 *ldsB = ldsA + A_UNITS;
-
-    const int n = blockIdx.x % N;
-    const long b0 = (long)(blockIdx.x / N) * kGemmVec;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int vg = wave & 3, eh = wave >> 2;   // vector group, entry half
-    const int r = lane & 15, g = lane >> 4;
-    const float *Bn = Bm + (long)n * K * Dp;
-    const int xstride = (MODE == MODE_STAGE0) ? Dp : D;
-    const bool x_vec = (MODE == MODE_STAGE0) || (((D & 3) == 0) && ((reinterpret_cast<uintptr_t>(xin) & 15) == 0));
-    const bool fast = (MODE == MODE_STAGE0) || (x_vec && D == Dp);
-
-    // staging: every load unconditional, indices clamped (see k_gemm); 32-bit element offsets from
-    // wave-uniform bases keep the addressing in one VGPR per stream (the chunk is < 2^32 bytes)
-    long browl = b0 + (tid >> 3);
-    browl = browl < B ? browl : B - 1;
-    const float *xbase = xin + b0 * xstride;                       // uniform
-    const uint32_t xoff = (uint32_t)((browl - b0) * xstride);
-    uint32_t ooff = 0;
-    if (MODE == MODE_STAGE0) ooff = (uint32_t)(((long)n * K + idx_in[browl * N + n]) * Dp);
-    uint32_t aoff[A_PER_THREAD];
-#pragma unroll
-    for (int s = 0; s < A_PER_THREAD; ++s) {
-        int row = (tid + NT * s) >> 3;
-        row = row < K ? row : K - 1;
-        aoff[s] = (uint32_t)(row * Dp);
-    }
-
-    f32x4 acc[TW];
-#pragma unroll
-    for (int t = 0; t < TW; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    f32x4 stA[A_PER_THREAD], stB, stO;
-    const int nkb = Dp / 16;
-    const int nsteps = (nkb + 1) / 2;
-
-    auto load_stage = [&](int step) {
-        const int k0 = step * kGemmBK;
-        int k = k0 + 4 * (tid & 7);
-        k = k < Dp ? k : Dp - 4;
-#pragma unroll
-        for (int s = 0; s < A_PER_THREAD; ++s) stA[s] = *reinterpret_cast<const f32x4 *>(Bn + (aoff[s] + (uint32_t)k));
-        if (fast) {
-            stB = *reinterpret_cast<const f32x4 *>(xbase + (xoff + (uint32_t)k));
-            if (MODE == MODE_STAGE0) stO = *reinterpret_cast<const f32x4 *>(Bm + (ooff + (uint32_t)k));
-        } else {
-            const int kk = k0 + 4 * (tid & 7);
-            const float *xr = xbase + xoff;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) stB[e] = (kk + e < xstride) ? xr[kk + e] : 0.f;
-        }
-    };
-    constexpr int STAGE_UNITS = A_UNITS + kGemmVec * 8;
-    auto store_stage = [&](int buf) {
-        f32x4 *sa = ldsA + (size_t)buf * STAGE_UNITS, *sb = ldsB + (size_t)buf * STAGE_UNITS;
-#pragma unroll
-        for (int s = 0; s < A_PER_THREAD; ++s) {
-            const int f = tid + NT * s;
-            if (f < A_UNITS) sa[lds_unit(K, f >> 3, (f & 7) >> 2, f & 3)] = stA[s];
-        }
-        const f32x4 v = (MODE == MODE_STAGE0) ? (stB - stO) : (stB * lscale);
-        sb[lds_unit(kGemmVec, tid >> 3, (tid & 7) >> 2, tid & 3)] = v;
-    };
-    auto compute_stage = [&](int buf, int step) {
-        const f32x4 *sa = ldsA + (size_t)buf * STAGE_UNITS, *sb = ldsB + (size_t)buf * STAGE_UNITS;
-        const int kbs = (2 * step + 1 < nkb) ? 2 : 1;
-        for (int kb = 0; kb < kbs; ++kb) {
-            const f32x4 bf = sb[lds_unit(kGemmVec, 16 * vg + r, kb, g)];
-            f32x4 af[TW];
-#pragma unroll
-            for (int t = 0; t < TW; ++t) af[t] = sa[lds_unit(K, 16 * (eh * TW + t) + r, kb, g)];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int t = 0; t < TW; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t][i], bf[i], acc[t], 0, 0, 0);
-        }
-    };
-
-    load_stage(0);
-    if constexpr (DB) {
-        // two LDS stages: the stores of stage s+1 and the loads of stage s+2 overlap the MFMAs of
-        // stage s; one barrier per stage
-        store_stage(0);
-        __syncthreads();
-        if (nsteps > 1) load_stage(1);
-        for (int step = 0; step < nsteps; ++step) {
-            compute_stage(step & 1, step);
-            if (step + 1 < nsteps) store_stage((step + 1) & 1);
-            __syncthreads();
-            if (step + 2 < nsteps) load_stage(step + 2);
-        }
-    } else {
-        for (int step = 0; step < nsteps; ++step) {
-            store_stage(0);
-            __syncthreads();
-            if (step + 1 < nsteps) load_stage(step + 1);
-            compute_stage(0, step);
-            __syncthreads();
-        }
-    }
-
-    // epilogue: lane holds, for vector b0 + 16*vg + r, entries k = 16*(eh*TW + t) + 4g + v
-    const long b = b0 + 16 * vg + r;
-    if (MODE == MODE_STAGE0) {
-        if (b < B) {
-            const float Rv = Rin[b * N + n];
-            float *o = out + (b * N + n) * (long)K;
-#pragma unroll
-            for (int t = 0; t < TW; ++t) {
-                const int k0 = 16 * (eh * TW + t) + 4 * g;
-                const f32x4 q = *reinterpret_cast<const f32x4 *>(Qin + (long)n * K + k0);
-                f32x4 sv;
-#pragma unroll
-                for (int v = 0; v < 4; ++v) sv[v] = (Rv + q[v]) + 2.0f * acc[t][v];
-                *reinterpret_cast<f32x4 *>(o + k0) = sv;
-            }
-        }
-    } else {
-        float best = -INFINITY;
-        int bk = 0;
-        bool first = true;
-#pragma unroll
-        for (int t = 0; t < TW; ++t) {
-            const int k0 = 16 * (eh * TW + t) + 4 * g;
-            const f32x4 bi = *reinterpret_cast<const f32x4 *>(bias + (long)n * K + k0);
-            f32x4 lv;
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                lv[v] = acc[t][v] + bi[v];
-                if (first || lv[v] > best) { best = lv[v]; bk = k0 + v; first = false; }
-            }
-            if (MODE == MODE_LOGITS_OUT && b < B) *reinterpret_cast<f32x4 *>(out + (b * N + n) * (long)K + k0) = lv;
-        }
-        if (MODE == MODE_LOGITS) {
-#pragma unroll
-            for (int m = 16; m <= 32; m <<= 1) {
-                const float ov = __shfl_xor(best, m, 64);
-                const int ok = __shfl_xor(bk, m, 64);
-                const bool take = (ov > best) || (ov == best && ok < bk);
-                best = take ? ov : best;
-                bk = take ? ok : bk;
-            }
-            // combine the two entry halves through LDS (free after the last barrier of the loop)
-            float *cv = reinterpret_cast<float *>(smem);
-            int *ck = reinterpret_cast<int *>(smem) + kGemmVec;
-            if (eh == 1 && g == 0) { cv[16 * vg + r] = best; ck[16 * vg + r] = bk; }
-            __syncthreads();
-            if (eh == 0 && g == 0 && b < B) {
-                const float ov = cv[16 * vg + r];
-                const int ok = ck[16 * vg + r];
-                // the upper half only wins with a strictly greater value (first maximum)
-                idx_out[b * N + n] = (uint8_t)((ov > best) ? ok : bk);
-            }
-        }
-    }
-}
-
-// ---- 8-wave variant, 16-float stages, two LDS buffers ---------------------------------
-// Measured on k_gemm8: with the per-stage global loads and LDS stores removed the same MFMA loop
-// runs at 140 TFLOP/s instead of 108 -- the staging phase, not the barriers, is what the MFMA pipe
-// waits for.  Here a stage is ONE k-block (20 KB at K = 256) and there are two LDS buffers, so a
-// wave stores stage s+1 right after issuing its MFMAs of stage s while the other waves of the
-// SIMD are still computing; the loads of stage s+2 are issued after the barrier.
+// ---- 8/16-wave variant (K >= 32): the default GEMM -----------------------------------------
+// Same tile and numerics as k_gemm, but the K entries are split over two groups of VGN waves: each
+// wave owns 16 vectors x K/2 entries (half the accumulators and fragments: <= 128 VGPRs, 4 waves per
+// SIMD).  A stage is ONE k-block (20 KB at K = 256) and there are two LDS buffers, so a wave stores
+// stage s+1 right after issuing its MFMAs of stage s while the other waves of the SIMD are still
+// computing; the loads of stage s+2 are issued after the barrier (one barrier per stage).
+// Ablation (this kernel, dim 512): without the per-stage LDS stores the loop runs at 135 TFLOP/s,
+// without the global loads 125, as is 111-115: LDS write bandwidth competing with the fragment
+// reads is what the MFMA pipe waits for -- barriers are free, and writing the entries tile by
+// LDS-DMA (global_load_lds) or from a 32-float single/double-buffered stage measured no better.
 // one k-block stage: row-major [row][4 units], unit index xor-ed with bits 1-2 of the row:
 // conflict-free for the fragment ds_read_b128 and for the staging ds_write_b128 (4 lanes per row),
 // checked by brute force in tools/lds_conflicts.py
 __device__ __forceinline__ int lds_unit1(int rows, int row, int g) { (void)rows; return row * 4 + (g ^ ((row >> 1) & 3)); }
 
-template <int T, int MODE>
-__global__ void __launch_bounds__(512, 4)
+template <int T, int MODE, int VGN>
+__global__ void __launch_bounds__(128 * VGN, 4)
 k_gemm8s(const float *__restrict__ Bm, const float *__restrict__ xin, const uint8_t *__restrict__ idx_in,
          float lscale, const float *__restrict__ bias, const float *__restrict__ Rin,
          const float *__restrict__ Qin, long B, int N, int D, int Dp, uint8_t *__restrict__ idx_out,
@@ -761,18 +589,19 @@ k_gemm8s(const float *__restrict__ Bm, const float *__restrict__ xin, const uint
     static_assert(T >= 2 && T % 2 == 0, "k_gemm8s splits the entry tiles over two wave groups");
     constexpr int K = 16 * T;
     constexpr int TW = T / 2;
-    constexpr int NT = 512;
+    constexpr int NT = 128 * VGN;             // VGN vector groups x 2 entry halves, one wave each
+    constexpr int VEC = 16 * VGN;              // vectors per workgroup
     constexpr int A_UNITS = K * 4;                 // 16-byte units of one k-block of the entries tile
-    constexpr int B_UNITS = kGemmVec * 4;          // 256
+    constexpr int B_UNITS = VEC * 4;
     constexpr int A_PER_THREAD = (A_UNITS + NT - 1) / NT;
     constexpr int STAGE_UNITS = A_UNITS + B_UNITS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4 *lds = reinterpret_cast<f32x4 *>(smem);  // [2][STAGE_UNITS]
 
     const int n = blockIdx.x % N;
-    const long b0 = (long)(blockIdx.x / N) * kGemmVec;
+    const long b0 = (long)(blockIdx.x / N) * VEC;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int vg = wave & 3, eh = wave >> 2;
+    const int vg = wave % VGN, eh = wave / VGN;
     const int r = lane & 15, g = lane >> 4;
     const float *Bn = Bm + (long)n * K * Dp;
     const int xstride = (MODE == MODE_STAGE0) ? Dp : D;
@@ -826,7 +655,7 @@ k_gemm8s(const float *__restrict__ Bm, const float *__restrict__ xin, const uint
         }
         if (has_b) {
             const f32x4 v = (MODE == MODE_STAGE0) ? (stB - stO) : (stB * lscale);
-            sb[lds_unit1(kGemmVec, tid >> 2, tid & 3)] = v;
+            sb[lds_unit1(VEC, tid >> 2, tid & 3)] = v;
         }
     };
 
@@ -836,178 +665,7 @@ k_gemm8s(const float *__restrict__ Bm, const float *__restrict__ xin, const uint
     if (nkb > 1) load_stage(1);
     for (int kb = 0; kb < nkb; ++kb) {
         const f32x4 *sa = lds + (size_t)(kb & 1) * STAGE_UNITS, *sb = sa + A_UNITS;
-        const f32x4 bf = sb[lds_unit1(kGemmVec, 16 * vg + r, g)];
-        f32x4 af[TW];
-#pragma unroll
-        for (int t = 0; t < TW; ++t) af[t] = sa[lds_unit1(K, 16 * (eh * TW + t) + r, g)];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int t = 0; t < TW; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t][i], bf[i], acc[t], 0, 0, 0);
-#ifndef MCQ_ABL
-#define MCQ_ABL 0
-#endif
-        if (!(MCQ_ABL & 2)) { if (kb + 1 < nkb) store_stage((kb + 1) & 1); }
-        __syncthreads();
-        if (!(MCQ_ABL & 1)) { if (kb + 2 < nkb) load_stage(kb + 2); }
-    }
-
-    // epilogue (identical to k_gemm8): lane holds, for vector b0 + 16*vg + r, entries 16*(eh*TW+t) + 4g + v
-    const long b = b0 + 16 * vg + r;
-    if (MODE == MODE_STAGE0) {
-        if (b < B) {
-            const float Rv = Rin[b * N + n];
-            float *o = out + (b * N + n) * (long)K;
-#pragma unroll
-            for (int t = 0; t < TW; ++t) {
-                const int k0 = 16 * (eh * TW + t) + 4 * g;
-                const f32x4 q = *reinterpret_cast<const f32x4 *>(Qin + (long)n * K + k0);
-                f32x4 sv;
-#pragma unroll
-                for (int v = 0; v < 4; ++v) sv[v] = (Rv + q[v]) + 2.0f * acc[t][v];
-                *reinterpret_cast<f32x4 *>(o + k0) = sv;
-            }
-        }
-    } else {
-        float best = -INFINITY;
-        int bk = 0;
-        bool first = true;
-#pragma unroll
-        for (int t = 0; t < TW; ++t) {
-            const int k0 = 16 * (eh * TW + t) + 4 * g;
-            const f32x4 bi = *reinterpret_cast<const f32x4 *>(bias + (long)n * K + k0);
-            f32x4 lv;
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                lv[v] = acc[t][v] + bi[v];
-                if (first || lv[v] > best) { best = lv[v]; bk = k0 + v; first = false; }
-            }
-            if (MODE == MODE_LOGITS_OUT && b < B) *reinterpret_cast<f32x4 *>(out + (b * N + n) * (long)K + k0) = lv;
-        }
-        if (MODE == MODE_LOGITS) {
-#pragma unroll
-            for (int m = 16; m <= 32; m <<= 1) {
-                const float ov = __shfl_xor(best, m, 64);
-                const int ok = __shfl_xor(bk, m, 64);
-                const bool take = (ov > best) || (ov == best && ok < bk);
-                best = take ? ov : best;
-                bk = take ? ok : bk;
-            }
-            float *cv = reinterpret_cast<float *>(smem);
-            int *ck = reinterpret_cast<int *>(smem) + kGemmVec;
-            __syncthreads();   // every wave is done reading the last stage
-            if (eh == 1 && g == 0) { cv[16 * vg + r] = best; ck[16 * vg + r] = bk; }
-            __syncthreads();
-            if (eh == 0 && g == 0 && b < B) {
-                const float ov = cv[16 * vg + r];
-                const int ok = ck[16 * vg + r];
-                idx_out[b * N + n] = (uint8_t)((ov > best) ? ok : bk);
-            }
-        }
-    }
-}
-
-// ---- 8-wave variant, entries tile by LDS-DMA ----------------------------------------------
-// As k_gemm8s, but the K x 16-float entries tile of each stage is written to LDS by
-// global_load_lds (no staging VGPRs, no ds_write instructions: the ablation of k_gemm8s showed the
-// ds_write_b128 stores of the A tile to be the largest single cost after the MFMAs).  The source
-// address is pre-swizzled per lane so that the linear DMA image IS the conflict-free layout.
-template <int T, int MODE>
-__global__ void __launch_bounds__(512, 4)
-k_gemm8d(const float *__restrict__ Bm, const float *__restrict__ xin, const uint8_t *__restrict__ idx_in,
-         float lscale, const float *__restrict__ bias, const float *__restrict__ Rin,
-         const float *__restrict__ Qin, long B, int N, int D, int Dp, uint8_t *__restrict__ idx_out,
-         float *__restrict__ out) {
-    static_assert(T >= 2 && T % 2 == 0, "k_gemm8d splits the entry tiles over two wave groups");
-    constexpr int K = 16 * T;
-    constexpr int TW = T / 2;
-    constexpr int NT = 512;
-    constexpr int A_UNITS = K * 4;                 // 16-byte units of one k-block of the entries tile
-    constexpr int B_UNITS = kGemmVec * 4;          // 256
-    constexpr int A_PER_THREAD = (A_UNITS + NT - 1) / NT;
-    constexpr int STAGE_UNITS = A_UNITS + B_UNITS;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    f32x4 *lds = reinterpret_cast<f32x4 *>(smem);  // [2][STAGE_UNITS]
-
-    const int n = blockIdx.x % N;
-    const long b0 = (long)(blockIdx.x / N) * kGemmVec;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int vg = wave & 3, eh = wave >> 2;
-    const int r = lane & 15, g = lane >> 4;
-    const float *Bn = Bm + (long)n * K * Dp;
-    const int xstride = (MODE == MODE_STAGE0) ? Dp : D;
-    const bool x_vec = (MODE == MODE_STAGE0) || (((D & 3) == 0) && ((reinterpret_cast<uintptr_t>(xin) & 15) == 0));
-    const bool fast = (MODE == MODE_STAGE0) || (x_vec && D == Dp);
-
-    // staging: unit f -> (row = f / 4, g = f % 4); threads 0..255 also stage the vector tile
-    const bool has_b = tid < B_UNITS;
-    long browl = b0 + ((tid & (B_UNITS - 1)) >> 2);
-    browl = browl < B ? browl : B - 1;
-    const float *xbase = xin + b0 * xstride;
-    const uint32_t xoff = (uint32_t)((browl - b0) * xstride) + 4 * (tid & 3);
-    uint32_t ooff = 0;
-    if (MODE == MODE_STAGE0) ooff = (uint32_t)(((long)n * K + idx_in[browl * N + n]) * Dp) + 4 * (tid & 3);
-    // the entries tile goes global -> LDS by DMA (global_load_lds, 16 B per lane): wave-instruction
-    // (s, wave) fills the 64 consecutive units starting at (s*8 + wave)*64 of the stage; lane i
-    // fetches the element that belongs at unit u = base + i of the swizzled image: row = u/4,
-    // float4 g = (u%4) ^ ((row/2)%4)   (inverse of lds_unit1)
-    const int uwave = __builtin_amdgcn_readfirstlane(wave);
-    uint32_t asrc[A_PER_THREAD];
-#pragma unroll
-    for (int s = 0; s < A_PER_THREAD; ++s) {
-        const int u = (s * 8 + uwave) * 64 + lane;
-        int row = u >> 2;
-        row = row < K ? row : K - 1;
-        const int gg = (u & 3) ^ ((row >> 1) & 3);
-        asrc[s] = (uint32_t)(row * Dp + 4 * gg);
-    }
-    f32x4 acc[TW];
-#pragma unroll
-    for (int t = 0; t < TW; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    f32x4 stB = (f32x4){0.f, 0.f, 0.f, 0.f}, stO = stB;
-    const int nkb = Dp / 16;
-
-    auto dma_stage = [&](int kb, int buf) {
-        char *stage = smem + (size_t)buf * STAGE_UNITS * 16;
-#pragma unroll
-        for (int s = 0; s < A_PER_THREAD; ++s) {
-            if ((s * 8 + uwave) * 64 < A_UNITS)
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void *)(Bn + (asrc[s] + (uint32_t)(16 * kb))),
-                    (__attribute__((address_space(3))) void *)(stage + (size_t)(s * 8 + uwave) * 1024), 16, 0, 0);
-        }
-    };
-    auto load_stage = [&](int kb) {
-        const uint32_t k = (uint32_t)(16 * kb);
-        if (has_b) {
-            if (fast) {
-                stB = *reinterpret_cast<const f32x4 *>(xbase + (xoff + k));
-                if (MODE == MODE_STAGE0) stO = *reinterpret_cast<const f32x4 *>(Bm + (ooff + k));
-            } else {
-                const int kk = 16 * kb + 4 * (tid & 3);
-                const float *xr = xbase + (xoff - 4 * (tid & 3));
-#pragma unroll
-                for (int e = 0; e < 4; ++e) stB[e] = (kk + e < xstride) ? xr[kk + e] : 0.f;
-            }
-        }
-    };
-    auto store_stage = [&](int buf) {
-        f32x4 *sb = lds + (size_t)buf * STAGE_UNITS + A_UNITS;
-        if (has_b) {
-            const f32x4 v = (MODE == MODE_STAGE0) ? (stB - stO) : (stB * lscale);
-            sb[lds_unit1(kGemmVec, tid >> 2, tid & 3)] = v;
-        }
-    };
-
-    dma_stage(0, 0);
-    load_stage(0);
-    store_stage(0);
-    __syncthreads();   // (the barrier's fence drains vmcnt: the DMA of stage 0 has landed)
-    if (nkb > 1) { dma_stage(1, 1); load_stage(1); }
-    for (int kb = 0; kb < nkb; ++kb) {
-        const f32x4 *sa = lds + (size_t)(kb & 1) * STAGE_UNITS, *sb = sa + A_UNITS;
-        const f32x4 bf = sb[lds_unit1(kGemmVec, 16 * vg + r, g)];
+        const f32x4 bf = sb[lds_unit1(VEC, 16 * vg + r, g)];
         f32x4 af[TW];
 #pragma unroll
         for (int t = 0; t < TW; ++t) af[t] = sa[lds_unit1(K, 16 * (eh * TW + t) + r, g)];
@@ -1017,11 +675,11 @@ k_gemm8d(const float *__restrict__ Bm, const float *__restrict__ xin, const uint
             for (int t = 0; t < TW; ++t)
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t][i], bf[i], acc[t], 0, 0, 0);
         if (kb + 1 < nkb) store_stage((kb + 1) & 1);
-        __syncthreads();   // vmcnt(0): the DMA of stage kb+1 has landed; every wave is done with stage kb
-        if (kb + 2 < nkb) { dma_stage(kb + 2, kb & 1); load_stage(kb + 2); }
+        __syncthreads();
+        if (kb + 2 < nkb) load_stage(kb + 2);
     }
 
-    // epilogue (identical to k_gemm8): lane holds, for vector b0 + 16*vg + r, entries 16*(eh*TW+t) + 4g + v
+    // epilogue: lane holds, for vector b0 + 16*vg + r, entries 16*(eh*TW+t) + 4g + v
     const long b = b0 + 16 * vg + r;
     if (MODE == MODE_STAGE0) {
         if (b < B) {
@@ -1063,7 +721,7 @@ k_gemm8d(const float *__restrict__ Bm, const float *__restrict__ xin, const uint
                 bk = take ? ok : bk;
             }
             float *cv = reinterpret_cast<float *>(smem);
-            int *ck = reinterpret_cast<int *>(smem) + kGemmVec;
+            int *ck = reinterpret_cast<int *>(smem) + VEC;
             __syncthreads();   // every wave is done reading the last stage
             if (eh == 1 && g == 0) { cv[16 * vg + r] = best; ck[16 * vg + r] = bk; }
             __syncthreads();
