@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("MCQ_LIB_OVERRIDE") or os.path.join(_HERE, "lib", "libmcq_hip.so")   # override: experiments only
+LIB_PATH = os.path.join(_HERE, "lib", "libmcq_hip.so")
 
 # every symbol include/mcq.h declares
 SYMBOLS = (

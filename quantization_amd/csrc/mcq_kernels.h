@@ -414,7 +414,6 @@ k_gemm(const float *__restrict__ Bm /*[N][K][Dp]*/, const float *__restrict__ xi
        uint8_t *__restrict__ idx_out, float *__restrict__ out) {
     constexpr int K = 16 * T;
     constexpr int A_UNITS = K * 8;           // 16-byte units of the entries tile per stage
-    constexpr int B_UNITS = kGemmVec * 8;
     constexpr int A_PER_THREAD = (A_UNITS + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4 *ldsA = reinterpret_cast<f32x4 *>(smem);
