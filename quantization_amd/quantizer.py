@@ -52,6 +52,14 @@ class Quantizer(nn.Module):
         self._prep = None       # (key, device buffer) of derived state for the kernels
         self._ws = None         # cached encode workspace (device uint8 tensor)
 
+    def __getstate__(self):
+        # derived device state and scratch are rebuilt on demand: keep them out of pickles / deepcopies
+        st = super().__getstate__() if hasattr(super(), "__getstate__") else self.__dict__.copy()
+        st = dict(st)
+        st["_prep"] = None
+        st["_ws"] = None
+        return st
+
     # ------------------------------------------------------------ bookkeeping
     def load_state_dict(self, *args, **kwargs):
         ret = super().load_state_dict(*args, **kwargs)
