@@ -54,9 +54,16 @@ struct Workspace {
     float *S[2];
 };
 
+// the first selection is fused into the stage-0 GEMM (no S0 buffer) for K >= 32 and N >= 2, unless a
+// tuning hook selects the 4-wave GEMM
+bool fused_select(int N, int K) {
+    static const bool off = getenv("MCQ_GEMM4") != nullptr || getenv("MCQ_NO_FUSED_SELECT") != nullptr;
+    return !off && K >= 32 && N >= 2;
+}
+
 size_t workspace_per_vector(int N, int K, int Dp) {
-    return (size_t)N + 4 * (size_t)Dp + 4 + 4 * (size_t)N + 4 * (size_t)N * K + 2 * 64 * (size_t)N +
-           2 * 4 * 16 * (size_t)N;
+    const size_t s0 = fused_select(N, K) ? 0 : 4 * (size_t)N * K;
+    return (size_t)N + 4 * (size_t)Dp + 4 + 4 * (size_t)N + s0 + 2 * 64 * (size_t)N + 2 * 4 * 16 * (size_t)N;
 }
 constexpr size_t kWorkspaceSlack = 16 * 256;
 constexpr long kDefaultChunk = 65536;
@@ -70,7 +77,7 @@ Workspace carve(void *ws, long Bc, int N, int K, int Dp) {
     w.xerr = reinterpret_cast<float *>(take((size_t)Bc * Dp * 4));
     w.E = reinterpret_cast<float *>(take((size_t)Bc * 4));
     w.R = reinterpret_cast<float *>(take((size_t)Bc * N * 4));
-    w.S0 = reinterpret_cast<float *>(take((size_t)Bc * N * K * 4));
+    w.S0 = fused_select(N, K) ? nullptr : reinterpret_cast<float *>(take((size_t)Bc * N * K * 4));
     for (int i = 0; i < 2; ++i) w.tup[i] = reinterpret_cast<uint8_t *>(take((size_t)Bc * N * 64));
     for (int i = 0; i < 2; ++i) w.S[i] = reinterpret_cast<float *>(take((size_t)Bc * N * 16 * 4));
     return w;
@@ -112,24 +119,30 @@ thread_local int g_last_launches = 0;
 template <int MODE>
 int launch_gemm(int K, const float *Bm, const float *xin, const uint8_t *idx_in, float lscale, const float *bias,
                 const float *R, const float *Q, long B, int N, int D, int Dp, uint8_t *idx_out, float *out,
-                hipStream_t st) {
+                hipStream_t st, int keep = 0) {
     // default: k_gemm8s with 8 waves (64 vectors); tuning hooks: MCQ_GEMM_16W=1 -> 16 waves (128
     // vectors), MCQ_GEMM4=1 -> the 4-wave 32-float-stage kernel k_gemm (always used for K == 16)
     static const bool four_wave = getenv("MCQ_GEMM4") != nullptr;
     static const bool big_block = getenv("MCQ_GEMM_16W") != nullptr;
     const unsigned grid64 = (unsigned)(((B + 63) / 64) * N), grid128 = (unsigned)(((B + 127) / 128) * N);
-#define MCQ_GEMM_ARGS Bm, xin, idx_in, lscale, bias, R, Q, B, N, D, Dp, idx_out, out
+#define MCQ_GEMM_ARGS Bm, xin, idx_in, lscale, bias, R, Q, B, N, D, Dp, idx_out, out, keep
+    // the fused-selection epilogue needs 32 score rows of K + 4 floats plus the select scratch of every wave
+    auto lds8 = [&](int K_, int vec, int waves) {
+        size_t a = (size_t)2 * (K_ * 4 + vec * 4) * 16;
+        size_t b = (MODE == MODE_STAGE0_SEL) ? (size_t)32 * (K_ + 4) * 4 + (size_t)waves * kSelectLdsU64 * 8 : 0;
+        return a > b ? a : b;
+    };
 #define MCQ_GEMM_CASE(TT)                                                                                       \
     case 16 * TT:                                                                                               \
-        if (four_wave || TT == 1)                                                                               \
-            hipLaunchKernelGGL((k_gemm<TT, MODE>), dim3(grid64), dim3(256), ((size_t)16 * TT * 8 + 64 * 8) * 16, st, \
-                               MCQ_GEMM_ARGS);                                                                  \
+        if (MODE != MODE_STAGE0_SEL && (four_wave || TT == 1))                                                  \
+            hipLaunchKernelGGL((k_gemm<TT, (MODE == MODE_STAGE0_SEL ? MODE_STAGE0 : MODE)>), dim3(grid64), dim3(256), \
+                               ((size_t)16 * TT * 8 + 64 * 8) * 16, st, MCQ_GEMM_ARGS);                         \
         else if (big_block)                                                                                     \
             hipLaunchKernelGGL((k_gemm8s<(TT > 1 ? TT : 2), MODE, 8>), dim3(grid128), dim3(1024),                \
-                               (size_t)2 * (16 * TT * 4 + 128 * 4) * 16, st, MCQ_GEMM_ARGS);                    \
+                               lds8(16 * TT, 128, 16), st, MCQ_GEMM_ARGS);                    \
         else                                                                                                    \
             hipLaunchKernelGGL((k_gemm8s<(TT > 1 ? TT : 2), MODE, 4>), dim3(grid64), dim3(512),                  \
-                               (size_t)2 * (16 * TT * 4 + 64 * 4) * 16, st, MCQ_GEMM_ARGS);                     \
+                               lds8(16 * TT, 64, 8), st, MCQ_GEMM_ARGS);                     \
         break;
     switch (K) {
         MCQ_GEMM_CASE(1)
@@ -280,13 +293,21 @@ int run_encode(const float *x, long B, const void *prepared, float lscale, int N
             rc = launch_residual(xc, w.idx, P.C, Bc, N, K, D, Dp, w.xerr, w.E, w.R, st);
             if (rc) return rc;
             if (prof) { prof->end(CAT_RESIDUAL); prof->begin(); }
-            rc = launch_gemm<MODE_STAGE0>(K, P.C, w.xerr, w.idx, 0.f, nullptr, w.R, P.Q, Bc, N, D, Dp, nullptr, w.S0,
-                                          st);
-            if (rc) return rc;
-            if (prof) { prof->end(CAT_STAGE0); prof->begin(); }
-            rc = launch_prune0(K, w.S0, Bc * N, first_keep, w.tup[0], w.S[0], (N == 1) ? w.idx : nullptr, st);
-            if (rc) return rc;
-            if (prof) prof->end(CAT_PRUNE0);
+            if (fused_select(N, K)) {
+                // stage-0 scores never reach HBM: the first sort-and-truncate runs in the GEMM epilogue
+                rc = launch_gemm<MODE_STAGE0_SEL>(K, P.C, w.xerr, w.idx, 0.f, nullptr, w.R, P.Q, Bc, N, D, Dp,
+                                                  w.tup[0], w.S[0], st, first_keep);
+                if (rc) return rc;
+                if (prof) { prof->end(CAT_STAGE0); prof->begin(); prof->end(CAT_PRUNE0); }
+            } else {
+                rc = launch_gemm<MODE_STAGE0>(K, P.C, w.xerr, w.idx, 0.f, nullptr, w.R, P.Q, Bc, N, D, Dp, nullptr,
+                                              w.S0, st);
+                if (rc) return rc;
+                if (prof) { prof->end(CAT_STAGE0); prof->begin(); }
+                rc = launch_prune0(K, w.S0, Bc * N, first_keep, w.tup[0], w.S[0], (N == 1) ? w.idx : nullptr, st);
+                if (rc) return rc;
+                if (prof) prof->end(CAT_PRUNE0);
+            }
             int G = N, L = 1, KI = first_keep, cur = 0, stage = 0;
             while (G > 1) {
                 const int Gout = G / 2;

@@ -393,7 +393,10 @@ __global__ void k_residual_reg(const float *__restrict__ x, const uint8_t *__res
 //   MODE_STAGE0 : A_n[b] = xerr[b] - C[n][idx[b][n]] (:403)
 //                 epilogue: S = (R + Q) + 2*dot      (:418), stored to S0
 //   MODE_LOGITS_OUT: as MODE_LOGITS but stores the logits (test hook)
-enum { MODE_LOGITS = 0, MODE_STAGE0 = 1, MODE_LOGITS_OUT = 2 };
+//   MODE_STAGE0_SEL: MODE_STAGE0 + the first sort-and-truncate (:470-503) in the epilogue: the scores
+//                 go through LDS to one wave per vector and only the `keep` survivors reach HBM
+//                 (k_gemm8s only)
+enum { MODE_LOGITS = 0, MODE_STAGE0 = 1, MODE_LOGITS_OUT = 2, MODE_STAGE0_SEL = 3 };
 
 constexpr int kGemmVec = 64;  // vectors per workgroup
 constexpr int kGemmBK = 32;   // floats of the feature axis per LDS stage (2 k-blocks)
@@ -411,7 +414,7 @@ __global__ void __launch_bounds__(256, 2)
 k_gemm(const float *__restrict__ Bm /*[N][K][Dp]*/, const float *__restrict__ xin /*x [B][D] or xerr [B][Dp]*/,
        const uint8_t *__restrict__ idx_in, float lscale, const float *__restrict__ bias,
        const float *__restrict__ Rin, const float *__restrict__ Qin, long B, int N, int D, int Dp,
-       uint8_t *__restrict__ idx_out, float *__restrict__ out) {
+       uint8_t *__restrict__ idx_out, float *__restrict__ out, int /*keep: k_gemm8s only*/) {
     constexpr int K = 16 * T;
     constexpr int A_UNITS = K * 8;           // 16-byte units of the entries tile per stage
     constexpr int A_PER_THREAD = (A_UNITS + 255) / 256;
@@ -584,7 +587,8 @@ __global__ void __launch_bounds__(128 * VGN, 4)
 k_gemm8s(const float *__restrict__ Bm, const float *__restrict__ xin, const uint8_t *__restrict__ idx_in,
          float lscale, const float *__restrict__ bias, const float *__restrict__ Rin,
          const float *__restrict__ Qin, long B, int N, int D, int Dp, uint8_t *__restrict__ idx_out,
-         float *__restrict__ out) {
+         float *__restrict__ out, int keep) {
+    constexpr bool IS0 = (MODE == MODE_STAGE0) || (MODE == MODE_STAGE0_SEL);
     static_assert(T >= 2 && T % 2 == 0, "k_gemm8s splits the entry tiles over two wave groups");
     constexpr int K = 16 * T;
     constexpr int TW = T / 2;
@@ -603,9 +607,9 @@ k_gemm8s(const float *__restrict__ Bm, const float *__restrict__ xin, const uint
     const int vg = wave % VGN, eh = wave / VGN;
     const int r = lane & 15, g = lane >> 4;
     const float *Bn = Bm + (long)n * K * Dp;
-    const int xstride = (MODE == MODE_STAGE0) ? Dp : D;
-    const bool x_vec = (MODE == MODE_STAGE0) || (((D & 3) == 0) && ((reinterpret_cast<uintptr_t>(xin) & 15) == 0));
-    const bool fast = (MODE == MODE_STAGE0) || (x_vec && D == Dp);
+    const int xstride = IS0 ? Dp : D;
+    const bool x_vec = IS0 || (((D & 3) == 0) && ((reinterpret_cast<uintptr_t>(xin) & 15) == 0));
+    const bool fast = IS0 || (x_vec && D == Dp);
 
     // staging: unit f -> (row = f / 4, g = f % 4); threads 0..255 also stage the vector tile
     const bool has_b = tid < B_UNITS;
@@ -614,7 +618,7 @@ k_gemm8s(const float *__restrict__ Bm, const float *__restrict__ xin, const uint
     const float *xbase = xin + b0 * xstride;
     const uint32_t xoff = (uint32_t)((browl - b0) * xstride) + 4 * (tid & 3);
     uint32_t ooff = 0;
-    if (MODE == MODE_STAGE0) ooff = (uint32_t)(((long)n * K + idx_in[browl * N + n]) * Dp) + 4 * (tid & 3);
+    if (IS0) ooff = (uint32_t)(((long)n * K + idx_in[browl * N + n]) * Dp) + 4 * (tid & 3);
     uint32_t aoff[A_PER_THREAD];
 #pragma unroll
     for (int s = 0; s < A_PER_THREAD; ++s) {
@@ -636,7 +640,7 @@ k_gemm8s(const float *__restrict__ Bm, const float *__restrict__ xin, const uint
         if (has_b) {
             if (fast) {
                 stB = *reinterpret_cast<const f32x4 *>(xbase + (xoff + k));
-                if (MODE == MODE_STAGE0) stO = *reinterpret_cast<const f32x4 *>(Bm + (ooff + k));
+                if (IS0) stO = *reinterpret_cast<const f32x4 *>(Bm + (ooff + k));
             } else {
                 const int kk = 16 * kb + 4 * (tid & 3);
                 const float *xr = xbase + (xoff - 4 * (tid & 3));
@@ -653,7 +657,7 @@ k_gemm8s(const float *__restrict__ Bm, const float *__restrict__ xin, const uint
             if (f < A_UNITS) sa[lds_unit1(K, f >> 2, f & 3)] = stA[s];
         }
         if (has_b) {
-            const f32x4 v = (MODE == MODE_STAGE0) ? (stB - stO) : (stB * lscale);
+            const f32x4 v = IS0 ? (stB - stO) : (stB * lscale);
             sb[lds_unit1(VEC, tid >> 2, tid & 3)] = v;
         }
     };
@@ -680,7 +684,63 @@ k_gemm8s(const float *__restrict__ Bm, const float *__restrict__ xin, const uint
 
     // epilogue: lane holds, for vector b0 + 16*vg + r, entries 16*(eh*TW+t) + 4g + v
     const long b = b0 + 16 * vg + r;
-    if (MODE == MODE_STAGE0) {
+    if (MODE == MODE_STAGE0_SEL) {
+        // Scores (R + Q) + 2X go to LDS, 32 vectors per round ([vector][K + 4] floats: the +4 keeps
+        // the ds_write_b128 of 8 lanes = 8 rows on 8 different bank groups), then each wave selects
+        // for 32 / (#waves) vectors with the same wave_select_fast as k_prune0.
+        constexpr int RS = K + 4;
+        constexpr int WAVES = 2 * VGN;
+        constexpr int PER_WAVE = 32 / WAVES;
+        constexpr int VPL = (K >= 64) ? K / 64 : 1;
+        float *S_lds = reinterpret_cast<float *>(smem);
+        u64 *scratch = reinterpret_cast<u64 *>(smem + 32 * RS * 4) + (size_t)wave * kSelectLdsU64;
+        const float Rv = Rin[(b < B ? b : B - 1) * N + n];
+        for (int round = 0; round < VEC / 32; ++round) {
+            __syncthreads();   // the stage buffers / the previous round's scores are no longer read
+            if ((vg >> 1) == round) {
+                float *row = S_lds + ((vg & 1) * 16 + r) * RS;
+#pragma unroll
+                for (int t = 0; t < TW; ++t) {
+                    const int k0 = 16 * (eh * TW + t) + 4 * g;
+                    const f32x4 q = *reinterpret_cast<const f32x4 *>(Qin + (long)n * K + k0);
+                    f32x4 sv;
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) sv[v] = (Rv + q[v]) + 2.0f * acc[t][v];
+                    *reinterpret_cast<f32x4 *>(row + k0) = sv;
+                }
+            }
+            __syncthreads();
+#pragma unroll 1
+            for (int j = 0; j < PER_WAVE; ++j) {
+                const int vloc = wave * PER_WAVE + j;
+                const long bv = b0 + round * 32 + vloc;
+                if (bv >= B) continue;   // wave-uniform
+                const float *sr = S_lds + vloc * RS;
+                float sv[VPL];
+                int sp[VPL];
+                if (K >= 256) {
+                    const f32x4 t4 = *reinterpret_cast<const f32x4 *>(sr + 4 * lane);
+#pragma unroll
+                    for (int i = 0; i < VPL; ++i) { sv[i] = t4[i & 3]; sp[i] = VPL * lane + i; }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < VPL; ++i) {
+                        const int pos = VPL * lane + i;
+                        const bool ok = pos < K;
+                        sv[i] = ok ? sr[ok ? pos : 0] : INFINITY;
+                        sp[i] = ok ? pos : kBigPos;
+                    }
+                }
+                float ov;
+                int op;
+                wave_select_fast<VPL>(sv, sp, keep, K, scratch, ov, op);
+                if (lane < keep) {
+                    idx_out[(bv * N + n) * keep + lane] = (uint8_t)op;   // idx_out = tuples [B][N][keep]
+                    out[(bv * N + n) * keep + lane] = ov;                 // out = scores [B][N][keep]
+                }
+            }
+        }
+    } else if (MODE == MODE_STAGE0) {
         if (b < B) {
             const float Rv = Rin[b * N + n];
             float *o = out + (b * N + n) * (long)K;
