@@ -86,6 +86,13 @@ int mcq_refine_indexes(const float *x, long B, const void *prepared, int N, int 
 int mcq_decode(const void *codes, int code_bytes, int codes_per_row, long B, const void *prepared,
                int N, int K, int D, float *out, void *stream);
 
+/* Gradient of decode w.r.t. the scaled centers (what autograd derives from the gather + sum of
+ * :142-147): gC[n][k][:] = sum over the vectors b with index(b, n) == k, b ascending, of
+ * grad_out[b][:].  Deterministic (fixed summation order, no atomics).  idx: int64 [B][N];
+ * grad_out: fp32 [B][D]; gC: fp32 [N][K][D], fully overwritten.                                */
+int mcq_decode_backward(const float *grad_out, const int64_t *idx, long B, int N, int K, int D, float *gC,
+                        void *stream);
+
 /* ---- test / profiling hooks -------------------------------------------------
  * Logits of Quantizer._logits (:277-279) for a batch, fp32 [B][N*K]; used by the
  * parity tests to localise a divergence.                                       */

@@ -427,6 +427,18 @@ int mcq_decode(const void *codes, int code_bytes, int codes_per_row, long B, con
     return e == hipSuccess ? 0 : (int)e;
 }
 
+int mcq_decode_backward(const float *grad_out, const int64_t *idx, long B, int N, int K, int D, float *gC,
+                        void *stream) {
+    if (N <= 0 || K <= 0 || D <= 0 || B < 0 || !gC) return MCQ_EINVAL;
+    if (B > 0 && (!grad_out || !idx)) return MCQ_EINVAL;
+    const int chunks = (D + 63) / 64;
+    const long waves = (long)N * K * chunks;
+    hipLaunchKernelGGL(k_decode_backward, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), grad_out, idx, B, N, K, D, chunks, gC);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
 int mcq_logits(const float *x, long B, const void *prepared, float lscale_exp, int N, int K, int D, float *out,
                void *stream) {
     if (!domain_ok(N, K, D)) return MCQ_EUNSUPPORTED;

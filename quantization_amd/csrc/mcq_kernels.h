@@ -1275,4 +1275,42 @@ __global__ void k_decode_reg(const uint8_t *__restrict__ codes, long B, const fl
     }
 }
 
+// ----------------------------------------------------------- decode backward
+// One wave per (codebook row (n, k), 64-feature chunk): scan the n-th index column of all B vectors
+// 64 at a time (ballot) and add grad_out[b][chunk] for every match in ascending b -- a fixed
+// summation order, so training is bit-reproducible (torch's index_add_ on the device uses atomics).
+// Matching rows are fetched eight at a time so the loads overlap; the adds stay in order.
+__global__ void k_decode_backward(const float *__restrict__ gout, const int64_t *__restrict__ idx, long B, int N, int K,
+                                  int D, int chunks, float *__restrict__ gC) {
+    const long w = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (w >= (long)N * K * chunks) return;
+    const int lane = lane_id();
+    const long row = w / chunks;
+    const int d = (int)(w % chunks) * 64 + lane;
+    const bool dok = d < D;
+    const int dc = dok ? d : 0;
+    const int n = (int)(row / K), k = (int)(row % K);
+    float acc = 0.f;
+    for (long b0 = 0; b0 < B; b0 += 64) {
+        const long b = b0 + lane;
+        const bool hit = (b < B) && (idx[b * N + n] == k);
+        unsigned long long m = __ballot(hit);
+        while (m) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                v[u] = 0.f;
+                if (m) {   // wave-uniform
+                    const int l = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    v[u] = gout[(b0 + l) * D + dc];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = acc + v[u];   // x + 0 is exact: padding slots change nothing
+        }
+    }
+    if (dok) gC[row * D + d] = acc;
+}
+
 }  // namespace mcq

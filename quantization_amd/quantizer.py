@@ -333,10 +333,19 @@ class _DecodeFn(torch.autograd.Function):
         N, K, D = centers.shape
         scale = (centers_scale.detach() * m.scale_speed).exp()
         # d/d(scaled centers): rows receive the sum of grad_out over the vectors that chose them
-        g = torch.zeros(N * K, D, dtype=grad_out.dtype, device=grad_out.device)
-        rows = (idx + torch.arange(N, device=idx.device) * K).reshape(-1)
-        g.index_add_(0, rows, grad_out.unsqueeze(1).expand(-1, N, -1).reshape(-1, D))
-        g = g.reshape(N, K, D)
+        if grad_out.is_cuda and grad_out.dtype == torch.float32:
+            # deterministic HIP kernel (fixed summation order; index_add_ on the device uses atomics)
+            go = grad_out.contiguous()
+            g = torch.empty((N, K, D), dtype=torch.float32, device=go.device)
+            with torch.cuda.device(go.device):
+                rc = _lib.lib().mcq_decode_backward(go.data_ptr(), idx.contiguous().data_ptr(), go.shape[0], N, K, D,
+                                                    g.data_ptr(), torch.cuda.current_stream(go.device).cuda_stream)
+            _lib.check(rc, "mcq_decode_backward")
+        else:
+            g = torch.zeros(N * K, D, dtype=grad_out.dtype, device=grad_out.device)
+            rows = (idx + torch.arange(N, device=idx.device) * K).reshape(-1)
+            g.index_add_(0, rows, grad_out.unsqueeze(1).expand(-1, N, -1).reshape(-1, D))
+            g = g.reshape(N, K, D)
         g_centers = g * scale
         g_scale = (g * centers.detach()).sum() * scale * m.scale_speed
         return None, None, g_centers, g_scale
