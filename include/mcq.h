@@ -70,6 +70,16 @@ int mcq_encode(const float *x, long B, const void *prepared, float lscale_exp, i
                int refine_iters, uint8_t *out_u8, int64_t *out_i64, void *workspace,
                size_t workspace_bytes, void *stream);
 
+/* mcq_encode with options.  MCQ_ENCODE_SKIP_FIXED_POINTS: _refine_indexes is a deterministic map
+ * of (x, indexes), so a vector whose indexes a pass leaves unchanged is already final; with this
+ * flag such vectors leave the active list and later passes only process the rest.  The codes are
+ * identical to mcq_encode's for every input; the cost becomes data dependent (off by default, and
+ * never used for the headline benchmark figure).                                                */
+#define MCQ_ENCODE_SKIP_FIXED_POINTS 1u
+int mcq_encode_ex(const float *x, long B, const void *prepared, float lscale_exp, int N, int K, int D,
+                  int refine_iters, uint8_t *out_u8, int64_t *out_i64, void *workspace,
+                  size_t workspace_bytes, void *stream, unsigned flags);
+
 /* Replaces Quantizer._refine_indexes (:308-547) applied `refine_iters` times to caller-supplied
  * indexes: idx_in int64 [B][N] with entries in [0, K) -> idx_out int64 [B][N] (may alias idx_in).
  * Same workspace as mcq_encode.                                                               */

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libmcq_hip.so")
 # every symbol include/mcq.h declares
 SYMBOLS = (
     "mcq_abi_version", "mcq_padded_dim", "mcq_prepared_bytes", "mcq_prepare", "mcq_encode_workspace_bytes",
-    "mcq_encode", "mcq_refine_indexes", "mcq_decode", "mcq_decode_backward", "mcq_logits", "mcq_last_encode_launches", "mcq_profile_encode",
+    "mcq_encode", "mcq_encode_ex", "mcq_refine_indexes", "mcq_decode", "mcq_decode_backward", "mcq_logits", "mcq_last_encode_launches", "mcq_profile_encode",
 )
 
 MCQ_EINVAL, MCQ_EUNSUPPORTED, MCQ_EWORKSPACE = -1, -2, -3
@@ -43,6 +43,8 @@ def lib():
     L.mcq_encode_workspace_bytes.argtypes = [i64, i32, i32, i32]
     L.mcq_encode.restype = i32
     L.mcq_encode.argtypes = [vp, i64, vp, f32, i32, i32, i32, i32, vp, vp, vp, sz, vp]
+    L.mcq_encode_ex.restype = i32
+    L.mcq_encode_ex.argtypes = [vp, i64, vp, f32, i32, i32, i32, i32, vp, vp, vp, sz, vp, ctypes.c_uint]
     L.mcq_refine_indexes.restype = i32
     L.mcq_refine_indexes.argtypes = [vp, i64, vp, i32, i32, i32, i32, vp, vp, vp, sz, vp]
     L.mcq_decode.restype = i32

@@ -48,7 +48,8 @@ Prepared prepared_view(const void *p, int N, int K, int D) {
 }
 
 struct Workspace {
-    uint8_t *idx;
+    uint8_t *idx, *idxB, *idxC, *final_idx;   // B, C, final: fixed-point skipping only
+    int *map[2], *cnt;
     float *xerr, *E, *R, *S0;
     uint8_t *tup[2];
     float *S[2];
@@ -63,9 +64,9 @@ bool fused_select(int N, int K) {
 
 size_t workspace_per_vector(int N, int K, int Dp) {
     const size_t s0 = fused_select(N, K) ? 0 : 4 * (size_t)N * K;
-    return (size_t)N + 4 * (size_t)Dp + 4 + 4 * (size_t)N + s0 + 2 * 64 * (size_t)N + 2 * 4 * 16 * (size_t)N;
+    return 4 * (size_t)N + 8 + 4 * (size_t)Dp + 4 + 4 * (size_t)N + s0 + 2 * 64 * (size_t)N + 2 * 4 * 16 * (size_t)N;
 }
-constexpr size_t kWorkspaceSlack = 16 * 256;
+constexpr size_t kWorkspaceSlack = 24 * 256;
 constexpr long kDefaultChunk = 65536;
 
 Workspace carve(void *ws, long Bc, int N, int K, int Dp) {
@@ -74,6 +75,11 @@ Workspace carve(void *ws, long Bc, int N, int K, int Dp) {
     auto take = [&](size_t bytes) { char *q = p + off; off = align256(off + bytes); return q; };
     Workspace w;
     w.idx = reinterpret_cast<uint8_t *>(take((size_t)Bc * N));
+    w.idxB = reinterpret_cast<uint8_t *>(take((size_t)Bc * N));
+    w.idxC = reinterpret_cast<uint8_t *>(take((size_t)Bc * N));
+    w.final_idx = reinterpret_cast<uint8_t *>(take((size_t)Bc * N));
+    for (int i = 0; i < 2; ++i) w.map[i] = reinterpret_cast<int *>(take((size_t)Bc * 4));
+    w.cnt = reinterpret_cast<int *>(take(64 * 4));
     w.xerr = reinterpret_cast<float *>(take((size_t)Bc * Dp * 4));
     w.E = reinterpret_cast<float *>(take((size_t)Bc * 4));
     w.R = reinterpret_cast<float *>(take((size_t)Bc * N * 4));
@@ -119,13 +125,13 @@ thread_local int g_last_launches = 0;
 template <int MODE>
 int launch_gemm(int K, const float *Bm, const float *xin, const uint8_t *idx_in, float lscale, const float *bias,
                 const float *R, const float *Q, long B, int N, int D, int Dp, uint8_t *idx_out, float *out,
-                hipStream_t st, int keep = 0) {
+                hipStream_t st, int keep = 0, const int *nact = nullptr) {
     // default: k_gemm8s with 8 waves (64 vectors); tuning hooks: MCQ_GEMM_16W=1 -> 16 waves (128
     // vectors), MCQ_GEMM4=1 -> the 4-wave 32-float-stage kernel k_gemm (always used for K == 16)
     static const bool four_wave = getenv("MCQ_GEMM4") != nullptr;
     static const bool big_block = getenv("MCQ_GEMM_16W") != nullptr;
     const unsigned grid64 = (unsigned)(((B + 63) / 64) * N), grid128 = (unsigned)(((B + 127) / 128) * N);
-#define MCQ_GEMM_ARGS Bm, xin, idx_in, lscale, bias, R, Q, B, N, D, Dp, idx_out, out, keep
+#define MCQ_GEMM_ARGS Bm, xin, idx_in, lscale, bias, R, Q, B, N, D, Dp, idx_out, out, keep, nact
     // the fused-selection epilogue needs 32 score rows of K + 4 floats plus the select scratch of every wave
     auto lds8 = [&](int K_, int vec, int waves) {
         size_t a = (size_t)2 * (K_ * 4 + vec * 4) * 16;
@@ -159,14 +165,14 @@ int launch_gemm(int K, const float *Bm, const float *xin, const uint8_t *idx_in,
 }
 
 int launch_prune0(int K, const float *S0, long BN, int keep, uint8_t *tup, float *S, uint8_t *idx_final,
-                  hipStream_t st) {
+                  hipStream_t st, const int *nact, int N) {
     const unsigned grid = (unsigned)((BN + 3) / 4);
     switch (K) {
-        case 16: hipLaunchKernelGGL((k_prune0<16>), dim3(grid), dim3(256), 4 * kSelectLdsU64 * 8, st, S0, BN, keep, tup, S, idx_final); break;
-        case 32: hipLaunchKernelGGL((k_prune0<32>), dim3(grid), dim3(256), 4 * kSelectLdsU64 * 8, st, S0, BN, keep, tup, S, idx_final); break;
-        case 64: hipLaunchKernelGGL((k_prune0<64>), dim3(grid), dim3(256), 4 * kSelectLdsU64 * 8, st, S0, BN, keep, tup, S, idx_final); break;
-        case 128: hipLaunchKernelGGL((k_prune0<128>), dim3(grid), dim3(256), 4 * kSelectLdsU64 * 8, st, S0, BN, keep, tup, S, idx_final); break;
-        case 256: hipLaunchKernelGGL((k_prune0<256>), dim3(grid), dim3(256), 4 * kSelectLdsU64 * 8, st, S0, BN, keep, tup, S, idx_final); break;
+        case 16: hipLaunchKernelGGL((k_prune0<16>), dim3(grid), dim3(256), 4 * kSelectLdsU64 * 8, st, S0, BN, keep, tup, S, idx_final, nact, N); break;
+        case 32: hipLaunchKernelGGL((k_prune0<32>), dim3(grid), dim3(256), 4 * kSelectLdsU64 * 8, st, S0, BN, keep, tup, S, idx_final, nact, N); break;
+        case 64: hipLaunchKernelGGL((k_prune0<64>), dim3(grid), dim3(256), 4 * kSelectLdsU64 * 8, st, S0, BN, keep, tup, S, idx_final, nact, N); break;
+        case 128: hipLaunchKernelGGL((k_prune0<128>), dim3(grid), dim3(256), 4 * kSelectLdsU64 * 8, st, S0, BN, keep, tup, S, idx_final, nact, N); break;
+        case 256: hipLaunchKernelGGL((k_prune0<256>), dim3(grid), dim3(256), 4 * kSelectLdsU64 * 8, st, S0, BN, keep, tup, S, idx_final, nact, N); break;
         default: return MCQ_EUNSUPPORTED;
     }
     MCQ_LAUNCH_CHECK();
@@ -176,7 +182,7 @@ int launch_prune0(int K, const float *S0, long BN, int keep, uint8_t *tup, float
 template <int L, int KI>
 int launch_pair_t(const float *C, const uint8_t *idx, const float *E, const uint8_t *tup_in, const float *S_in,
                   long B, int N, int K, int Dp, int Gout, int keep, uint8_t *tup_out, float *S_out,
-                  uint8_t *idx_final, hipStream_t st) {
+                  uint8_t *idx_final, const int *nact, hipStream_t st) {
     // each wave stages its 2L old rows in a private LDS window: whole rows while that stays <= 32 KB
     // per wave (measured best), otherwise `win` floats at a time in windows of <= 16 KB
     const size_t scratch = (size_t)kSelectLdsU64 * 8;
@@ -198,17 +204,18 @@ int launch_pair_t(const float *C, const uint8_t *idx, const float *E, const uint
     }
     const unsigned grid = (unsigned)(((B + wpb - 1) / wpb) * Gout);
     hipLaunchKernelGGL((k_pair<L, KI>), dim3(grid), dim3(64 * wpb), per_wave * wpb, st, C, idx, E, tup_in, S_in, B, N, K,
-                       Dp, Gout, keep, win, tup_out, S_out, idx_final);
+                       Dp, Gout, keep, win, tup_out, S_out, idx_final, nact);
     MCQ_LAUNCH_CHECK();
     return 0;
 }
 
 int launch_pair(int L, int KI, const float *C, const uint8_t *idx, const float *E, const uint8_t *tup_in,
                 const float *S_in, long B, int N, int K, int Dp, int Gout, int keep, uint8_t *tup_out, float *S_out,
-                uint8_t *idx_final, hipStream_t st) {
+                uint8_t *idx_final, const int *nact, hipStream_t st) {
 #define MCQ_PAIR_CASE(LL, KK)                                                                                     \
     if (L == LL && KI == KK)                                                                                      \
-        return launch_pair_t<LL, KK>(C, idx, E, tup_in, S_in, B, N, K, Dp, Gout, keep, tup_out, S_out, idx_final, st);
+        return launch_pair_t<LL, KK>(C, idx, E, tup_in, S_in, B, N, K, Dp, Gout, keep, tup_out, S_out, idx_final, nact, \
+                                     st);
     // K >= 32 ladders: 16,16,32,32,64 ; K == 16 ladders: 8,8,16,16,32,32
     MCQ_PAIR_CASE(1, 16)
     MCQ_PAIR_CASE(2, 16)
@@ -226,12 +233,13 @@ int launch_pair(int L, int KI, const float *C, const uint8_t *idx, const float *
 }
 
 int launch_residual(const float *x, const uint8_t *idx, const float *C, long B, int N, int K, int D, int Dp,
-                    float *xerr, float *E, float *R, hipStream_t st) {
+                    float *xerr, float *E, float *R, hipStream_t st, const int *nact, const int *map) {
     const dim3 grid((unsigned)((B + 3) / 4)), block(256);
     const int J = (Dp / 4 + 63) / 64;
 #define MCQ_RES_CASE(NN, JJ)                                                                                   \
     if (N == NN && J == JJ) {                                                                                  \
-        hipLaunchKernelGGL((k_residual_reg<NN, JJ>), grid, block, 0, st, x, idx, C, B, K, D, Dp, xerr, E, R);  \
+        hipLaunchKernelGGL((k_residual_reg<NN, JJ>), grid, block, 0, st, x, idx, C, B, K, D, Dp, xerr, E, R, nact, \
+                           map);                                                                              \
         MCQ_LAUNCH_CHECK();                                                                                    \
         return 0;                                                                                              \
     }
@@ -245,7 +253,7 @@ int launch_residual(const float *x, const uint8_t *idx, const float *C, long B, 
     MCQ_RES_CASE(2, 1)
     MCQ_RES_CASE(2, 2)
 #undef MCQ_RES_CASE
-    hipLaunchKernelGGL(k_residual, grid, block, 0, st, x, idx, C, B, N, K, D, Dp, xerr, E, R);
+    hipLaunchKernelGGL(k_residual, grid, block, 0, st, x, idx, C, B, N, K, D, Dp, xerr, E, R, nact, map);
     MCQ_LAUNCH_CHECK();
     return 0;
 }
@@ -255,10 +263,10 @@ enum { CAT_LOGITS = 0, CAT_RESIDUAL = 1, CAT_STAGE0 = 2, CAT_PRUNE0 = 3, CAT_PAI
 
 int run_encode(const float *x, long B, const void *prepared, float lscale, int N, int K, int D, int iters,
                uint8_t *out_u8, int64_t *out_i64, void *workspace, size_t workspace_bytes, hipStream_t st,
-               Prof *prof, const int64_t *init_idx = nullptr) {
+               Prof *prof, const int64_t *init_idx = nullptr, unsigned flags = 0) {
     g_last_launches = 0;
     if (!domain_ok(N, K, D)) return (K < 16 || K > 256 || N > 64) ? MCQ_EUNSUPPORTED : MCQ_EINVAL;
-    if (B < 0 || iters < 0 || (out_u8 == nullptr) == (out_i64 == nullptr)) return MCQ_EINVAL;
+    if (B < 0 || iters < 0 || iters > 60 || (out_u8 == nullptr) == (out_i64 == nullptr)) return MCQ_EINVAL;
     if (B == 0) return 0;
     if (!x || !prepared || !workspace) return MCQ_EINVAL;
     const int Dp = round_up16(D);
@@ -271,6 +279,9 @@ int run_encode(const float *x, long B, const void *prepared, float lscale, int N
     const Prepared P = prepared_view(prepared, N, K, D);
     const int pack = (out_u8 != nullptr && K == 16 && N >= 2) ? 2 : 1;
     const int first_keep = (N == 1) ? 1 : k_cutoff(K, 1);
+    // fixed-point skipping (opt-in): vectors whose indexes a pass leaves unchanged drop out of the later
+    // passes (k_compact); results are identical, the cost becomes data dependent
+    const bool skip = (flags & MCQ_ENCODE_SKIP_FIXED_POINTS) != 0 && iters >= 2;
 
     for (long lo = 0; lo < B; lo += chunk) {
         const long Bc = (B - lo < chunk) ? (B - lo) : chunk;
@@ -288,23 +299,32 @@ int run_encode(const float *x, long B, const void *prepared, float lscale, int N
             if (rc) return rc;
             if (prof) prof->end(CAT_LOGITS);
         }
+        // without skipping: indexes are refined in place in w.idx, nothing is packed
+        uint8_t *idx_cur = w.idx, *idx_new = skip ? w.idxB : w.idx, *idx_pk = w.idxC;
+        const int *map_cur = nullptr, *nact = nullptr;
+        int *map_nxt = w.map[0], *map_spare = w.map[1];
+        if (skip) {
+            hipError_t e = hipMemsetAsync(w.cnt, 0, 64 * sizeof(int), st);
+            if (e != hipSuccess) return (int)e;
+        }
         for (int it = 0; it < iters; ++it) {
             if (prof) prof->begin();
-            rc = launch_residual(xc, w.idx, P.C, Bc, N, K, D, Dp, w.xerr, w.E, w.R, st);
+            rc = launch_residual(xc, idx_cur, P.C, Bc, N, K, D, Dp, w.xerr, w.E, w.R, st, nact, map_cur);
             if (rc) return rc;
             if (prof) { prof->end(CAT_RESIDUAL); prof->begin(); }
             if (fused_select(N, K)) {
                 // stage-0 scores never reach HBM: the first sort-and-truncate runs in the GEMM epilogue
-                rc = launch_gemm<MODE_STAGE0_SEL>(K, P.C, w.xerr, w.idx, 0.f, nullptr, w.R, P.Q, Bc, N, D, Dp,
-                                                  w.tup[0], w.S[0], st, first_keep);
+                rc = launch_gemm<MODE_STAGE0_SEL>(K, P.C, w.xerr, idx_cur, 0.f, nullptr, w.R, P.Q, Bc, N, D, Dp,
+                                                  w.tup[0], w.S[0], st, first_keep, nact);
                 if (rc) return rc;
                 if (prof) { prof->end(CAT_STAGE0); prof->begin(); prof->end(CAT_PRUNE0); }
             } else {
-                rc = launch_gemm<MODE_STAGE0>(K, P.C, w.xerr, w.idx, 0.f, nullptr, w.R, P.Q, Bc, N, D, Dp, nullptr,
-                                              w.S0, st);
+                rc = launch_gemm<MODE_STAGE0>(K, P.C, w.xerr, idx_cur, 0.f, nullptr, w.R, P.Q, Bc, N, D, Dp, nullptr,
+                                              w.S0, st, 0, nact);
                 if (rc) return rc;
                 if (prof) { prof->end(CAT_STAGE0); prof->begin(); }
-                rc = launch_prune0(K, w.S0, Bc * N, first_keep, w.tup[0], w.S[0], (N == 1) ? w.idx : nullptr, st);
+                rc = launch_prune0(K, w.S0, Bc * N, first_keep, w.tup[0], w.S[0], (N == 1) ? idx_new : nullptr, st,
+                                   nact, N);
                 if (rc) return rc;
                 if (prof) prof->end(CAT_PRUNE0);
             }
@@ -313,15 +333,28 @@ int run_encode(const float *x, long B, const void *prepared, float lscale, int N
                 const int Gout = G / 2;
                 const int keep = (Gout == 1) ? 1 : k_cutoff(K, 2 * L);
                 if (prof) prof->begin();
-                rc = launch_pair(L, KI, P.C, w.idx, w.E, w.tup[cur], w.S[cur], Bc, N, K, Dp, Gout, keep,
-                                 w.tup[cur ^ 1], w.S[cur ^ 1], (Gout == 1) ? w.idx : nullptr, st);
+                rc = launch_pair(L, KI, P.C, idx_cur, w.E, w.tup[cur], w.S[cur], Bc, N, K, Dp, Gout, keep,
+                                 w.tup[cur ^ 1], w.S[cur ^ 1], (Gout == 1) ? idx_new : nullptr, nact, st);
                 if (rc) return rc;
                 if (prof) prof->end(CAT_PAIR0 + stage);
                 G = Gout; L *= 2; KI = keep; cur ^= 1; ++stage;
             }
+            if (skip) {
+                const int last = (it + 1 == iters) ? 1 : 0;
+                hipLaunchKernelGGL(k_compact, dim3((unsigned)((Bc + 255) / 256)), dim3(256), 0, st, idx_cur, idx_new,
+                                   map_cur, nact, Bc, N, last, w.final_idx, idx_pk, map_nxt, w.cnt + it);
+                MCQ_LAUNCH_CHECK();
+                // rotate: the packed list becomes the current one
+                uint8_t *t = idx_cur; idx_cur = idx_pk; idx_pk = t;
+                int *old_map = const_cast<int *>(map_cur);
+                map_cur = map_nxt;
+                map_nxt = old_map ? old_map : map_spare;
+                nact = w.cnt + it;
+            }
         }
+        const uint8_t *result = (skip && iters > 0) ? w.final_idx : w.idx;
         const long outn = (out_i64 != nullptr) ? Bc * N : Bc * (N / pack);
-        hipLaunchKernelGGL(k_finalize, dim3((unsigned)((outn + 255) / 256)), dim3(256), 0, st, w.idx, Bc, N, pack,
+        hipLaunchKernelGGL(k_finalize, dim3((unsigned)((outn + 255) / 256)), dim3(256), 0, st, result, Bc, N, pack,
                            out_u8 ? out_u8 + lo * (N / pack) : nullptr, out_i64 ? out_i64 + lo * N : nullptr);
         MCQ_LAUNCH_CHECK();
     }
@@ -376,6 +409,13 @@ int mcq_encode(const float *x, long B, const void *prepared, float lscale_exp, i
                uint8_t *out_u8, int64_t *out_i64, void *workspace, size_t workspace_bytes, void *stream) {
     return run_encode(x, B, prepared, lscale_exp, N, K, D, refine_iters, out_u8, out_i64, workspace,
                       workspace_bytes, static_cast<hipStream_t>(stream), nullptr);
+}
+
+int mcq_encode_ex(const float *x, long B, const void *prepared, float lscale_exp, int N, int K, int D,
+                  int refine_iters, uint8_t *out_u8, int64_t *out_i64, void *workspace, size_t workspace_bytes,
+                  void *stream, unsigned flags) {
+    return run_encode(x, B, prepared, lscale_exp, N, K, D, refine_iters, out_u8, out_i64, workspace,
+                      workspace_bytes, static_cast<hipStream_t>(stream), nullptr, nullptr, flags);
 }
 
 int mcq_refine_indexes(const float *x, long B, const void *prepared, int N, int K, int D, int refine_iters,

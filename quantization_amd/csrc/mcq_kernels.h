@@ -272,14 +272,19 @@ __global__ void k_prepare_rows(const float *__restrict__ src, float scale, int a
 // One wave per vector (quantization.py:338-340, :401-409):
 //   xerr[b] = (old_0 + old_1 + ... ) - x[b];  E[b] = sumsq64(xerr);
 //   R[b][n] = sumsq64(xerr - old_n),  old_n = C[n][idx[b][n]].
+// `nact` / `map` (both nullable) serve the optional fixed-point skipping of mcq_encode_ex: the
+// refinement kernels then work on a packed list of *nact still-active vectors whose rows of x are
+// x[map[slot]]; every other per-vector array is indexed by slot.
 __global__ void k_residual(const float *__restrict__ x, const uint8_t *__restrict__ idx,
                            const float *__restrict__ C, long B, int N, int K, int D, int Dp,
-                           float *__restrict__ xerr, float *__restrict__ E, float *__restrict__ R) {
+                           float *__restrict__ xerr, float *__restrict__ E, float *__restrict__ R,
+                           const int *__restrict__ nact, const int *__restrict__ map) {
     const long b = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (nact) B = *nact;
     if (b >= B) return;
     const int lane = lane_id();
     const uint8_t *id = idx + b * N;
-    const float *xb = x + b * D;
+    const float *xb = x + (map ? (long)map[b] : b) * D;
     float *xe = xerr + b * Dp;
     const bool vec_ok = ((D & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
     float pe = 0.f;
@@ -321,12 +326,14 @@ __global__ void k_residual(const float *__restrict__ x, const uint8_t *__restric
 template <int NN, int J>
 __global__ void k_residual_reg(const float *__restrict__ x, const uint8_t *__restrict__ idx,
                                const float *__restrict__ C, long B, int K, int D, int Dp,
-                               float *__restrict__ xerr, float *__restrict__ E, float *__restrict__ R) {
+                               float *__restrict__ xerr, float *__restrict__ E, float *__restrict__ R,
+                               const int *__restrict__ nact, const int *__restrict__ map) {
     const long b = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (nact) B = *nact;
     if (b >= B) return;
     const int lane = lane_id();
     const uint8_t *id = idx + b * NN;
-    const float *xb = x + b * D;
+    const float *xb = x + (map ? (long)map[b] : b) * D;
     float *xe = xerr + b * Dp;
     const bool vec_ok = ((D & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
     const int nq = Dp / 4;
@@ -414,8 +421,11 @@ __global__ void __launch_bounds__(256, 2)
 k_gemm(const float *__restrict__ Bm /*[N][K][Dp]*/, const float *__restrict__ xin /*x [B][D] or xerr [B][Dp]*/,
        const uint8_t *__restrict__ idx_in, float lscale, const float *__restrict__ bias,
        const float *__restrict__ Rin, const float *__restrict__ Qin, long B, int N, int D, int Dp,
-       uint8_t *__restrict__ idx_out, float *__restrict__ out, int /*keep: k_gemm8s only*/) {
+       uint8_t *__restrict__ idx_out, float *__restrict__ out, int /*keep: k_gemm8s only*/,
+       const int *__restrict__ nact) {
     constexpr int K = 16 * T;
+    if (nact) B = *nact;
+    if ((long)(blockIdx.x / N) * kGemmVec >= B) return;   // whole tile past the active list (uniform)
     constexpr int A_UNITS = K * 8;           // 16-byte units of the entries tile per stage
     constexpr int A_PER_THREAD = (A_UNITS + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -587,8 +597,10 @@ __global__ void __launch_bounds__(128 * VGN, 4)
 k_gemm8s(const float *__restrict__ Bm, const float *__restrict__ xin, const uint8_t *__restrict__ idx_in,
          float lscale, const float *__restrict__ bias, const float *__restrict__ Rin,
          const float *__restrict__ Qin, long B, int N, int D, int Dp, uint8_t *__restrict__ idx_out,
-         float *__restrict__ out, int keep) {
+         float *__restrict__ out, int keep, const int *__restrict__ nact) {
     constexpr bool IS0 = (MODE == MODE_STAGE0) || (MODE == MODE_STAGE0_SEL);
+    if (nact) B = *nact;
+    if ((long)(blockIdx.x / N) * (16 * VGN) >= B) return;   // whole tile past the active list (uniform)
     static_assert(T >= 2 && T % 2 == 0, "k_gemm8s splits the entry tiles over two wave groups");
     constexpr int K = 16 * T;
     constexpr int TW = T / 2;
@@ -799,7 +811,9 @@ k_gemm8s(const float *__restrict__ Bm, const float *__restrict__ xin, const uint
 // where the kept entry IS the new index (:468-469).
 template <int K>
 __global__ void k_prune0(const float *__restrict__ S0, long BN, int keep, uint8_t *__restrict__ tup_out,
-                         float *__restrict__ S_out, uint8_t *__restrict__ idx_final) {
+                         float *__restrict__ S_out, uint8_t *__restrict__ idx_final, const int *__restrict__ nact,
+                         int N) {
+    if (nact) BN = (long)*nact * N;
     constexpr int VPL = (K >= 64) ? K / 64 : 1;
     const long w = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (w >= BN) return;
@@ -868,8 +882,10 @@ k_pair(const float *__restrict__ C, const uint8_t *__restrict__ idx, const float
        const uint8_t *__restrict__ tup_in /*[B][Gin][KI][L]*/, const float *__restrict__ S_in /*[B][Gin][KI]*/,
        long B, int N, int K, int Dp, int Gout, int keep, int win /* floats of each old row staged per window */,
        uint8_t *__restrict__ tup_out /*[B][Gout][keep][2L]*/, float *__restrict__ S_out,
-       uint8_t *__restrict__ idx_final) {
+       uint8_t *__restrict__ idx_final /* may alias idx: a wave only rewrites its own vector, at the end */,
+       const int *__restrict__ nact) {
     constexpr int TI = (KI + 15) / 16;
+    if (nact) B = *nact;
     constexpr int VPL = TI * TI * 4;
     constexpr int M = KI * KI;
     constexpr bool SMALL = L <= 4;            // row offsets precomputed in registers
@@ -1171,6 +1187,32 @@ k_pair(const float *__restrict__ C, const uint8_t *__restrict__ idx, const float
             for (int j = 0; j < L; ++j) { o[j] = te[a * L + j]; o[L + j] = to[bb * L + j]; }
             S_out[(b * Gout + go) * (long)keep + lane] = ov;
         }
+    }
+}
+
+// ------------------------------------------------------- fixed-point skipping
+// _refine_indexes is a deterministic map F of (x, indexes): once F(idx) == idx every later pass
+// returns idx again, so such a vector can leave the active list without changing any result.
+// One thread per active slot: converged (or last pass) -> the indexes go to their original row of
+// `final_idx`; otherwise the slot is re-packed (order irrelevant: vectors are independent) for the
+// next pass.  `cnt_next` was zeroed by the host (memset node ahead of the launch).
+__global__ void k_compact(const uint8_t *__restrict__ idx_old, const uint8_t *__restrict__ idx_new,
+                          const int *__restrict__ map_cur, const int *__restrict__ nact, long B, int N, int last,
+                          uint8_t *__restrict__ final_idx, uint8_t *__restrict__ idx_packed, int *__restrict__ map_next,
+                          int *__restrict__ cnt_next) {
+    const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (nact) B = *nact;
+    if (s >= B) return;
+    const int orig = map_cur ? map_cur[s] : (int)s;
+    bool changed = false;
+    if (!last)
+        for (int n = 0; n < N; ++n) changed = changed || (idx_old[s * N + n] != idx_new[s * N + n]);
+    if (changed) {
+        const int slot = atomicAdd(cnt_next, 1);
+        for (int n = 0; n < N; ++n) idx_packed[(long)slot * N + n] = idx_new[s * N + n];
+        map_next[slot] = orig;
+    } else {
+        for (int n = 0; n < N; ++n) final_idx[(long)orig * N + n] = idx_new[s * N + n];
     }
 }
 

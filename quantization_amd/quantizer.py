@@ -49,6 +49,9 @@ class Quantizer(nn.Module):
         id_bytes = binascii.b2a_hex(os.urandom(4))           # quantization.py:53-55
         self.id_str = id_bytes.decode("utf-8")
         self.register_buffer("id_buf", torch.tensor(list(id_bytes), dtype=torch.uint8))
+        # opt-in (not in the reference): vectors whose indexes a refinement pass leaves unchanged are
+        # final (the pass is a deterministic map) and skip the remaining passes; same codes, less work
+        self.skip_fixed_points = False
         self._prep = None       # (key, device buffer) of derived state for the kernels
         self._ws = None         # cached encode workspace (device uint8 tensor)
 
@@ -143,9 +146,9 @@ class Quantizer(nn.Module):
         ws = self._workspace(B, dev)
         with torch.cuda.device(dev):
             st = torch.cuda.current_stream(dev).cuda_stream
-            rc = L.mcq_encode(x2d.data_ptr(), B, blob.data_ptr(), self._lscale_exp, N, K, D, int(iters),
-                              out.data_ptr() if as_bytes else None, None if as_bytes else out.data_ptr(),
-                              ws.data_ptr(), ws.numel(), st)
+            rc = L.mcq_encode_ex(x2d.data_ptr(), B, blob.data_ptr(), self._lscale_exp, N, K, D, int(iters),
+                                 out.data_ptr() if as_bytes else None, None if as_bytes else out.data_ptr(),
+                                 ws.data_ptr(), ws.numel(), st, 1 if getattr(self, "skip_fixed_points", False) else 0)
         _lib.check(rc, "mcq_encode")
         return out
 

@@ -215,3 +215,19 @@ def test_small_workspace_forces_chunks_same_codes():
     rc = L.mcq_encode(x.data_ptr(), 1000, q._prepared().data_ptr(), q._lscale_exp, N, K, D, 2, out.data_ptr(), None,
                       ws.data_ptr(), 4096 + 10, torch.cuda.current_stream().cuda_stream)
     assert rc == _lib.MCQ_EWORKSPACE
+
+
+@pytest.mark.parametrize("name", ["trained_d64_b8_p2", "trained_d64_b4_p1", "synth_d32_k256_n1", "synth_d64_k256_n16",
+                                  "synth_d32_k16_n64", "config_a_d256_n4"])
+def test_fixed_point_skipping_gives_identical_codes(name):
+    fx = fixtures.load(name)
+    q = load_quantizer(fx["state"], fx["D"], fx["K"], fx["N"])
+    x = torch.from_numpy(fx["x"]).cuda()
+    for it in (1, 2, 5, 8):
+        q.skip_fixed_points = False
+        ref = q.encode(x, it, as_bytes=False)
+        q.skip_fixed_points = True
+        got = q.encode(x, it, as_bytes=False)
+        assert torch.equal(ref, got), (name, it)
+    q.skip_fixed_points = True
+    assert torch.equal(q.encode(x[:77], 5), q.encode(x, 5)[:77])
