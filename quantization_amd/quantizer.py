@@ -100,8 +100,10 @@ class Quantizer(nn.Module):
         centers = self.centers.detach().to(torch.float32).contiguous()
         weight = self.to_logits.weight.detach().to(torch.float32).contiguous()
         bias = self.to_logits.bias.detach().to(torch.float32).contiguous()
-        self._cscale_exp = _scale_exp(self.centers_scale, self.scale_speed)
-        self._lscale_exp = _scale_exp(self.logits_scale, self.scale_speed)
+        # both scalars in one device->host copy; exp on the host (see _scale_exp)
+        both = torch.stack([self.centers_scale.detach(), self.logits_scale.detach()]).to("cpu", torch.float32)
+        self._cscale_exp = _scale_exp(both[0], self.scale_speed)
+        self._lscale_exp = _scale_exp(both[1], self.scale_speed)
         with torch.cuda.device(dev):
             st = torch.cuda.current_stream(dev).cuda_stream
             rc = L.mcq_prepare(centers.data_ptr(), self._cscale_exp, weight.data_ptr(), bias.data_ptr(), N, K, D,

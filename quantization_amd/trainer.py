@@ -104,7 +104,7 @@ class QuantizerTrainer(object):
 
         entropy_scale = 0.01                                                # quantization.py:682
         tot_loss = reconstruction_loss + logprob_loss + logits_entropy_loss * entropy_scale
-        self.last_losses = tuple(float(v.detach()) for v in losses)
+        self._last_losses = tuple(v.detach() for v in losses)   # floats on demand: no device sync per step
         tot_loss.backward()
         if self._world() > 1:
             self._all_reduce_flat([p.grad for p in self.quantizer.parameters()])
@@ -153,6 +153,11 @@ class QuantizerTrainer(object):
         ref_entropy = math.log(K)
         return (rel, logprob_loss, (ref_entropy - logits_entropy) / ref_entropy,
                 (ref_entropy - index_entropy) / ref_entropy)
+
+    @property
+    def last_losses(self):
+        """(rel_reconstruction, logprob, logits_entropy, index_entropy) losses of the last step, as floats."""
+        return tuple(float(v) for v in self._last_losses)
 
     def _init_optimizer(self):
         # quantization.py:722-730
