@@ -56,6 +56,13 @@ size_t mcq_prepared_bytes(int N, int K, int D);
 int mcq_prepare(const float *centers, float cscale_exp, const float *weight, const float *bias,
                 int N, int K, int D, void *prepared, void *stream);
 
+/* As mcq_prepare with the two scale factors read from DEVICE memory: scales_exp = float[2]
+ * {exp(10*centers_scale), exp(10*logits_scale)}.  No host copy of the (trained) scale parameters is
+ * needed, so a training loop never synchronises; the logits factor is kept inside `prepared` and
+ * used by mcq_encode_ex when MCQ_ENCODE_LSCALE_FROM_PREPARED is set.                            */
+int mcq_prepare_dev(const float *centers, const float *scales_exp, const float *weight, const float *bias,
+                    int N, int K, int D, void *prepared, void *stream);
+
 /* ---- index search ----------------------------------------------------------
  * Replaces Quantizer._compute_indexes (:281-305): learned-logit argmax followed
  * by `refine_iters` passes of Quantizer._refine_indexes (:308-547).
@@ -76,6 +83,7 @@ int mcq_encode(const float *x, long B, const void *prepared, float lscale_exp, i
  * identical to mcq_encode's for every input; the cost becomes data dependent (off by default, and
  * never used for the headline benchmark figure).                                                */
 #define MCQ_ENCODE_SKIP_FIXED_POINTS 1u
+#define MCQ_ENCODE_LSCALE_FROM_PREPARED 2u /* lscale_exp argument ignored: see mcq_prepare_dev */
 int mcq_encode_ex(const float *x, long B, const void *prepared, float lscale_exp, int N, int K, int D,
                   int refine_iters, uint8_t *out_u8, int64_t *out_i64, void *workspace,
                   size_t workspace_bytes, void *stream, unsigned flags);

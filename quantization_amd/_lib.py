@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libmcq_hip.so")
 
 # every symbol include/mcq.h declares
 SYMBOLS = (
-    "mcq_abi_version", "mcq_padded_dim", "mcq_prepared_bytes", "mcq_prepare", "mcq_encode_workspace_bytes",
+    "mcq_abi_version", "mcq_padded_dim", "mcq_prepared_bytes", "mcq_prepare", "mcq_prepare_dev", "mcq_encode_workspace_bytes",
     "mcq_encode", "mcq_encode_ex", "mcq_refine_indexes", "mcq_decode", "mcq_decode_backward", "mcq_logits", "mcq_last_encode_launches", "mcq_profile_encode",
 )
 
@@ -39,6 +39,8 @@ def lib():
     L.mcq_prepared_bytes.argtypes = [i32, i32, i32]
     L.mcq_prepare.restype = i32
     L.mcq_prepare.argtypes = [vp, f32, vp, vp, i32, i32, i32, vp, vp]
+    L.mcq_prepare_dev.restype = i32
+    L.mcq_prepare_dev.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp]
     L.mcq_encode_workspace_bytes.restype = sz
     L.mcq_encode_workspace_bytes.argtypes = [i64, i32, i32, i32]
     L.mcq_encode.restype = i32

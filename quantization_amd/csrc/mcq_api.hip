@@ -22,11 +22,11 @@ int k_cutoff(int K, int L) {
 }
 
 struct Prepared {
-    const float *C, *Q, *W, *bias;
+    const float *C, *Q, *W, *bias, *scales;
 };
 
 struct PreparedLayout {
-    size_t offC, offQ, offW, offBias, total;
+    size_t offC, offQ, offW, offBias, offScales, total;
 };
 
 PreparedLayout prepared_layout(int N, int K, int D) {
@@ -36,7 +36,8 @@ PreparedLayout prepared_layout(int N, int K, int D) {
     l.offQ = align256(l.offC + nk * Dp * 4);
     l.offW = align256(l.offQ + nk * 4);
     l.offBias = align256(l.offW + nk * Dp * 4);
-    l.total = align256(l.offBias + nk * 4);
+    l.offScales = align256(l.offBias + nk * 4);   // float[2] {cscale_exp, lscale_exp} (mcq_prepare_dev)
+    l.total = align256(l.offScales + 8);
     return l;
 }
 
@@ -44,7 +45,8 @@ Prepared prepared_view(const void *p, int N, int K, int D) {
     const PreparedLayout l = prepared_layout(N, K, D);
     const char *b = static_cast<const char *>(p);
     return Prepared{reinterpret_cast<const float *>(b + l.offC), reinterpret_cast<const float *>(b + l.offQ),
-                    reinterpret_cast<const float *>(b + l.offW), reinterpret_cast<const float *>(b + l.offBias)};
+                    reinterpret_cast<const float *>(b + l.offW), reinterpret_cast<const float *>(b + l.offBias),
+                    reinterpret_cast<const float *>(b + l.offScales)};
 }
 
 struct Workspace {
@@ -125,13 +127,13 @@ thread_local int g_last_launches = 0;
 template <int MODE>
 int launch_gemm(int K, const float *Bm, const float *xin, const uint8_t *idx_in, float lscale, const float *bias,
                 const float *R, const float *Q, long B, int N, int D, int Dp, uint8_t *idx_out, float *out,
-                hipStream_t st, int keep = 0, const int *nact = nullptr) {
+                hipStream_t st, int keep = 0, const int *nact = nullptr, const float *lscale_ptr = nullptr) {
     // default: k_gemm8s with 8 waves (64 vectors); tuning hooks: MCQ_GEMM_16W=1 -> 16 waves (128
     // vectors), MCQ_GEMM4=1 -> the 4-wave 32-float-stage kernel k_gemm (always used for K == 16)
     static const bool four_wave = getenv("MCQ_GEMM4") != nullptr;
     static const bool big_block = getenv("MCQ_GEMM_16W") != nullptr;
     const unsigned grid64 = (unsigned)(((B + 63) / 64) * N), grid128 = (unsigned)(((B + 127) / 128) * N);
-#define MCQ_GEMM_ARGS Bm, xin, idx_in, lscale, bias, R, Q, B, N, D, Dp, idx_out, out, keep, nact
+#define MCQ_GEMM_ARGS Bm, xin, idx_in, lscale, bias, R, Q, B, N, D, Dp, idx_out, out, keep, nact, lscale_ptr
     // the fused-selection epilogue needs 32 score rows of K + 4 floats plus the select scratch of every wave
     auto lds8 = [&](int K_, int vec, int waves) {
         size_t a = (size_t)2 * (K_ * 4 + vec * 4) * 16;
@@ -295,7 +297,8 @@ int run_encode(const float *x, long B, const void *prepared, float lscale, int N
         } else {
             if (prof) prof->begin();
             rc = launch_gemm<MODE_LOGITS>(K, P.W, xc, nullptr, lscale, P.bias, nullptr, nullptr, Bc, N, D, Dp, w.idx,
-                                          nullptr, st);
+                                          nullptr, st, 0, nullptr,
+                                          (flags & MCQ_ENCODE_LSCALE_FROM_PREPARED) ? P.scales + 1 : nullptr);
             if (rc) return rc;
             if (prof) prof->end(CAT_LOGITS);
         }
@@ -374,8 +377,8 @@ size_t mcq_prepared_bytes(int N, int K, int D) {
     return prepared_layout(N, K, D).total;
 }
 
-int mcq_prepare(const float *centers, float cscale_exp, const float *weight, const float *bias, int N, int K, int D,
-                void *prepared, void *stream) {
+static int prepare_impl(const float *centers, float cscale_exp, const float *scales_dev, const float *weight,
+                        const float *bias, int N, int K, int D, void *prepared, void *stream) {
     if (!domain_ok(N, K, D)) return (K < 16 || K > 256 || N > 64) ? MCQ_EUNSUPPORTED : MCQ_EINVAL;
     if (!centers || !prepared || ((weight == nullptr) != (bias == nullptr))) return MCQ_EINVAL;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -385,18 +388,34 @@ int mcq_prepare(const float *centers, float cscale_exp, const float *weight, con
     const int Dp = round_up16(D);
     const unsigned grid = (unsigned)((rows + 3) / 4);
     hipLaunchKernelGGL(k_prepare_rows, dim3(grid), dim3(256), 0, st, centers, cscale_exp, 1, rows, D, Dp,
-                       reinterpret_cast<float *>(b + l.offC), reinterpret_cast<float *>(b + l.offQ));
+                       reinterpret_cast<float *>(b + l.offC), reinterpret_cast<float *>(b + l.offQ), scales_dev);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     if (weight) {
         hipLaunchKernelGGL(k_prepare_rows, dim3(grid), dim3(256), 0, st, weight, 1.0f, 0, rows, D, Dp,
-                           reinterpret_cast<float *>(b + l.offW), static_cast<float *>(nullptr));
+                           reinterpret_cast<float *>(b + l.offW), static_cast<float *>(nullptr),
+                           static_cast<const float *>(nullptr));
         e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
         e = hipMemcpyAsync(b + l.offBias, bias, (size_t)rows * 4, hipMemcpyDeviceToDevice, st);
         if (e != hipSuccess) return (int)e;
     }
+    if (scales_dev) {
+        e = hipMemcpyAsync(b + l.offScales, scales_dev, 8, hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return (int)e;
+    }
     return 0;
+}
+
+int mcq_prepare(const float *centers, float cscale_exp, const float *weight, const float *bias, int N, int K, int D,
+                void *prepared, void *stream) {
+    return prepare_impl(centers, cscale_exp, nullptr, weight, bias, N, K, D, prepared, stream);
+}
+
+int mcq_prepare_dev(const float *centers, const float *scales_exp, const float *weight, const float *bias, int N,
+                    int K, int D, void *prepared, void *stream) {
+    if (!scales_exp) return MCQ_EINVAL;
+    return prepare_impl(centers, 1.0f, scales_exp, weight, bias, N, K, D, prepared, stream);
 }
 
 size_t mcq_encode_workspace_bytes(long B, int N, int K, int D) {

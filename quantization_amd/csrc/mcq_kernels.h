@@ -245,9 +245,11 @@ __device__ __forceinline__ void wave_select_fast(const float (&v)[VPL], const in
 // One wave per row: dst[row][0..Dp) = scale * src[row][0..D) zero padded; Q[row] = sumsq64.
 // (get_centers(), quantization.py:77-79; all_centers_sumsq, :411)
 __global__ void k_prepare_rows(const float *__restrict__ src, float scale, int apply_scale, long rows, int D,
-                               int Dp, float *__restrict__ dst, float *__restrict__ Q) {
+                               int Dp, float *__restrict__ dst, float *__restrict__ Q,
+                               const float *__restrict__ scale_ptr /* overrides `scale` when non-null */) {
     const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= rows) return;
+    if (scale_ptr) scale = *scale_ptr;
     const int lane = lane_id();
     const float *s = src + row * D;
     float *d = dst + row * Dp;
@@ -422,9 +424,10 @@ k_gemm(const float *__restrict__ Bm /*[N][K][Dp]*/, const float *__restrict__ xi
        const uint8_t *__restrict__ idx_in, float lscale, const float *__restrict__ bias,
        const float *__restrict__ Rin, const float *__restrict__ Qin, long B, int N, int D, int Dp,
        uint8_t *__restrict__ idx_out, float *__restrict__ out, int /*keep: k_gemm8s only*/,
-       const int *__restrict__ nact) {
+       const int *__restrict__ nact, const float *__restrict__ lscale_ptr /* overrides lscale when non-null */) {
     constexpr int K = 16 * T;
     if (nact) B = *nact;
+    if (lscale_ptr) lscale = *lscale_ptr;
     if ((long)(blockIdx.x / N) * kGemmVec >= B) return;   // whole tile past the active list (uniform)
     constexpr int A_UNITS = K * 8;           // 16-byte units of the entries tile per stage
     constexpr int A_PER_THREAD = (A_UNITS + 255) / 256;
@@ -597,9 +600,11 @@ __global__ void __launch_bounds__(128 * VGN, 4)
 k_gemm8s(const float *__restrict__ Bm, const float *__restrict__ xin, const uint8_t *__restrict__ idx_in,
          float lscale, const float *__restrict__ bias, const float *__restrict__ Rin,
          const float *__restrict__ Qin, long B, int N, int D, int Dp, uint8_t *__restrict__ idx_out,
-         float *__restrict__ out, int keep, const int *__restrict__ nact) {
+         float *__restrict__ out, int keep, const int *__restrict__ nact,
+         const float *__restrict__ lscale_ptr /* overrides lscale when non-null */) {
     constexpr bool IS0 = (MODE == MODE_STAGE0) || (MODE == MODE_STAGE0_SEL);
     if (nact) B = *nact;
+    if (lscale_ptr) lscale = *lscale_ptr;
     if ((long)(blockIdx.x / N) * (16 * VGN) >= B) return;   // whole tile past the active list (uniform)
     static_assert(T >= 2 && T % 2 == 0, "k_gemm8s splits the entry tiles over two wave groups");
     constexpr int K = 16 * T;

@@ -84,12 +84,20 @@ class Quantizer(nn.Module):
         return self.get_centers().mean(dim=1).sum(dim=0).detach()             # quantization.py:67-75
 
     # --------------------------------------------------------- derived state
-    def _prepared(self) -> Tensor:
-        """Device blob consumed by mcq_encode / mcq_decode; rebuilt only when a parameter changed."""
+    def _prepared(self, any_flavour: bool = False) -> Tensor:
+        """Device blob consumed by mcq_encode / mcq_decode; rebuilt only when a parameter changed.
+
+        Inference (autograd off): exp(10*scale) is formed on the host exactly as the reference does on
+        CPU (parity with its fixtures).  Training (autograd recording): the scales are read on the
+        device (mcq_prepare_dev) so that a training loop never synchronises with the host.  A blob of
+        the training flavour is never used for an inference search (its scale factors may differ from
+        the host's by an ulp); decode (`any_flavour`) takes whichever is current."""
         ps = (self.centers, self.centers_scale, self.logits_scale, self.to_logits.weight, self.to_logits.bias)
+        training = torch.is_grad_enabled() and any(p.requires_grad for p in ps)
         key = tuple((p.data_ptr(), p._version, str(p.device)) for p in ps)
-        if self._prep is not None and self._prep[0] == key:
+        if self._prep is not None and self._prep[0] == key and (self._prep[2] == "host" or training or any_flavour):
             return self._prep[1]
+        on_device = training
         dev = self.centers.device
         if dev.type != "cuda":
             raise _lib.McqError("quantization_amd.Quantizer runs on a HIP device only: move the module with "
@@ -100,17 +108,25 @@ class Quantizer(nn.Module):
         centers = self.centers.detach().to(torch.float32).contiguous()
         weight = self.to_logits.weight.detach().to(torch.float32).contiguous()
         bias = self.to_logits.bias.detach().to(torch.float32).contiguous()
-        # both scalars in one device->host copy; exp on the host (see _scale_exp)
-        both = torch.stack([self.centers_scale.detach(), self.logits_scale.detach()]).to("cpu", torch.float32)
-        self._cscale_exp = _scale_exp(both[0], self.scale_speed)
-        self._lscale_exp = _scale_exp(both[1], self.scale_speed)
+        both = torch.stack([self.centers_scale.detach(), self.logits_scale.detach()]).to(torch.float32)
         with torch.cuda.device(dev):
             st = torch.cuda.current_stream(dev).cuda_stream
-            rc = L.mcq_prepare(centers.data_ptr(), self._cscale_exp, weight.data_ptr(), bias.data_ptr(), N, K, D,
-                               blob.data_ptr(), st)
+            if on_device:
+                scales = (both * self.scale_speed).exp().contiguous()
+                self._scale_flags = 2       # MCQ_ENCODE_LSCALE_FROM_PREPARED
+                self._cscale_exp = self._lscale_exp = 1.0
+                rc = L.mcq_prepare_dev(centers.data_ptr(), scales.data_ptr(), weight.data_ptr(), bias.data_ptr(), N, K,
+                                       D, blob.data_ptr(), st)
+            else:
+                both = both.to("cpu")       # both scalars in one device->host copy; exp on the host
+                self._scale_flags = 0
+                self._cscale_exp = _scale_exp(both[0], self.scale_speed)
+                self._lscale_exp = _scale_exp(both[1], self.scale_speed)
+                rc = L.mcq_prepare(centers.data_ptr(), self._cscale_exp, weight.data_ptr(), bias.data_ptr(), N, K, D,
+                                   blob.data_ptr(), st)
         _lib.check(rc, "mcq_prepare")
         # the inputs above may be temporaries: the stream orders their reuse after the kernel
-        self._prep = (key, blob)
+        self._prep = (key, blob, "device" if on_device else "host")
         return blob
 
     def _check_domain(self):
@@ -150,7 +166,8 @@ class Quantizer(nn.Module):
             st = torch.cuda.current_stream(dev).cuda_stream
             rc = L.mcq_encode_ex(x2d.data_ptr(), B, blob.data_ptr(), self._lscale_exp, N, K, D, int(iters),
                                  out.data_ptr() if as_bytes else None, None if as_bytes else out.data_ptr(),
-                                 ws.data_ptr(), ws.numel(), st, 1 if getattr(self, "skip_fixed_points", False) else 0)
+                                 ws.data_ptr(), ws.numel(), st,
+                                 (1 if getattr(self, "skip_fixed_points", False) else 0) | self._scale_flags)
         _lib.check(rc, "mcq_encode")
         return out
 
@@ -238,7 +255,7 @@ class Quantizer(nn.Module):
         out = torch.empty((B, D), dtype=torch.float32, device=flat.device)
         if B == 0:
             return out
-        blob = self._prepared()
+        blob = self._prepared(any_flavour=True)
         with torch.cuda.device(flat.device):
             st = torch.cuda.current_stream(flat.device).cuda_stream
             rc = L.mcq_decode(flat.data_ptr(), 1 if flat.dtype == torch.uint8 else 8, per_row, B, blob.data_ptr(),
@@ -252,7 +269,8 @@ class Quantizer(nn.Module):
         x2d = x.reshape(-1, self.dim).detach().to(torch.float32).contiguous()
         N, K, D = self.num_codebooks, self.codebook_size, self.dim
         out = torch.empty((x2d.shape[0], N * K), dtype=torch.float32, device=x2d.device)
-        blob = self._prepared()
+        with torch.no_grad():      # host-side scale factors (mcq_logits takes lscale by value)
+            blob = self._prepared()
         with torch.cuda.device(x2d.device):
             st = torch.cuda.current_stream(x2d.device).cuda_stream
             rc = L.mcq_logits(x2d.data_ptr(), x2d.shape[0], blob.data_ptr(), self._lscale_exp, N, K, D,

@@ -51,3 +51,17 @@ q = tr.quantizer
 def search(): q._compute_indexes(x, 2)
 print("search(2 iters) ms", round(1e3 * timeit(search, 5), 3))
 json.dump(res, open(os.path.join(ROOT, "gpurun_out", "configs.json"), "w"), indent=1)
+
+# trainer throughput without a host sync per step (what a training loop sees)
+torch.manual_seed(0); random.seed(0)
+tr = QuantizerTrainer(dim=512, bytes_per_frame=8, device=torch.device("cuda"), phase_one_iters=400, phase_two_iters=400)
+x = torch.randn(4096, 512, device="cuda")
+for _ in range(5): tr.step(x)
+res2 = {}
+for phase, until in (("phase1", 300), ("phase2", 700)):
+    while tr.cur_iter < until - 100: tr.step(x)
+    torch.cuda.synchronize(); t = time.perf_counter(); n0 = tr.cur_iter
+    while tr.cur_iter < until: tr.step(x)
+    torch.cuda.synchronize()
+    res2[phase] = round(1e3 * (time.perf_counter() - t) / (tr.cur_iter - n0), 3)
+print("trainer ms/step, free-running:", res2)
