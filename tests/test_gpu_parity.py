@@ -231,3 +231,17 @@ def test_fixed_point_skipping_gives_identical_codes(name):
         assert torch.equal(ref, got), (name, it)
     q.skip_fixed_points = True
     assert torch.equal(q.encode(x[:77], 5), q.encode(x, 5)[:77])
+
+
+@pytest.mark.parametrize("D,K,N,B,it", [(1024, 16, 64, 48, 1), (768, 256, 32, 48, 1), (2048, 256, 8, 100, 2),
+                                         (1000, 128, 16, 64, 2)])
+def test_large_and_unusual_shapes_vs_oracle(D, K, N, B, it):
+    """windowed old-row staging, streaming heavy-L pair path, N = 32 / 64 ladders, dims past 1024"""
+    sd = gen.synthetic_state(500 + D + N, D, K, N)
+    q = load_quantizer(sd, D, K, N)
+    o = oracle_of(sd)
+    x = gen.make_gaussian(7 + D, B, D)
+    got = q.encode(torch.from_numpy(x).cuda(), it, as_bytes=False).cpu().numpy()
+    want = o.compute_indexes(x, it)
+    assert np.array_equal(got, want)
+    assert np.array_equal(q.decode(torch.from_numpy(got).cuda()).cpu().numpy(), o.decode(want))
