@@ -923,6 +923,35 @@ k_pair(const float *__restrict__ C, const uint8_t *__restrict__ idx, const float
     const int perm_addr = (4 * r + (g ^ ((r >> 3) << 1))) << 2;   // byte address of this lane's source lane
     const uint8_t *te = tup_in + ((b * Gin + ge) * KI) * (long)L;
     const uint8_t *to = tup_in + ((b * Gin + gd) * KI) * (long)L;
+    // Everything the epilogue needs from memory is requested NOW (E, the candidates' scores, and for
+    // L <= 4 the candidates' tuples, lane j holding tuple j of both groups), so that after the MFMA
+    // loop no global round trip is left: the selected tuples then come from registers by ds_bpermute.
+    const float Eb = E[b];
+    float se_pre[TI][4], so_pre[TI];
+    {
+        const float *Se = S_in + (b * Gin + ge) * (long)KI;
+        const float *So = S_in + (b * Gin + gd) * (long)KI;
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti) {
+            const int bcol = 16 * ti + r;
+            so_pre[ti] = So[bcol < KI ? bcol : 0];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int a = 16 * ti + 4 * g + v;
+                se_pre[ti][v] = Se[a < KI ? a : 0];
+            }
+        }
+    }
+    constexpr bool TUP_IN_REGS = (L <= 4);
+    uint32_t tup_e = 0, tup_o = 0;   // lane j < KI: the L bytes of tuple j of the even / odd group
+    if constexpr (TUP_IN_REGS) {
+        const int cj = lane < KI ? lane : 0;
+#pragma unroll
+        for (int j = 0; j < L; ++j) {
+            tup_e |= (uint32_t)te[cj * L + j] << (8 * j);
+            tup_o |= (uint32_t)to[cj * L + j] << (8 * j);
+        }
+    }
     bool validA[TI], validB[TI];
     // side 0 = even group (MFMA A / rows), side 1 = odd group (MFMA B / columns)
     uint32_t coff[2][TI][SMALL ? L : 1];
@@ -1156,9 +1185,6 @@ k_pair(const float *__restrict__ C, const uint8_t *__restrict__ idx, const float
     }
 
     // scores: lane holds rows a = 16*ti + 4*g + v, column bcol = 16*tj + r
-    const float Eb = E[b];
-    const float *Se = S_in + (b * Gin + ge) * (long)KI;
-    const float *So = S_in + (b * Gin + gd) * (long)KI;
     float sv[VPL];
     int sp[VPL];
 #pragma unroll
@@ -1166,13 +1192,11 @@ k_pair(const float *__restrict__ C, const uint8_t *__restrict__ idx, const float
 #pragma unroll
         for (int tj = 0; tj < TI; ++tj) {
             const int bcol = 16 * tj + r;
-            const float sob = (bcol < KI) ? So[bcol < KI ? bcol : 0] : 0.f;
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const int a = 16 * ti + 4 * g + v;
                 const bool ok = (a < KI) && (bcol < KI);
-                const float sea = ok ? Se[ok ? a : 0] : 0.f;
-                const float val = ((sea + sob) - Eb) + 2.0f * acc[ti][tj][v];
+                const float val = ((se_pre[ti][v] + so_pre[tj]) - Eb) + 2.0f * acc[ti][tj][v];
                 const int slot = (ti * TI + tj) * 4 + v;
                 sv[slot] = ok ? val : INFINITY;
                 sp[slot] = ok ? a * KI + bcol : kBigPos;
@@ -1181,17 +1205,24 @@ k_pair(const float *__restrict__ C, const uint8_t *__restrict__ idx, const float
     float ov;
     int op;
     wave_select_fast<VPL>(sv, sp, keep, M, scratch, ov, op);
+    // lane j < keep owns output candidate j = (a, bb) in the input lists
+    const int a = (lane < keep ? op : 0) / KI, bb = (lane < keep ? op : 0) % KI;
+    uint32_t we = 0, wo = 0;
+    if constexpr (TUP_IN_REGS) {   // all lanes take part in the cross-lane reads
+        we = (uint32_t)__builtin_amdgcn_ds_bpermute(a << 2, (int)tup_e);
+        wo = (uint32_t)__builtin_amdgcn_ds_bpermute(bb << 2, (int)tup_o);
+    }
     if (lane < keep) {
-        const int a = op / KI, bb = op % KI;
-        if (idx_final != nullptr) {
-            // last step (one group, keep == 1): the tuple is the new index vector (:468-469)
-            uint8_t *o = idx_final + b * N;
-            for (int j = 0; j < L; ++j) { o[j] = te[a * L + j]; o[L + j] = to[bb * L + j]; }
+        // last step (one group, keep == 1): the tuple is the new index vector (:468-469)
+        uint8_t *o = (idx_final != nullptr) ? idx_final + b * N
+                                            : tup_out + ((b * Gout + go) * (long)keep + lane) * (2 * L);
+        if constexpr (TUP_IN_REGS) {
+#pragma unroll
+            for (int j = 0; j < L; ++j) { o[j] = (uint8_t)(we >> (8 * j)); o[L + j] = (uint8_t)(wo >> (8 * j)); }
         } else {
-            uint8_t *o = tup_out + ((b * Gout + go) * (long)keep + lane) * (2 * L);
             for (int j = 0; j < L; ++j) { o[j] = te[a * L + j]; o[L + j] = to[bb * L + j]; }
-            S_out[(b * Gout + go) * (long)keep + lane] = ov;
         }
+        if (idx_final == nullptr) S_out[(b * Gout + go) * (long)keep + lane] = ov;
     }
 }
 
