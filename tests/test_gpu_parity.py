@@ -245,3 +245,26 @@ def test_large_and_unusual_shapes_vs_oracle(D, K, N, B, it):
     want = o.compute_indexes(x, it)
     assert np.array_equal(got, want)
     assert np.array_equal(q.decode(torch.from_numpy(got).cuda()).cpu().numpy(), o.decode(want))
+
+
+def test_non_finite_inputs_terminate_with_codes_in_range():
+    """NaN / Inf rows give unspecified codes but never a hang, a fault or an
+    out-of-range index, and do not disturb their neighbours."""
+    sd = gen.synthetic_state(1, 64, 256, 8)
+    q = load_quantizer(sd, 64, 256, 8)
+    o = oracle_of(sd)
+    x = gen.make_gaussian(2, 300, 64)
+    bad = x.copy()
+    bad[3] = np.nan
+    bad[7, 5] = np.inf
+    bad[9] = -np.inf
+    bad[11] = 1e30
+    for skip in (False, True):
+        q.skip_fixed_points = skip
+        c = q.encode(torch.from_numpy(bad).cuda(), 5, as_bytes=False)
+        y = q.decode(c)
+        torch.cuda.synchronize()
+        c = c.cpu().numpy()
+        assert c.min() >= 0 and c.max() <= 255 and tuple(y.shape) == (300, 64)
+        good = np.setdiff1d(np.arange(300), [3, 7, 9, 11])
+        assert np.array_equal(c[good], o.compute_indexes(x[good], 5))
