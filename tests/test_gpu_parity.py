@@ -268,3 +268,14 @@ def test_non_finite_inputs_terminate_with_codes_in_range():
         assert c.min() >= 0 and c.max() <= 255 and tuple(y.shape) == (300, 64)
         good = np.setdiff1d(np.arange(300), [3, 7, 9, 11])
         assert np.array_equal(c[good], o.compute_indexes(x[good], 5))
+
+
+def test_encode_from_host_overlapped_copies():
+    fx = fixtures.load("trained_d64_b8_p2")
+    q = load_quantizer(fx["state"], fx["D"], fx["K"], fx["N"])
+    x = torch.from_numpy(fx["x"])
+    want = q.encode(x.cuda(), 3).cpu()
+    got = q.encode_from_host(x, 3, chunk=300)          # 7 chunks, ragged tail, double-buffered H2D
+    assert got.dtype == torch.uint8 and not got.is_cuda and torch.equal(got, want)
+    got64 = q.encode_from_host(x.reshape(4, 512, -1), 3, as_bytes=False, chunk=1000)
+    assert tuple(got64.shape) == (4, 512, fx["N"]) and torch.equal(got64.reshape(-1, fx["N"]), want.to(torch.int64))
