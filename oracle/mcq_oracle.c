@@ -364,6 +364,26 @@ int mcq_oracle_compute_indexes(const mcq_oracle *o, const float *x, long B, int 
     return 0;
 }
 
+/* `iters` passes of _refine_indexes (:308-547) from caller-supplied indexes, batch form */
+int mcq_oracle_refine(const mcq_oracle *o, const float *x, long B, int iters, uint8_t *idx, int nthreads) {
+    const int N = o->N, K = o->K, D = o->D, Dp = o->Dp;
+    if (K < 16 || K > 256) return -2;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#else
+    (void)nthreads;
+#endif
+#pragma omp parallel
+    {
+        scratch s; scratch_alloc(&s, N, K, Dp);
+#pragma omp for schedule(dynamic, 8)
+        for (long b = 0; b < B; b++)
+            for (int it = 0; it < iters; it++) refine_one(o, x + (size_t)b * D, idx + (size_t)b * N, &s, NULL);
+        scratch_free(&s);
+    }
+    return 0;
+}
+
 /* one refinement pass from given indexes, with the per-stage trace (one vector) */
 int mcq_oracle_refine_trace(const mcq_oracle *o, const float *x, uint8_t *idx, float *xerr, float *E,
                             float *R, float *S0, int *sel_pos, float *sel_val, float *comb) {

@@ -17,8 +17,8 @@ _lib = None
 
 def build(force: bool = False) -> str:
     """Compile mcq_oracle.c with gcc (oracle/Makefile); returns the .so path."""
-    src = os.path.join(_HERE, "mcq_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    newest = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("mcq_oracle.c", "mcq_host.c", "mcq_host.h"))
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < newest:
         subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s", "_build/libmcq_oracle.so"])
     return _SO
 
