@@ -196,7 +196,13 @@ int launch_pair_t(const float *C, const uint8_t *idx, const float *E, const uint
         win = (((Dp + nwin - 1) / nwin) + 63) / 64 * 64;
     }
     if (const char *e = getenv("MCQ_PAIR_WIN")) { const int v = atoi(e); if (v >= 64 && L >= 4) win = v < Dp ? v : Dp; }   // tuning hook
-    const size_t per_wave = (size_t)2 * L * win * 4 + scratch;
+    // operands reach MFMA lane order through an LDS tile (ds_write_b128 + ds_read_b128) for single-leaf
+    // candidates, by ds_bpermute otherwise (measured: L=1 5 % faster, L=4 10 % slower with the tile);
+    // MCQ_PAIR_XL=0/1 forces one way (tuning hook)
+    static const int xl_env = getenv("MCQ_PAIR_XL") ? atoi(getenv("MCQ_PAIR_XL")) : -1;
+    const bool xl = xl_env >= 0 ? xl_env != 0 : (L == 1);
+    constexpr int TI = (KI + 15) / 16;
+    const size_t per_wave = (size_t)2 * L * win * 4 + scratch + (xl ? (size_t)2 * TI * 1024 : 0);
     // one wave per workgroup: the waves share nothing (private LDS, no barrier), and single-wave
     // workgroups measured fastest (finer-grained dispatch, LDS released per wave)
     int wpb = 1;
@@ -205,8 +211,21 @@ int launch_pair_t(const float *C, const uint8_t *idx, const float *E, const uint
         if (v >= 1 && v <= 4 && per_wave * v <= 65536) wpb = v;
     }
     const unsigned grid = (unsigned)(((B + wpb - 1) / wpb) * Gout);
-    hipLaunchKernelGGL((k_pair<L, KI>), dim3(grid), dim3(64 * wpb), per_wave * wpb, st, C, idx, E, tup_in, S_in, B, N, K,
-                       Dp, Gout, keep, win, tup_out, S_out, idx_final, nact);
+    static const int abl = getenv("MCQ_PAIR_ABL") ? atoi(getenv("MCQ_PAIR_ABL")) : 0;   // timing experiments (wrong results)
+#define MCQ_PAIR_ABL_CASE(A)                                                                                          \
+    if (abl == A) {                                                                                                   \
+        hipLaunchKernelGGL((k_pair<L, KI, false, A>), dim3(grid), dim3(64 * wpb), per_wave * wpb, st, C, idx, E, tup_in,  \
+                           S_in, B, N, K, Dp, Gout, keep, win, tup_out, S_out, idx_final, nact);                      \
+        return 0;                                                                                                     \
+    }
+    MCQ_PAIR_ABL_CASE(1) MCQ_PAIR_ABL_CASE(2) MCQ_PAIR_ABL_CASE(3) MCQ_PAIR_ABL_CASE(4)
+#undef MCQ_PAIR_ABL_CASE
+    if (xl)
+        hipLaunchKernelGGL((k_pair<L, KI, true>), dim3(grid), dim3(64 * wpb), per_wave * wpb, st, C, idx, E, tup_in, S_in, B,
+                           N, K, Dp, Gout, keep, win, tup_out, S_out, idx_final, nact);
+    else
+        hipLaunchKernelGGL((k_pair<L, KI, false>), dim3(grid), dim3(64 * wpb), per_wave * wpb, st, C, idx, E, tup_in, S_in,
+                           B, N, K, Dp, Gout, keep, win, tup_out, S_out, idx_final, nact);
     MCQ_LAUNCH_CHECK();
     return 0;
 }

@@ -881,7 +881,7 @@ struct DeltaBuilder {
     }
 };
 
-template <int L, int KI>
+template <int L, int KI, bool XL = false, int ABL = 0>
 __global__ void __launch_bounds__(256)
 k_pair(const float *__restrict__ C, const uint8_t *__restrict__ idx, const float *__restrict__ E,
        const uint8_t *__restrict__ tup_in /*[B][Gin][KI][L]*/, const float *__restrict__ S_in /*[B][Gin][KI]*/,
@@ -912,6 +912,10 @@ k_pair(const float *__restrict__ C, const uint8_t *__restrict__ idx, const float
 
     u64 *scratch = reinterpret_cast<u64 *>(smem) + (size_t)wave * kSelectLdsU64;
     float *oldwin = reinterpret_cast<float *>(smem) + (size_t)wpb * kSelectLdsU64 * 2 + (size_t)wave * 2 * L * win;
+    // XL: operands change lane order through a wave-private LDS tile (ds_write_b128 + ds_read_b128:
+    // 13.4 + 4.3 LDS cycles per KB) instead of four ds_bpermute (4 x 6.2) -- tools/micro/lds_write_rates.hip
+    f32x4 *xpose = reinterpret_cast<f32x4 *>(smem + (size_t)wpb * (kSelectLdsU64 * 8 + (size_t)2 * L * win * 4)) +
+                   (size_t)wave * (2 * TI * 64);
 
     // Operand rows are LOADED in a coalescing-friendly lane order -- lane 4*rs + ps reads the
     // ps-th float4 of the k-block of candidate row rs, so each quad of lanes covers 64 contiguous
@@ -919,8 +923,11 @@ k_pair(const float *__restrict__ C, const uint8_t *__restrict__ idx, const float
     // order (lane 16*g + r holds row r, float4 g) with four ds_bpermute per float4.
     // (quads 8..15 hold their four parts rotated by two so that the 32 lanes of a bpermute
     // half-wave pull from 32 distinct LDS-crossbar banks)
-    const int rs = lane >> 2, ps = (lane & 3) ^ ((lane >> 5) << 1);
+    const int rs = lane >> 2, ps = XL ? (lane & 3) : ((lane & 3) ^ ((lane >> 5) << 1));
     const int perm_addr = (4 * r + (g ^ ((r >> 3) << 1))) << 2;   // byte address of this lane's source lane
+    // LDS tile units (16 B): row-major 4 per row, the quad index xor (row / 4) % 4 keeps the 16 lanes of a
+    // ds_read_b128 group (fixed g) on 16 distinct bank quads
+    const int xw = 4 * rs + (ps ^ ((rs >> 2) & 3)), xr = 4 * r + (g ^ ((r >> 2) & 3));
     const uint8_t *te = tup_in + ((b * Gin + ge) * KI) * (long)L;
     const uint8_t *to = tup_in + ((b * Gin + gd) * KI) * (long)L;
     // Everything the epilogue needs from memory is requested NOW (E, the candidates' scores, and for
@@ -984,11 +991,23 @@ k_pair(const float *__restrict__ C, const uint8_t *__restrict__ idx, const float
         }
     };
     const char *Cb = reinterpret_cast<const char *>(C);   // byte offsets (< 2^32) from the uniform base
-    auto to_mfma_order = [&](f32x4 v) {
+    const f32x4 abl_const = {Eb, Eb + 1.f, Eb + 2.f, Eb + 3.f};
+#define MCQ_PAIR_GATHER(expr) ((ABL == 4) ? abl_const : *reinterpret_cast<const f32x4 *>(expr))
+    auto to_mfma_order = [&](f32x4 v, int slot) {
         f32x4 o;
+        if constexpr (ABL == 3) {
+            return v;
+        } else if constexpr (XL) {
+            f32x4 *t = xpose + slot * 64;
+            t[xw] = v;
+            asm volatile("" ::: "memory");   // same-wave LDS accesses execute in order; keep the compiler from swapping them
+            o = t[xr];
+            asm volatile("" ::: "memory");
+        } else {
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-            o[c] = __int_as_float(__builtin_amdgcn_ds_bpermute(perm_addr, __float_as_int(v[c])));
+            for (int c = 0; c < 4; ++c)
+                o[c] = __int_as_float(__builtin_amdgcn_ds_bpermute(perm_addr, __float_as_int(v[c])));
+        }
         return o;
     };
 
@@ -1033,11 +1052,13 @@ k_pair(const float *__restrict__ C, const uint8_t *__restrict__ idx, const float
 #pragma unroll
             for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
-                for (int tj = 0; tj < TI; ++tj)
-                    acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(da[ti][i], db[tj][i], acc[ti][tj], 0, 0, 0);
+                for (int tj = 0; tj < TI; ++tj) {
+                    if constexpr (ABL == 2) acc[ti][tj][i] += da[ti][i] + db[tj][i];
+                    else acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(da[ti][i], db[tj][i], acc[ti][tj], 0, 0, 0);
+                }
     };
-    auto finish_operand = [&](f32x4 d, bool valid) {
-        d = to_mfma_order(d);
+    auto finish_operand = [&](f32x4 d, bool valid, int slot) {
+        d = to_mfma_order(d, slot);
         if (KI < 16 && !valid) d = (f32x4){0.f, 0.f, 0.f, 0.f};  // padded rows of an 8-candidate group
         return d;
     };
@@ -1045,7 +1066,7 @@ k_pair(const float *__restrict__ C, const uint8_t *__restrict__ idx, const float
     constexpr bool PIPE = (L * TI) <= 2;
     constexpr int UNR = PIPE ? 4 / (L * TI) : 1;
 
-    for (int w0 = 0; w0 < Dp; w0 += win) {
+    for (int w0 = 0; w0 < (ABL == 1 ? 0 : Dp); w0 += win) {
         const int wlen = (Dp - w0 < win) ? (Dp - w0) : win;
         if (w0 > 0) wave_lds_fence();      // every read of the previous window has been issued
         stage_old(w0, wlen);
@@ -1065,8 +1086,8 @@ k_pair(const float *__restrict__ C, const uint8_t *__restrict__ idx, const float
                     for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
                         for (int j = 0; j < L; ++j) {
-                            ra[u][ti][j] = *reinterpret_cast<const f32x4 *>(Cb + (row_off(0, ti, j) + (uint32_t)(64 * (kb_lo + kb0 + u))));
-                            rb[u][ti][j] = *reinterpret_cast<const f32x4 *>(Cb + (row_off(1, ti, j) + (uint32_t)(64 * (kb_lo + kb0 + u))));
+                            ra[u][ti][j] = MCQ_PAIR_GATHER(Cb + (row_off(0, ti, j) + (uint32_t)(64 * (kb_lo + kb0 + u))));
+                            rb[u][ti][j] = MCQ_PAIR_GATHER(Cb + (row_off(1, ti, j) + (uint32_t)(64 * (kb_lo + kb0 + u))));
                         }
             };
             auto compute_batch = [&](const f32x4 (&ra)[UNR][TI][L], const f32x4 (&rb)[UNR][TI][L], int kb0) {
@@ -1075,8 +1096,8 @@ k_pair(const float *__restrict__ C, const uint8_t *__restrict__ idx, const float
                     f32x4 da[TI], db[TI];
 #pragma unroll
                     for (int ti = 0; ti < TI; ++ti) {
-                        da[ti] = finish_operand(DeltaBuilder<L>::template build<L>(ra[u][ti], oldp, win, 0, 16 * (kb0 + u)), validA[ti]);
-                        db[ti] = finish_operand(DeltaBuilder<L>::template build<L>(rb[u][ti], oldp + L * win, win, 0, 16 * (kb0 + u)), validB[ti]);
+                        da[ti] = finish_operand(DeltaBuilder<L>::template build<L>(ra[u][ti], oldp, win, 0, 16 * (kb0 + u)), validA[ti], ti);
+                        db[ti] = finish_operand(DeltaBuilder<L>::template build<L>(rb[u][ti], oldp + L * win, win, 0, 16 * (kb0 + u)), validB[ti], TI + ti);
                     }
                     mfma_block(da, db);
                 }
@@ -1113,14 +1134,14 @@ k_pair(const float *__restrict__ C, const uint8_t *__restrict__ idx, const float
                 for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
                     for (int j = 0; j < L; ++j) {
-                        ta[ti][j] = *reinterpret_cast<const f32x4 *>(Cb + (row_off(0, ti, j) + (uint32_t)(64 * (kb_lo + kbi))));
-                        tb[ti][j] = *reinterpret_cast<const f32x4 *>(Cb + (row_off(1, ti, j) + (uint32_t)(64 * (kb_lo + kbi))));
+                        ta[ti][j] = MCQ_PAIR_GATHER(Cb + (row_off(0, ti, j) + (uint32_t)(64 * (kb_lo + kbi))));
+                        tb[ti][j] = MCQ_PAIR_GATHER(Cb + (row_off(1, ti, j) + (uint32_t)(64 * (kb_lo + kbi))));
                     }
                 f32x4 da[TI], db[TI];
 #pragma unroll
                 for (int ti = 0; ti < TI; ++ti) {
-                    da[ti] = finish_operand(DeltaBuilder<L>::template build<L>(ta[ti], oldp, win, 0, 16 * kbi), validA[ti]);
-                    db[ti] = finish_operand(DeltaBuilder<L>::template build<L>(tb[ti], oldp + L * win, win, 0, 16 * kbi), validB[ti]);
+                    da[ti] = finish_operand(DeltaBuilder<L>::template build<L>(ta[ti], oldp, win, 0, 16 * kbi), validA[ti], ti);
+                    db[ti] = finish_operand(DeltaBuilder<L>::template build<L>(tb[ti], oldp + L * win, win, 0, 16 * kbi), validB[ti], TI + ti);
                 }
                 mfma_block(da, db);
             }
@@ -1134,8 +1155,8 @@ k_pair(const float *__restrict__ C, const uint8_t *__restrict__ idx, const float
                 for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
                     for (int j = 0; j < L; ++j) {
-                        ra[ti][j] = *reinterpret_cast<const f32x4 *>(Cb + (row_off(0, ti, j) + (uint32_t)(64 * (kb_lo + kbi))));
-                        rb[ti][j] = *reinterpret_cast<const f32x4 *>(Cb + (row_off(1, ti, j) + (uint32_t)(64 * (kb_lo + kbi))));
+                        ra[ti][j] = MCQ_PAIR_GATHER(Cb + (row_off(0, ti, j) + (uint32_t)(64 * (kb_lo + kbi))));
+                        rb[ti][j] = MCQ_PAIR_GATHER(Cb + (row_off(1, ti, j) + (uint32_t)(64 * (kb_lo + kbi))));
                     }
             };
             for (int kbi = 0; kbi < nkb; ++kbi) {
@@ -1144,8 +1165,8 @@ k_pair(const float *__restrict__ C, const uint8_t *__restrict__ idx, const float
                 f32x4 da[TI], db[TI];
 #pragma unroll
                 for (int ti = 0; ti < TI; ++ti) {
-                    da[ti] = finish_operand(DeltaBuilder<L>::template build<L>(ra[ti], oldp, win, 0, 16 * kbi), validA[ti]);
-                    db[ti] = finish_operand(DeltaBuilder<L>::template build<L>(rb[ti], oldp + L * win, win, 0, 16 * kbi), validB[ti]);
+                    da[ti] = finish_operand(DeltaBuilder<L>::template build<L>(ra[ti], oldp, win, 0, 16 * kbi), validA[ti], ti);
+                    db[ti] = finish_operand(DeltaBuilder<L>::template build<L>(rb[ti], oldp + L * win, win, 0, 16 * kbi), validB[ti], TI + ti);
                 }
                 mfma_block(da, db);
                 __builtin_amdgcn_sched_barrier(0);
@@ -1157,7 +1178,7 @@ k_pair(const float *__restrict__ C, const uint8_t *__restrict__ idx, const float
             auto load_tile = [&](f32x4 (&buf)[L], int side, int ti, int kbi) {
 #pragma unroll
                 for (int j = 0; j < L; ++j)
-                    buf[j] = *reinterpret_cast<const f32x4 *>(Cb + (row_off(side, ti, j) + (uint32_t)(64 * (kb_lo + kbi))));
+                    buf[j] = MCQ_PAIR_GATHER(Cb + (row_off(side, ti, j) + (uint32_t)(64 * (kb_lo + kbi))));
             };
             f32x4 bufA[L], bufB[L];
             load_tile(bufA, 0, 0, 0);
@@ -1175,8 +1196,8 @@ k_pair(const float *__restrict__ C, const uint8_t *__restrict__ idx, const float
                         load_tile(bufA, 0, 0, nxt);
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    if (side == 0) da[ti] = finish_operand(DeltaBuilder<L>::template build<L>(bufA, oldp, win, 0, 16 * kbi), validA[ti]);
-                    else db[ti] = finish_operand(DeltaBuilder<L>::template build<L>(bufB, oldp + L * win, win, 0, 16 * kbi), validB[ti]);
+                    if (side == 0) da[ti] = finish_operand(DeltaBuilder<L>::template build<L>(bufA, oldp, win, 0, 16 * kbi), validA[ti], ti);
+                    else db[ti] = finish_operand(DeltaBuilder<L>::template build<L>(bufB, oldp + L * win, win, 0, 16 * kbi), validB[ti], TI + ti);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 mfma_block(da, db);
