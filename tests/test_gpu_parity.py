@@ -279,3 +279,30 @@ def test_encode_from_host_overlapped_copies():
     assert got.dtype == torch.uint8 and not got.is_cuda and torch.equal(got, want)
     got64 = q.encode_from_host(x.reshape(4, 512, -1), 3, as_bytes=False, chunk=1000)
     assert tuple(got64.shape) == (4, 512, fx["N"]) and torch.equal(got64.reshape(-1, fx["N"]), want.to(torch.int64))
+
+
+def test_encode_and_decode_are_hip_graph_capturable():
+    """every entry point only enqueues on the given stream (include/mcq.h): a captured encode+decode
+    replays on new input without host work, device-side scale factors included"""
+    fx = fixtures.load("trained_d64_b8_p2")
+    q = load_quantizer(fx["state"], fx["D"], fx["K"], fx["N"])
+    x_all = torch.from_numpy(fx["x"]).cuda()
+    static_x = x_all[:1024].clone()
+    want0 = q.encode(static_x, 5)                       # also warms the prepared state and the workspace
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        q.encode(static_x, 5)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        static_codes = q.encode(static_x, 5)
+        static_y = q.decode(static_codes)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(static_codes, want0)
+    static_x.copy_(x_all[1024:2048])
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(static_codes, q.encode(x_all[1024:2048], 5))
+    assert torch.equal(static_y, q.decode(static_codes))
