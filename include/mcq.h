@@ -84,6 +84,10 @@ int mcq_encode(const float *x, long B, const void *prepared, float lscale_exp, i
  * never used for the headline benchmark figure).                                                */
 #define MCQ_ENCODE_SKIP_FIXED_POINTS 1u
 #define MCQ_ENCODE_LSCALE_FROM_PREPARED 2u /* lscale_exp argument ignored: see mcq_prepare_dev */
+/* x points to IEEE fp16 [B][D] (the reference's data helper yields fp16 frames that callers widen,
+ * quantization/quantization.py:798): rows widen to fp32 in the kernels' load path.  Every fp16 value
+ * is an fp32 value, so the codes equal those of the widened input bit for bit.                   */
+#define MCQ_ENCODE_X_FP16 4u
 int mcq_encode_ex(const float *x, long B, const void *prepared, float lscale_exp, int N, int K, int D,
                   int refine_iters, uint8_t *out_u8, int64_t *out_i64, void *workspace,
                   size_t workspace_bytes, void *stream, unsigned flags);

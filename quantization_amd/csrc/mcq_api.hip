@@ -127,13 +127,14 @@ thread_local int g_last_launches = 0;
 template <int MODE>
 int launch_gemm(int K, const float *Bm, const float *xin, const uint8_t *idx_in, float lscale, const float *bias,
                 const float *R, const float *Q, long B, int N, int D, int Dp, uint8_t *idx_out, float *out,
-                hipStream_t st, int keep = 0, const int *nact = nullptr, const float *lscale_ptr = nullptr) {
+                hipStream_t st, int keep = 0, const int *nact = nullptr, const float *lscale_ptr = nullptr,
+                int xh = 0) {
     // default: k_gemm8s with 8 waves (64 vectors); tuning hooks: MCQ_GEMM_16W=1 -> 16 waves (128
     // vectors), MCQ_GEMM4=1 -> the 4-wave 32-float-stage kernel k_gemm (always used for K == 16)
     static const bool four_wave = getenv("MCQ_GEMM4") != nullptr;
     static const bool big_block = getenv("MCQ_GEMM_16W") != nullptr;
     const unsigned grid64 = (unsigned)(((B + 63) / 64) * N), grid128 = (unsigned)(((B + 127) / 128) * N);
-#define MCQ_GEMM_ARGS Bm, xin, idx_in, lscale, bias, R, Q, B, N, D, Dp, idx_out, out, keep, nact, lscale_ptr
+#define MCQ_GEMM_ARGS Bm, xin, idx_in, lscale, bias, R, Q, B, N, D, Dp, idx_out, out, keep, nact, lscale_ptr, xh
     // the fused-selection epilogue needs 32 score rows of K + 4 floats plus the select scratch of every wave
     auto lds8 = [&](int K_, int vec, int waves) {
         size_t a = (size_t)2 * (K_ * 4 + vec * 4) * 16;
@@ -254,13 +255,13 @@ int launch_pair(int L, int KI, const float *C, const uint8_t *idx, const float *
 }
 
 int launch_residual(const float *x, const uint8_t *idx, const float *C, long B, int N, int K, int D, int Dp,
-                    float *xerr, float *E, float *R, hipStream_t st, const int *nact, const int *map) {
+                    float *xerr, float *E, float *R, hipStream_t st, const int *nact, const int *map, int xh = 0) {
     const dim3 grid((unsigned)((B + 3) / 4)), block(256);
     const int J = (Dp / 4 + 63) / 64;
 #define MCQ_RES_CASE(NN, JJ)                                                                                   \
     if (N == NN && J == JJ) {                                                                                  \
         hipLaunchKernelGGL((k_residual_reg<NN, JJ>), grid, block, 0, st, x, idx, C, B, K, D, Dp, xerr, E, R, nact, \
-                           map);                                                                              \
+                           map, xh);                                                                          \
         MCQ_LAUNCH_CHECK();                                                                                    \
         return 0;                                                                                              \
     }
@@ -274,7 +275,7 @@ int launch_residual(const float *x, const uint8_t *idx, const float *C, long B, 
     MCQ_RES_CASE(2, 1)
     MCQ_RES_CASE(2, 2)
 #undef MCQ_RES_CASE
-    hipLaunchKernelGGL(k_residual, grid, block, 0, st, x, idx, C, B, N, K, D, Dp, xerr, E, R, nact, map);
+    hipLaunchKernelGGL(k_residual, grid, block, 0, st, x, idx, C, B, N, K, D, Dp, xerr, E, R, nact, map, xh);
     MCQ_LAUNCH_CHECK();
     return 0;
 }
@@ -307,7 +308,8 @@ int run_encode(const float *x, long B, const void *prepared, float lscale, int N
     for (long lo = 0; lo < B; lo += chunk) {
         const long Bc = (B - lo < chunk) ? (B - lo) : chunk;
         const Workspace w = carve(workspace, Bc, N, K, Dp);
-        const float *xc = x + lo * D;
+        const int xh = (flags & MCQ_ENCODE_X_FP16) ? 1 : 0;   // rows of 2-byte elements
+        const float *xc = xh ? reinterpret_cast<const float *>(reinterpret_cast<const uint16_t *>(x) + lo * D) : x + lo * D;
         int rc;
         if (init_idx != nullptr) {
             hipLaunchKernelGGL(k_import_indexes, dim3((unsigned)((Bc * N + 255) / 256)), dim3(256), 0, st,
@@ -317,7 +319,7 @@ int run_encode(const float *x, long B, const void *prepared, float lscale, int N
             if (prof) prof->begin();
             rc = launch_gemm<MODE_LOGITS>(K, P.W, xc, nullptr, lscale, P.bias, nullptr, nullptr, Bc, N, D, Dp, w.idx,
                                           nullptr, st, 0, nullptr,
-                                          (flags & MCQ_ENCODE_LSCALE_FROM_PREPARED) ? P.scales + 1 : nullptr);
+                                          (flags & MCQ_ENCODE_LSCALE_FROM_PREPARED) ? P.scales + 1 : nullptr, xh);
             if (rc) return rc;
             if (prof) prof->end(CAT_LOGITS);
         }
@@ -331,7 +333,7 @@ int run_encode(const float *x, long B, const void *prepared, float lscale, int N
         }
         for (int it = 0; it < iters; ++it) {
             if (prof) prof->begin();
-            rc = launch_residual(xc, idx_cur, P.C, Bc, N, K, D, Dp, w.xerr, w.E, w.R, st, nact, map_cur);
+            rc = launch_residual(xc, idx_cur, P.C, Bc, N, K, D, Dp, w.xerr, w.E, w.R, st, nact, map_cur, xh);
             if (rc) return rc;
             if (prof) { prof->end(CAT_RESIDUAL); prof->begin(); }
             if (fused_select(N, K)) {

@@ -105,6 +105,12 @@ __device__ __forceinline__ void wave_select(const float (&v)[VPL], const int (&p
 // integer order of the keys equals (value, position) order.
 typedef unsigned long long u64;
 constexpr u64 kKeyMax = ~0ull;
+// fp16 ingestion (MCQ_ENCODE_X_FP16): x rows are _Float16 in HBM and widen to fp32 in the load path;
+// every fp16 value is exactly representable, so the codes equal those of the widened input.
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 load_h4(const void *p) {
+    return __builtin_convertvector(*reinterpret_cast<const f16x4 *>(p), f32x4);
+}
 constexpr int kSelectLdsU64 = 128;  // per-wave LDS scratch of wave_select_fast, in u64
 
 __device__ __forceinline__ uint32_t ord32(float v) {
@@ -280,15 +286,16 @@ __global__ void k_prepare_rows(const float *__restrict__ src, float scale, int a
 __global__ void k_residual(const float *__restrict__ x, const uint8_t *__restrict__ idx,
                            const float *__restrict__ C, long B, int N, int K, int D, int Dp,
                            float *__restrict__ xerr, float *__restrict__ E, float *__restrict__ R,
-                           const int *__restrict__ nact, const int *__restrict__ map) {
+                           const int *__restrict__ nact, const int *__restrict__ map, int xh /* x is fp16 */) {
     const long b = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (nact) B = *nact;
     if (b >= B) return;
     const int lane = lane_id();
     const uint8_t *id = idx + b * N;
     const float *xb = x + (map ? (long)map[b] : b) * D;
+    const _Float16 *xbh = reinterpret_cast<const _Float16 *>(x) + (map ? (long)map[b] : b) * D;
     float *xe = xerr + b * Dp;
-    const bool vec_ok = ((D & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+    const bool vec_ok = ((D & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & (xh ? 7 : 15)) == 0);
     float pe = 0.f;
     for (int q = lane; q < Dp / 4; q += 64) {
         f32x4 t = *reinterpret_cast<const f32x4 *>(C + ((long)id[0]) * Dp + 4 * q);
@@ -296,10 +303,14 @@ __global__ void k_residual(const float *__restrict__ x, const uint8_t *__restric
             t = t + *reinterpret_cast<const f32x4 *>(C + ((long)n * K + id[n]) * Dp + 4 * q);
         f32x4 xv;
         if (vec_ok && 4 * q + 3 < D) {
-            xv = *reinterpret_cast<const f32x4 *>(xb + 4 * q);
+            xv = xh ? load_h4(xbh + 4 * q) : *reinterpret_cast<const f32x4 *>(xb + 4 * q);
         } else {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) xv[c] = (4 * q + c < D) ? xb[4 * q + c] : 0.f;
+            for (int c = 0; c < 4; ++c) {
+                const int kc = (4 * q + c < D) ? 4 * q + c : 0;
+                const float val = xh ? (float)xbh[kc] : xb[kc];
+                xv[c] = (4 * q + c < D) ? val : 0.f;
+            }
         }
         t = t - xv;
         *reinterpret_cast<f32x4 *>(xe + 4 * q) = t;
@@ -329,15 +340,16 @@ template <int NN, int J>
 __global__ void k_residual_reg(const float *__restrict__ x, const uint8_t *__restrict__ idx,
                                const float *__restrict__ C, long B, int K, int D, int Dp,
                                float *__restrict__ xerr, float *__restrict__ E, float *__restrict__ R,
-                               const int *__restrict__ nact, const int *__restrict__ map) {
+                               const int *__restrict__ nact, const int *__restrict__ map, int xh /* x is fp16 */) {
     const long b = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (nact) B = *nact;
     if (b >= B) return;
     const int lane = lane_id();
     const uint8_t *id = idx + b * NN;
     const float *xb = x + (map ? (long)map[b] : b) * D;
+    const _Float16 *xbh = reinterpret_cast<const _Float16 *>(x) + (map ? (long)map[b] : b) * D;
     float *xe = xerr + b * Dp;
-    const bool vec_ok = ((D & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+    const bool vec_ok = ((D & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & (xh ? 7 : 15)) == 0);
     const int nq = Dp / 4;
     f32x4 rows[NN][J];
 #pragma unroll
@@ -360,10 +372,14 @@ __global__ void k_residual_reg(const float *__restrict__ x, const uint8_t *__res
         f32x4 xv = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (q < nq) {
             if (vec_ok && 4 * q + 3 < D) {
-                xv = *reinterpret_cast<const f32x4 *>(xb + 4 * q);
+                xv = xh ? load_h4(xbh + 4 * q) : *reinterpret_cast<const f32x4 *>(xb + 4 * q);
             } else {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) xv[c] = (4 * q + c < D) ? xb[4 * q + c] : 0.f;
+                for (int c = 0; c < 4; ++c) {
+                    const int kc = (4 * q + c < D) ? 4 * q + c : 0;
+                    const float val = xh ? (float)xbh[kc] : xb[kc];
+                    xv[c] = (4 * q + c < D) ? val : 0.f;
+                }
             }
         }
         t = t - xv;
@@ -424,7 +440,8 @@ k_gemm(const float *__restrict__ Bm /*[N][K][Dp]*/, const float *__restrict__ xi
        const uint8_t *__restrict__ idx_in, float lscale, const float *__restrict__ bias,
        const float *__restrict__ Rin, const float *__restrict__ Qin, long B, int N, int D, int Dp,
        uint8_t *__restrict__ idx_out, float *__restrict__ out, int /*keep: k_gemm8s only*/,
-       const int *__restrict__ nact, const float *__restrict__ lscale_ptr /* overrides lscale when non-null */) {
+       const int *__restrict__ nact, const float *__restrict__ lscale_ptr /* overrides lscale when non-null */,
+       int xh /* logits modes: x is fp16 */) {
     constexpr int K = 16 * T;
     if (nact) B = *nact;
     if (lscale_ptr) lscale = *lscale_ptr;
@@ -458,7 +475,9 @@ k_gemm(const float *__restrict__ Bm /*[N][K][Dp]*/, const float *__restrict__ xi
         if (MODE == MODE_STAGE0) oldrow[s] = Bm + ((long)n * K + idx_in[brow[s] * N + n]) * Dp;
     }
     // the x rows of the logits pass are unpadded: vector loads only when D is already a multiple of 16
-    const bool fast = (MODE == MODE_STAGE0) || (x_vec && D == Dp);
+    const bool fast = (MODE == MODE_STAGE0) || (x_vec && D == Dp && !xh);
+    const _Float16 *xin_h = reinterpret_cast<const _Float16 *>(xin);
+    const bool fast_h = (MODE != MODE_STAGE0) && xh && D == Dp && ((reinterpret_cast<uintptr_t>(xin) & 7) == 0);
 
     f32x4 acc[T];
 #pragma unroll
@@ -489,14 +508,26 @@ k_gemm(const float *__restrict__ Bm /*[N][K][Dp]*/, const float *__restrict__ xi
                 stB[s] = *reinterpret_cast<const f32x4 *>(xin + brow[s] * xstride + k);
                 if (MODE == MODE_STAGE0) stO[s] = *reinterpret_cast<const f32x4 *>(oldrow[s] + k);
             }
+        } else if (fast_h) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                int k = k0 + 4 * ((tid + 256 * s) & 7);
+                k = k < Dp ? k : Dp - 4;
+                stB[s] = load_h4(xin_h + brow[s] * xstride + k);
+            }
         } else {
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const int k = k0 + 4 * ((tid + 256 * s) & 7);
                 const float *xr = xin + brow[s] * xstride;
+                const _Float16 *xrh = xin_h + brow[s] * xstride;
                 f32x4 v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = (k + e < xstride) ? xr[k + e] : 0.f;
+                for (int e = 0; e < 4; ++e) {
+                    const int ke = (k + e < xstride) ? k + e : 0;
+                    const float val = xh ? (float)xrh[ke] : xr[ke];
+                    v[e] = (k + e < xstride) ? val : 0.f;
+                }
                 stB[s] = v;
             }
         }
@@ -601,7 +632,7 @@ k_gemm8s(const float *__restrict__ Bm, const float *__restrict__ xin, const uint
          float lscale, const float *__restrict__ bias, const float *__restrict__ Rin,
          const float *__restrict__ Qin, long B, int N, int D, int Dp, uint8_t *__restrict__ idx_out,
          float *__restrict__ out, int keep, const int *__restrict__ nact,
-         const float *__restrict__ lscale_ptr /* overrides lscale when non-null */) {
+         const float *__restrict__ lscale_ptr /* overrides lscale when non-null */, int xh /* logits modes: x is fp16 */) {
     constexpr bool IS0 = (MODE == MODE_STAGE0) || (MODE == MODE_STAGE0_SEL);
     if (nact) B = *nact;
     if (lscale_ptr) lscale = *lscale_ptr;
@@ -626,13 +657,15 @@ k_gemm8s(const float *__restrict__ Bm, const float *__restrict__ xin, const uint
     const float *Bn = Bm + (long)n * K * Dp;
     const int xstride = IS0 ? Dp : D;
     const bool x_vec = IS0 || (((D & 3) == 0) && ((reinterpret_cast<uintptr_t>(xin) & 15) == 0));
-    const bool fast = IS0 || (x_vec && D == Dp);
+    const bool fast = IS0 || (x_vec && D == Dp && !xh);
+    const bool fast_h = !IS0 && xh && D == Dp && ((reinterpret_cast<uintptr_t>(xin) & 7) == 0);
 
     // staging: unit f -> (row = f / 4, g = f % 4); threads 0..255 also stage the vector tile
     const bool has_b = tid < B_UNITS;
     long browl = b0 + ((tid & (B_UNITS - 1)) >> 2);
     browl = browl < B ? browl : B - 1;
     const float *xbase = xin + b0 * xstride;
+    const _Float16 *xbase_h = reinterpret_cast<const _Float16 *>(xin) + b0 * xstride;
     const uint32_t xoff = (uint32_t)((browl - b0) * xstride) + 4 * (tid & 3);
     uint32_t ooff = 0;
     if (IS0) ooff = (uint32_t)(((long)n * K + idx_in[browl * N + n]) * Dp) + 4 * (tid & 3);
@@ -658,11 +691,18 @@ k_gemm8s(const float *__restrict__ Bm, const float *__restrict__ xin, const uint
             if (fast) {
                 stB = *reinterpret_cast<const f32x4 *>(xbase + (xoff + k));
                 if (IS0) stO = *reinterpret_cast<const f32x4 *>(Bm + (ooff + k));
+            } else if (fast_h) {
+                stB = load_h4(xbase_h + (xoff + k));
             } else {
                 const int kk = 16 * kb + 4 * (tid & 3);
                 const float *xr = xbase + (xoff - 4 * (tid & 3));
+                const _Float16 *xrh = xbase_h + (xoff - 4 * (tid & 3));
 #pragma unroll
-                for (int e = 0; e < 4; ++e) stB[e] = (kk + e < xstride) ? xr[kk + e] : 0.f;
+                for (int e = 0; e < 4; ++e) {
+                    const int ke = (kk + e < xstride) ? kk + e : 0;
+                    const float val = xh ? (float)xrh[ke] : xr[ke];
+                    stB[e] = (kk + e < xstride) ? val : 0.f;
+                }
             }
         }
     };
@@ -881,6 +921,12 @@ struct DeltaBuilder {
     }
 };
 
+#ifndef MCQ_PAIR_UNR1
+#define MCQ_PAIR_UNR1 2   // same, single-leaf 16x16 stage
+#endif
+#ifndef MCQ_PAIR_UNR
+#define MCQ_PAIR_UNR 2   // k-blocks per software-pipeline batch x leaves (4: deeper prefetch, one wave per SIMD fewer)
+#endif
 template <int L, int KI, bool XL = false, int ABL = 0>
 __global__ void __launch_bounds__(256)
 k_pair(const float *__restrict__ C, const uint8_t *__restrict__ idx, const float *__restrict__ E,
@@ -1064,7 +1110,7 @@ k_pair(const float *__restrict__ C, const uint8_t *__restrict__ idx, const float
     };
 
     constexpr bool PIPE = (L * TI) <= 2;
-    constexpr int UNR = PIPE ? 4 / (L * TI) : 1;
+    constexpr int UNR = PIPE ? (L * TI == 1 ? MCQ_PAIR_UNR1 : MCQ_PAIR_UNR / (L * TI)) : 1;
 
     for (int w0 = 0; w0 < (ABL == 1 ? 0 : Dp); w0 += win) {
         const int wlen = (Dp - w0 < win) ? (Dp - w0) : win;

@@ -151,7 +151,10 @@ class Quantizer(nn.Module):
                                 "(no CPU fallback)")
         L = _lib.lib()
         N, K, D = self.num_codebooks, self.codebook_size, self.dim
-        x2d = x2d.detach().to(torch.float32).contiguous()
+        # fp16 frames (what the reference's read_hdf5_data yields, quantization.py:798) are consumed as they
+        # are: the kernels widen them in the load path (MCQ_ENCODE_X_FP16), same codes as for x.float()
+        x_fp16 = x2d.dtype == torch.float16
+        x2d = x2d.detach().contiguous() if x_fp16 else x2d.detach().to(torch.float32).contiguous()
         B = x2d.shape[0]
         dev = x2d.device
         blob = self._prepared()
@@ -168,7 +171,8 @@ class Quantizer(nn.Module):
             rc = L.mcq_encode_ex(x2d.data_ptr(), B, blob.data_ptr(), self._lscale_exp, N, K, D, int(iters),
                                  out.data_ptr() if as_bytes else None, None if as_bytes else out.data_ptr(),
                                  ws.data_ptr(), ws.numel(), st,
-                                 (1 if getattr(self, "skip_fixed_points", False) else 0) | self._scale_flags)
+                                 (1 if getattr(self, "skip_fixed_points", False) else 0) | self._scale_flags |
+                                 (4 if x_fp16 else 0))
         _lib.check(rc, "mcq_encode")
         return out
 
@@ -192,7 +196,9 @@ class Quantizer(nn.Module):
         dev = self.centers.device
         if dev.type != "cuda":
             raise _lib.McqError("quantization_amd.Quantizer runs on a HIP device only")
-        x2d = x.reshape(-1, self.dim).to(torch.float32)
+        x2d = x.reshape(-1, self.dim)
+        if x2d.dtype != torch.float16:       # fp16 frames cross PCIe as they are (half the bytes)
+            x2d = x2d.to(torch.float32)
         if not x2d.is_pinned():
             x2d = x2d.contiguous().pin_memory()
         B = x2d.shape[0]
@@ -202,8 +208,8 @@ class Quantizer(nn.Module):
         compute = torch.cuda.current_stream(dev)
         rows = min(chunk, max(B, 1))
         stage = getattr(self, "_host_stage", None)
-        if stage is None or stage[0].device != dev or stage[0].shape[1] < rows:
-            stage = (torch.empty((2, rows, self.dim), dtype=torch.float32, device=dev), torch.cuda.Stream(dev))
+        if stage is None or stage[0].device != dev or stage[0].shape[1] < rows or stage[0].dtype != x2d.dtype:
+            stage = (torch.empty((2, rows, self.dim), dtype=x2d.dtype, device=dev), torch.cuda.Stream(dev))
             self._host_stage = stage
         bufs, copy = [stage[0][0], stage[0][1]], stage[1]
         copy.wait_stream(compute)       # earlier users of the staging buffers are done

@@ -306,3 +306,22 @@ def test_encode_and_decode_are_hip_graph_capturable():
     torch.cuda.synchronize()
     assert torch.equal(static_codes, q.encode(x_all[1024:2048], 5))
     assert torch.equal(static_y, q.decode(static_codes))
+
+
+@pytest.mark.parametrize("name", ["trained_d64_b8_p2", "trained_d64_b4_p1", "synth_d30_k32_n4", "config_b_d512_n8"])
+def test_fp16_frames_are_widened_in_the_load_path(name):
+    """MCQ_ENCODE_X_FP16: fp16 input gives exactly the codes of the same values widened to fp32 (oracle-checked),
+    on aligned and unaligned (D % 4 != 0) rows, with and without fixed-point skipping, from host memory too"""
+    fx = fixtures.load(name)
+    q = load_quantizer(fx["state"], fx["D"], fx["K"], fx["N"])
+    xh = torch.from_numpy(fx["x"][:1000]).to(torch.float16)
+    oq = OracleQuantizer.from_state_dict(fx["state"])
+    want = oq.compute_indexes(xh.float().numpy(), 5)
+    got = q.encode(xh.cuda(), 5, as_bytes=False)
+    assert np.array_equal(got.cpu().numpy(), want)
+    assert torch.equal(got, q.encode(xh.cuda().float(), 5, as_bytes=False))
+    assert torch.equal(q.encode(xh.cuda()[1:], 5, as_bytes=False), got[1:])      # rows at an odd 2-byte offset
+    q.skip_fixed_points = True
+    assert torch.equal(q.encode(xh.cuda(), 5, as_bytes=False), got)
+    q.skip_fixed_points = False
+    assert torch.equal(q.encode_from_host(xh, 5, as_bytes=False, chunk=300).cuda(), got)
