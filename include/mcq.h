@@ -38,7 +38,7 @@ extern "C" {
 #define MCQ_EUNSUPPORTED (-2) /* outside the supported (K, N) domain             */
 #define MCQ_EWORKSPACE (-3) /* workspace smaller than mcq_encode_workspace_bytes */
 
-#define MCQ_ABI_VERSION 1
+#define MCQ_ABI_VERSION 2
 int mcq_abi_version(void);
 
 /* D rounded up to the padded row length used inside `prepared` and workspaces. */
@@ -114,6 +114,38 @@ int mcq_decode(const void *codes, int code_bytes, int codes_per_row, long B, con
  * grad_out: fp32 [B][D]; gC: fp32 [N][K][D], fully overwritten.                                */
 int mcq_decode_backward(const float *grad_out, const int64_t *idx, long B, int N, int K, int D, float *gC,
                         void *stream);
+
+/* ---- trainer pieces ------------------------------------------------------------
+ * What QuantizerTrainer.step (:641-719) runs besides the index search: the loss of
+ * Quantizer.compute_loss (:211-242) as batch SUMS (the caller forms the means and ratios, and in
+ * data-parallel training all-reduces the sums first) and its gradient.  Every reduction has a
+ * fixed order: results are bit-reproducible.
+ *
+ * mcq_logits_argmax: logits fp32 [B][N*K] of Quantizer._logits (:277-279) AND their per-codebook
+ * first-maximum argmax int64 [B][N] (:301) from one GEMM; the indexes then go through
+ * mcq_refine_indexes.  workspace >= B*N bytes.  flags: MCQ_ENCODE_LSCALE_FROM_PREPARED, MCQ_ENCODE_X_FP16. */
+int mcq_logits_argmax(const float *x, long B, const void *prepared, float lscale_exp, int N, int K, int D,
+                      float *logits_out, int64_t *argmax_out, void *workspace, size_t workspace_bytes,
+                      void *stream, unsigned flags);
+
+/* Log-softmax statistics of logits [B][N*K] against indexes int64 [B][N] (:221-240):
+ *   lse[b][n] = logsumexp_k;  chosen_sum[n] = sum_b (logit[b][n][idx] - lse);
+ *   prob_sum[n][k] = sum_b softmax;  count[n][k] = #{b: idx[b][n] == k}.                       */
+size_t mcq_loss_workspace_bytes(long B, int N, int K);
+int mcq_loss_fwd(const float *logits, const int64_t *idx, long B, int N, int K, float *lse, float *chosen_sum,
+                 float *prob_sum, float *count, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Gradient w.r.t. the logits of  g_chosen * sum_n chosen_sum[n] + sum_{n,k} g_prob[n][k] * prob_sum[n][k];
+ * g_chosen (float[1]) and g_prob (float[N][K]) are DEVICE pointers (no host copy of upstream gradients). */
+int mcq_loss_bwd(const float *logits, const int64_t *idx, const float *lse, long B, int N, int K,
+                 const float *g_chosen, const float *g_prob, float *grad_logits, void *stream);
+
+/* Reconstruction pieces (:213-217): err[b] = decode(idx[b]) - x[b] (fp32 [B][D]); partial sums over
+ * groups of 4 vectors of err^2 (num_part) and (x - mean)^2 (den_part), float[(B + 3) / 4] each, to be
+ * summed by the caller; mean = get_data_mean() (:67-75), float[D].  d(sum err^2)/d(centers) is
+ * 2 * mcq_decode_backward(err).                                                                   */
+int mcq_recon_fwd(const float *x, const int64_t *idx, long B, const void *prepared, const float *mean, int N,
+                  int K, int D, float *err, float *num_part, float *den_part, void *stream);
 
 /* ---- test / profiling hooks -------------------------------------------------
  * Logits of Quantizer._logits (:277-279) for a batch, fp32 [B][N*K]; used by the

@@ -2,6 +2,7 @@
 // Host side only enqueues kernels on the caller's stream; see mcq.h for the contract.
 #include "../../include/mcq.h"
 #include "mcq_kernels.h"
+#include "mcq_loss_kernels.h"
 
 #include <cstdlib>
 #include <vector>
@@ -527,6 +528,100 @@ int mcq_logits(const float *x, long B, const void *prepared, float lscale_exp, i
     const Prepared P = prepared_view(prepared, N, K, D);
     return launch_gemm<MODE_LOGITS_OUT>(K, P.W, x, nullptr, lscale_exp, P.bias, nullptr, nullptr, B, N, D,
                                         round_up16(D), nullptr, out, static_cast<hipStream_t>(stream));
+}
+
+// ------------------------------------------------------------------ trainer pieces
+int mcq_logits_argmax(const float *x, long B, const void *prepared, float lscale_exp, int N, int K, int D,
+                      float *logits_out, int64_t *argmax_out, void *workspace, size_t workspace_bytes, void *stream,
+                      unsigned flags) {
+    if (!domain_ok(N, K, D)) return MCQ_EUNSUPPORTED;
+    if (B < 0) return MCQ_EINVAL;
+    if (B == 0) return 0;
+    if (!x || !prepared || !logits_out || !argmax_out || !workspace) return MCQ_EINVAL;
+    if (workspace_bytes < (size_t)B * N) return MCQ_EWORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const Prepared P = prepared_view(prepared, N, K, D);
+    uint8_t *idx8 = static_cast<uint8_t *>(workspace);
+    int rc = launch_gemm<MODE_LOGITS_OUT>(K, P.W, x, nullptr, lscale_exp, P.bias, nullptr, nullptr, B, N, D, round_up16(D),
+                                          idx8, logits_out, st, 0, nullptr,
+                                          (flags & MCQ_ENCODE_LSCALE_FROM_PREPARED) ? P.scales + 1 : nullptr,
+                                          (flags & MCQ_ENCODE_X_FP16) ? 1 : 0);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_export_indexes, dim3((unsigned)((B * N + 255) / 256)), dim3(256), 0, st, idx8, B * N, argmax_out);
+    MCQ_LAUNCH_CHECK();
+    return 0;
+}
+
+namespace {
+long loss_rows_per_chunk(long B) {   // at most ~1024 chunks, at least 64 rows each
+    long r = (B + 1023) / 1024;
+    r = r < 64 ? 64 : r;
+    return (r + 15) / 16 * 16;
+}
+long loss_chunks(long B) { const long r = loss_rows_per_chunk(B); return (B + r - 1) / r; }
+}  // namespace
+
+size_t mcq_loss_workspace_bytes(long B, int N, int K) {
+    if (B <= 0) return 256;
+    return (size_t)loss_chunks(B) * N * (2 * (size_t)K + 1) * sizeof(float) + 256;
+}
+
+int mcq_loss_fwd(const float *logits, const int64_t *idx, long B, int N, int K, float *lse, float *chosen_sum,
+                 float *prob_sum, float *count, void *workspace, size_t workspace_bytes, void *stream) {
+    if (!is_pow2(K) || K < 16 || K > 256 || N < 1) return MCQ_EUNSUPPORTED;
+    if (B <= 0) return MCQ_EINVAL;
+    if (!logits || !idx || !lse || !chosen_sum || !prob_sum || !count || !workspace) return MCQ_EINVAL;
+    if (workspace_bytes < mcq_loss_workspace_bytes(B, N, K)) return MCQ_EWORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const long rpc = loss_rows_per_chunk(B), chunks = loss_chunks(B);
+    float *pp = static_cast<float *>(workspace);
+    float *pc = pp + chunks * N * K;
+    float *ph = pc + chunks * N * K;
+    const dim3 grid((unsigned)(chunks * N)), block(64 * kLossWaves);
+#define MCQ_LOSS_CASE(KK)                                                                                             \
+    case KK: hipLaunchKernelGGL((k_loss_fwd<KK>), grid, block, 0, st, logits, idx, B, N, rpc, lse, pp, pc, ph); break;
+    switch (K) {
+        MCQ_LOSS_CASE(16) MCQ_LOSS_CASE(32) MCQ_LOSS_CASE(64) MCQ_LOSS_CASE(128) MCQ_LOSS_CASE(256)
+        default: return MCQ_EUNSUPPORTED;
+    }
+#undef MCQ_LOSS_CASE
+    MCQ_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_loss_reduce, dim3((unsigned)N), dim3(256), 0, st, pp, pc, ph, chunks, N, K, prob_sum, count,
+                       chosen_sum);
+    MCQ_LAUNCH_CHECK();
+    return 0;
+}
+
+int mcq_loss_bwd(const float *logits, const int64_t *idx, const float *lse, long B, int N, int K, const float *g_chosen,
+                 const float *g_prob, float *grad_logits, void *stream) {
+    if (!is_pow2(K) || K < 16 || K > 256 || N < 1) return MCQ_EUNSUPPORTED;
+    if (B <= 0) return MCQ_EINVAL;
+    if (!logits || !idx || !lse || !g_chosen || !g_prob || !grad_logits) return MCQ_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int rpw = K < 64 ? 64 / K : 1;
+    const long rows = B * N;
+    const dim3 grid((unsigned)((rows + (long)kLossWaves * rpw - 1) / ((long)kLossWaves * rpw))), block(64 * kLossWaves);
+#define MCQ_LOSS_CASE(KK)                                                                                             \
+    case KK: hipLaunchKernelGGL((k_loss_bwd<KK>), grid, block, 0, st, logits, idx, lse, B, N, g_chosen, g_prob, grad_logits); break;
+    switch (K) {
+        MCQ_LOSS_CASE(16) MCQ_LOSS_CASE(32) MCQ_LOSS_CASE(64) MCQ_LOSS_CASE(128) MCQ_LOSS_CASE(256)
+        default: return MCQ_EUNSUPPORTED;
+    }
+#undef MCQ_LOSS_CASE
+    MCQ_LAUNCH_CHECK();
+    return 0;
+}
+
+int mcq_recon_fwd(const float *x, const int64_t *idx, long B, const void *prepared, const float *mean, int N, int K,
+                  int D, float *err, float *num_part, float *den_part, void *stream) {
+    if (!domain_ok(N, K, D)) return MCQ_EUNSUPPORTED;
+    if (B <= 0) return MCQ_EINVAL;
+    if (!x || !idx || !prepared || !mean || !err || !num_part || !den_part) return MCQ_EINVAL;
+    const Prepared P = prepared_view(prepared, N, K, D);
+    hipLaunchKernelGGL(k_recon_fwd, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), x, idx, B,
+                       P.C, mean, N, K, D, round_up16(D), err, num_part, den_part);
+    MCQ_LAUNCH_CHECK();
+    return 0;
 }
 
 int mcq_last_encode_launches(void) { return g_last_launches; }

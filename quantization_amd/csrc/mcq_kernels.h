@@ -596,7 +596,7 @@ k_gemm(const float *__restrict__ Bm /*[N][K][Dp]*/, const float *__restrict__ xi
             if (MODE == MODE_LOGITS_OUT && b < B)
                 *reinterpret_cast<f32x4 *>(out + (b * N + n) * (long)K + 16 * t + 4 * g) = lv;
         }
-        if (MODE == MODE_LOGITS) {
+        if (MODE == MODE_LOGITS || (MODE == MODE_LOGITS_OUT && idx_out != nullptr)) {
             // combine the 4 lanes of this vector: first maximum = greatest value, lowest k on ties
 #pragma unroll
             for (int m = 16; m <= 32; m <<= 1) {
@@ -827,7 +827,7 @@ k_gemm8s(const float *__restrict__ Bm, const float *__restrict__ xin, const uint
             }
             if (MODE == MODE_LOGITS_OUT && b < B) *reinterpret_cast<f32x4 *>(out + (b * N + n) * (long)K + k0) = lv;
         }
-        if (MODE == MODE_LOGITS) {
+        if (MODE == MODE_LOGITS || (MODE == MODE_LOGITS_OUT && idx_out != nullptr)) {
 #pragma unroll
             for (int m = 16; m <= 32; m <<= 1) {
                 const float ov = __shfl_xor(best, m, 64);

@@ -1,0 +1,221 @@
+// mcq_loss_kernels.h -- HIP kernels (gfx950) for the loss of Quantizer.compute_loss
+// (quantization/quantization.py:211-242) and its gradient: what QuantizerTrainer.step (:641-719)
+// runs besides the index search.  All batch reductions are two-stage with a fixed order
+// (no float atomics): results are bit-reproducible run to run.
+//
+//   logprobs  lp[b][n][k] = z[b][n][k] - lse[b][n]                    (log_softmax, :223)
+//   chosen    Sum_b lp[b][n][idx[b][n]]                                (:225-227, before the mean)
+//   prob_sum  Sum_b exp(lp[b][n][k])                                   (:238, before the mean)
+//   count     #{b : idx[b][n] == k}                                    (:231-234, before the mean)
+//   recon     err = decode(idx) - x,  Sum err^2,  Sum (x - mean)^2     (:213-217)
+#pragma once
+#include "mcq_kernels.h"
+
+namespace mcq {
+
+constexpr int kLossWaves = 4;   // waves per workgroup of the loss kernels
+
+// Lanes of one logits row: KL = min(K, 64) lanes hold VPL = K / KL values each (k = lane_in_row + KL * i);
+// a wave works on RPW = 64 / KL rows at a time.  Reductions stay inside the row's lane group.
+template <int KL>
+__device__ __forceinline__ float row_max(float v) {
+#pragma unroll
+    for (int m = KL / 2; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+    return v;
+}
+template <int KL>
+__device__ __forceinline__ float row_sum(float v) {
+#pragma unroll
+    for (int m = KL / 2; m >= 1; m >>= 1) v = v + __shfl_xor(v, m, 64);
+    return v;
+}
+
+// Forward statistics.  Workgroup (n, chunk): kLossWaves waves share the rows b in
+// [chunk * rows_per_chunk, +rows_per_chunk) of codebook n.  Outputs per (chunk, n): partial prob sums and
+// counts [K], partial chosen sum; per row: lse.
+template <int K>
+__global__ void __launch_bounds__(64 * kLossWaves)
+k_loss_fwd(const float *__restrict__ logits, const int64_t *__restrict__ idx, long B, int N, long rows_per_chunk,
+           float *__restrict__ lse_out /*[B][N]*/, float *__restrict__ part_prob /*[chunks][N][K]*/,
+           float *__restrict__ part_count /*[chunks][N][K]*/, float *__restrict__ part_chosen /*[chunks][N]*/) {
+    constexpr int KL = K < 64 ? K : 64, VPL = K / KL, RPW = 64 / KL;
+    __shared__ float s_prob[kLossWaves * RPW][K];
+    __shared__ int s_count[K];
+    __shared__ float s_chosen[kLossWaves];
+    const int n = blockIdx.x % N;
+    const long chunk = blockIdx.x / N;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int sub = lane / KL, kl = lane % KL;
+    for (int k = tid; k < K; k += blockDim.x) s_count[k] = 0;
+    __syncthreads();
+    const long b_lo = chunk * rows_per_chunk;
+    const long b_hi = (b_lo + rows_per_chunk < B) ? b_lo + rows_per_chunk : B;
+    float acc[VPL];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) acc[i] = 0.f;
+    float chosen = 0.f;
+    for (long b0 = b_lo + (long)wave * RPW; b0 < b_hi; b0 += (long)kLossWaves * RPW) {
+        const long b = b0 + sub;
+        const bool ok = b < b_hi;
+        const long bc = ok ? b : b_hi - 1;
+        const float *z = logits + (bc * N + n) * (long)K;
+        float v[VPL];
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) v[i] = z[kl + KL * i];
+        float mx = v[0];
+#pragma unroll
+        for (int i = 1; i < VPL; ++i) mx = fmaxf(mx, v[i]);
+        mx = row_max<KL>(mx);
+        float se = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) se += expf(v[i] - mx);
+        se = row_sum<KL>(se);
+        const float lse = mx + logf(se);
+        const int ki = (int)idx[bc * N + n];
+        if (ok) {
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) {
+                const float lp = v[i] - lse;
+                acc[i] += expf(lp);
+                if (kl + KL * i == ki) chosen += lp;
+            }
+            if (kl == 0) {
+                lse_out[b * N + n] = lse;
+                atomicAdd(&s_count[ki & (K - 1)], 1);   // integer: order-independent
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) s_prob[wave * RPW + sub][kl + KL * i] = acc[i];
+    chosen = wave_sum_butterfly(chosen);
+    if (lane == 0) s_chosen[wave] = chosen;
+    __syncthreads();
+    const long o = (chunk * N + n) * (long)K;
+    for (int k = tid; k < K; k += blockDim.x) {
+        float p = s_prob[0][k];
+#pragma unroll
+        for (int j = 1; j < kLossWaves * RPW; ++j) p += s_prob[j][k];
+        part_prob[o + k] = p;
+        part_count[o + k] = (float)s_count[k];
+    }
+    if (tid == 0) {
+        float c = s_chosen[0];
+#pragma unroll
+        for (int w = 1; w < kLossWaves; ++w) c += s_chosen[w];
+        part_chosen[chunk * N + n] = c;
+    }
+}
+
+// Second stage: chunk partials -> sums, chunks ascending.  One workgroup per codebook.
+__global__ void k_loss_reduce(const float *__restrict__ part_prob, const float *__restrict__ part_count,
+                              const float *__restrict__ part_chosen, long chunks, int N, int K,
+                              float *__restrict__ prob_sum /*[N][K]*/, float *__restrict__ count /*[N][K]*/,
+                              float *__restrict__ chosen_sum /*[N]*/) {
+    const int n = blockIdx.x;
+    constexpr int U = 16;   // loads in flight; the additions stay in chunk order
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        float p = 0.f, c = 0.f;
+        for (long c0 = 0; c0 < chunks; c0 += U) {
+            float tp[U], tc[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const long ch = (c0 + u < chunks) ? c0 + u : chunks - 1;
+                tp[u] = part_prob[(ch * N + n) * (long)K + k];
+                tc[u] = part_count[(ch * N + n) * (long)K + k];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (c0 + u < chunks) { p += tp[u]; c += tc[u]; }
+        }
+        prob_sum[n * K + k] = p;
+        count[n * K + k] = c;
+    }
+    if (threadIdx.x == blockDim.x - 1) {
+        float s = 0.f;
+        for (long c0 = 0; c0 < chunks; c0 += U) {
+            float t[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) t[u] = part_chosen[((c0 + u < chunks) ? c0 + u : chunks - 1) * N + n];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (c0 + u < chunks) s += t[u];
+        }
+        chosen_sum[n] = s;
+    }
+}
+
+// Gradient w.r.t. the logits of  L = g_chosen * chosen + Sum_{n,k} g_prob[n][k] * prob_sum[n][k]:
+//   dL/dz[b][n][k] = g_chosen * (delta(k, idx) - p) + p * (g_prob[n][k] - Sum_j p_j g_prob[n][j]),  p = exp(z - lse)
+template <int K>
+__global__ void __launch_bounds__(64 * kLossWaves)
+k_loss_bwd(const float *__restrict__ logits, const int64_t *__restrict__ idx, const float *__restrict__ lse_in,
+           long B, int N, const float *__restrict__ g_chosen /*[1]*/, const float *__restrict__ g_prob /*[N][K]*/,
+           float *__restrict__ grad /*[B][N][K]*/) {
+    constexpr int KL = K < 64 ? K : 64, VPL = K / KL, RPW = 64 / KL;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane / KL, kl = lane % KL;
+    const long row = ((long)blockIdx.x * kLossWaves + wave) * RPW + sub;   // row = b * N + n
+    const bool ok = row < B * N;
+    const long rc = ok ? row : B * N - 1;
+    const int n = (int)(rc % N);
+    const float gc = *g_chosen;
+    const float lse = lse_in[rc];
+    const int ki = (int)idx[rc];
+    const float *z = logits + rc * (long)K;
+    float p[VPL], g[VPL], dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        p[i] = expf(z[kl + KL * i] - lse);
+        g[i] = g_prob[n * K + kl + KL * i];
+        dot += p[i] * g[i];
+    }
+    dot = row_sum<KL>(dot);
+    if (ok) {
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const float d = (kl + KL * i == ki) ? 1.f : 0.f;
+            grad[rc * (long)K + kl + KL * i] = gc * (d - p[i]) + p[i] * (g[i] - dot);
+        }
+    }
+}
+
+// Reconstruction pieces (:213-217): one wave per vector.  err[b] = (Sum_n C[n][idx[b][n]], n ascending) - x[b];
+// per-workgroup partial sums of err^2 and (x - mean)^2 (4 vectors each), summed by the caller in order.
+__global__ void __launch_bounds__(256)
+k_recon_fwd(const float *__restrict__ x, const int64_t *__restrict__ idx, long B, const float *__restrict__ C,
+            const float *__restrict__ mean /*[D]*/, int N, int K, int D, int Dp, float *__restrict__ err /*[B][D]*/,
+            float *__restrict__ num_part, float *__restrict__ den_part) {
+    __shared__ float s_num[4], s_den[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long b = (long)blockIdx.x * 4 + wave;
+    float pn = 0.f, pd = 0.f;
+    if (b < B) {
+        const int64_t *id = idx + b * N;
+        for (int d = lane; d < D; d += 64) {
+            float t = C[((long)0 * K + (int)(id[0] & (K - 1))) * Dp + d];
+            for (int n = 1; n < N; ++n) t = t + C[((long)n * K + (int)(id[n] & (K - 1))) * Dp + d];
+            const float xv = x[b * D + d];
+            const float e = t - xv;
+            err[b * D + d] = e;
+            pn = fmaf(e, e, pn);
+            const float c = xv - mean[d];
+            pd = fmaf(c, c, pd);
+        }
+    }
+    pn = wave_sum_butterfly(pn);
+    pd = wave_sum_butterfly(pd);
+    if (lane == 0) { s_num[wave] = pn; s_den[wave] = pd; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        num_part[blockIdx.x] = ((s_num[0] + s_num[1]) + s_num[2]) + s_num[3];
+        den_part[blockIdx.x] = ((s_den[0] + s_den[1]) + s_den[2]) + s_den[3];
+    }
+}
+
+// uint8 working indexes -> int64 (argmax output of mcq_logits_argmax)
+__global__ void k_export_indexes(const uint8_t *__restrict__ in, long n, int64_t *__restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i];
+}
+
+}  // namespace mcq

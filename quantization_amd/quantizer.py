@@ -331,27 +331,46 @@ class Quantizer(nn.Module):
         return out
 
     # -------------------------------------------------------------- training
+    def _loss_sums(self, x: Tensor, refine_indexes_iters: int):
+        """The batch SUMS every term of compute_loss is made of (quantization.py:211-242):
+        (sum of squared reconstruction error, sum of squared (x - data mean), sum of the chosen log-probs,
+        per-(codebook, entry) sum of softmax probabilities (N, K), per-(codebook, entry) count of chosen
+        indexes (N, K)).  compute_loss forms the means / ratios from them; the data-parallel trainer
+        all-reduces them first.  On a HIP tensor the whole thing is five kernels forward (logits + argmax,
+        refinement, reconstruction, softmax statistics) and a hand-derived backward (_LossSumsFn)."""
+        B = x.shape[0]
+        N, K = self.num_codebooks, self.codebook_size
+        if x.is_cuda and not x.requires_grad and B > 0:
+            self._check_domain()
+            blob = self._prepared()          # here, not inside the Function: autograd mode decides the flavour
+            return _LossSumsFn.apply(self, x, int(refine_indexes_iters), blob, self._lscale_exp, self._scale_flags,
+                                     self.centers, self.centers_scale, self.to_logits.weight, self.to_logits.bias,
+                                     self.logits_scale)[:5]
+        # the same sums with the reference's own torch op sequence (x that requires grad; CPU test harness)
+        indexes = self._compute_indexes(x, refine_indexes_iters)
+        x_approx = self.decode(indexes)
+        num = ((x_approx - x) ** 2).sum()
+        den = ((x - self.get_data_mean()) ** 2).sum()
+        logprobs = self._logits(x).reshape(B, N, K).log_softmax(dim=2)
+        chosen = torch.gather(logprobs, dim=2, index=indexes.unsqueeze(2)).sum()
+        prob_sum = logprobs.exp().sum(dim=0)
+        count = torch.zeros(N, K, device=x.device)
+        count.scatter_add_(1, indexes.t().contiguous(), torch.ones(N, B, device=x.device))
+        return num, den, chosen, prob_sum, count
+
     def compute_loss(self, x: Tensor, refine_indexes_iters: int = 0):
         """(rel_reconstruction_loss, logprob_loss, logits_entropy_loss, index_entropy_loss);
-        quantization.py:184-242.  The (non-differentiable) index search runs in the HIP
-        kernels; the losses are torch autograd ops on the same device."""
+        quantization.py:184-242."""
         x = x.reshape(-1, self.dim)
         B = x.shape[0]
         N, K = self.num_codebooks, self.codebook_size
-        indexes = self._compute_indexes(x, refine_indexes_iters)
-        x_approx = self.decode(indexes)
-        tot_error = x_approx - x
-        rel_reconstruction_loss = (tot_error ** 2).sum() / (((x - self.get_data_mean()) ** 2).sum() + 1.0e-20)
+        num, den, chosen, prob_sum, count = self._loss_sums(x, refine_indexes_iters)
+        rel_reconstruction_loss = num / (den + 1.0e-20)
+        logprob_loss = -chosen / (B * N)
 
-        logprobs = self._logits(x).reshape(B, N, K).log_softmax(dim=2)
-        logprob_loss = -torch.gather(logprobs, dim=2, index=indexes.unsqueeze(2)).mean()
-
-        counts = torch.zeros(B, N, K, device=x.device)
-        counts.scatter_(dim=2, index=indexes.unsqueeze(2), src=torch.ones(1, 1, 1, device=x.device).expand(B, N, K))
-        avg_counts = counts.mean(dim=0) + 1.0e-20
+        avg_counts = count / B + 1.0e-20
         index_entropy = -(avg_counts * avg_counts.log()).sum(dim=1).mean()
-
-        probs = logprobs.exp().mean(dim=0) + 1.0e-20
+        probs = prob_sum / B + 1.0e-20
         logits_entropy = -(probs * probs.log()).sum(dim=1).mean()
         ref_entropy = math.log(K)
         logits_entropy_loss = (ref_entropy - logits_entropy) / ref_entropy
@@ -424,3 +443,85 @@ class _DecodeFn(torch.autograd.Function):
         g_centers = g * scale
         g_scale = (g * centers.detach()).sum() * scale * m.scale_speed
         return None, None, g_centers, g_scale
+
+
+class _LossSumsFn(torch.autograd.Function):
+    """Quantizer._loss_sums on the HIP device.  Forward: mcq_logits_argmax (one GEMM gives the logits AND
+    the initial indexes), mcq_refine_indexes, mcq_recon_fwd, mcq_loss_fwd.  Backward, derived by hand:
+      d num / d(scaled centers) = 2 * scatter-add of err (mcq_decode_backward);
+      d / d logits from mcq_loss_bwd;  logits = s * (x W^T) + b with s = exp(speed * logits_scale), so
+      dW = s * G^T x,  db = sum_b G,  d logits_scale = speed * <G, logits - b>."""
+
+    @staticmethod
+    def forward(ctx, module, x, iters, blob, lscale_exp, flags, centers, centers_scale, weight, bias, logits_scale):
+        L = _lib.lib()
+        N, K, D = module.num_codebooks, module.codebook_size, module.dim
+        x_fp16 = x.dtype == torch.float16
+        xk = x.detach().contiguous() if x_fp16 else x.detach().to(torch.float32).contiguous()
+        B, dev = xk.shape[0], xk.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        logits = torch.empty((B, N * K), **f32)
+        idx = torch.empty((B, N), dtype=torch.int64, device=dev)
+        ws = module._workspace(B, dev)
+        xf = xk.float() if x_fp16 else xk
+        # get_data_mean() (:67-75) from the scaled centers already sitting in the prepared blob
+        Dp = L.mcq_padded_dim(D)
+        C = blob[:N * K * Dp * 4].view(torch.float32).view(N, K, Dp)
+        mean = C.mean(dim=1).sum(dim=0)[:D].contiguous()
+        err = torch.empty((B, D), **f32)
+        parts = torch.empty((2, (B + 3) // 4), **f32)
+        lse = torch.empty((B, N), **f32)
+        chosen_n = torch.empty((N,), **f32)
+        prob_sum = torch.empty((N, K), **f32)
+        count = torch.empty((N, K), **f32)
+        lws = torch.empty(L.mcq_loss_workspace_bytes(B, N, K), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            st = torch.cuda.current_stream(dev).cuda_stream
+            _lib.check(L.mcq_logits_argmax(xk.data_ptr(), B, blob.data_ptr(), lscale_exp, N, K, D, logits.data_ptr(),
+                                           idx.data_ptr(), ws.data_ptr(), ws.numel(), st, flags | (4 if x_fp16 else 0)),
+                       "mcq_logits_argmax")
+            if iters > 0:
+                _lib.check(L.mcq_refine_indexes(xf.data_ptr(), B, blob.data_ptr(), N, K, D, iters, idx.data_ptr(),
+                                                idx.data_ptr(), ws.data_ptr(), ws.numel(), st), "mcq_refine_indexes")
+            _lib.check(L.mcq_recon_fwd(xf.data_ptr(), idx.data_ptr(), B, blob.data_ptr(), mean.data_ptr(), N, K, D,
+                                       err.data_ptr(), parts[0].data_ptr(), parts[1].data_ptr(), st), "mcq_recon_fwd")
+            _lib.check(L.mcq_loss_fwd(logits.data_ptr(), idx.data_ptr(), B, N, K, lse.data_ptr(), chosen_n.data_ptr(),
+                                      prob_sum.data_ptr(), count.data_ptr(), lws.data_ptr(), lws.numel(), st),
+                       "mcq_loss_fwd")
+        sums = parts.sum(dim=1)
+        num, den, chosen = sums[0], sums[1], chosen_n.sum()
+        ctx.module = module
+        ctx.save_for_backward(xf, idx, err, logits, lse, centers, centers_scale, bias, logits_scale)
+        ctx.mark_non_differentiable(den, count, idx)
+        return num, den, chosen, prob_sum, count, idx
+
+    @staticmethod
+    def backward(ctx, g_num, g_den, g_chosen, g_prob, g_count, g_idx):
+        xf, idx, err, logits, lse, centers, centers_scale, bias, logits_scale = ctx.saved_tensors
+        m = ctx.module
+        L = _lib.lib()
+        N, K, D = centers.shape
+        B, dev = xf.shape[0], xf.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        g_centers = g_cscale = g_weight = g_bias = g_lscale = None
+        with torch.cuda.device(dev):
+            st = torch.cuda.current_stream(dev).cuda_stream
+            if g_num is not None:
+                gC = torch.empty((N, K, D), **f32)
+                _lib.check(L.mcq_decode_backward(err.data_ptr(), idx.data_ptr(), B, N, K, D, gC.data_ptr(), st),
+                           "mcq_decode_backward")
+                scale = (centers_scale.detach() * m.scale_speed).exp()
+                gC = gC * (2.0 * g_num)
+                g_centers = gC * scale
+                g_cscale = (gC * centers.detach()).sum() * scale * m.scale_speed
+            if g_chosen is not None or g_prob is not None:
+                gc = (g_chosen if g_chosen is not None else torch.zeros((), **f32)).to(torch.float32).reshape(1).contiguous()
+                gp = (g_prob if g_prob is not None else torch.zeros((N, K), **f32)).to(torch.float32).contiguous()
+                G = torch.empty((B, N * K), **f32)
+                _lib.check(L.mcq_loss_bwd(logits.data_ptr(), idx.data_ptr(), lse.data_ptr(), B, N, K, gc.data_ptr(),
+                                          gp.data_ptr(), G.data_ptr(), st), "mcq_loss_bwd")
+                s = (logits_scale.detach() * m.scale_speed).exp()
+                g_weight = torch.mm(G.t(), xf) * s
+                g_bias = G.sum(dim=0)
+                g_lscale = (torch.dot(G.reshape(-1), logits.reshape(-1)) - torch.dot(g_bias, bias.detach())) * m.scale_speed
+        return None, None, None, None, None, None, g_centers, g_cscale, g_weight, g_bias, g_lscale

@@ -125,15 +125,7 @@ class QuantizerTrainer(object):
         q = self.quantizer
         B = x.shape[0]
         N, K = q.num_codebooks, q.codebook_size
-        indexes = q._compute_indexes(x, num_iters)
-        x_approx = q.decode(indexes)
-        num_local = ((x_approx - x) ** 2).sum()
-        den_local = ((x - q.get_data_mean()) ** 2).sum()
-        logprobs = q._logits(x).reshape(B, N, K).log_softmax(dim=2)
-        chosen_local = torch.gather(logprobs, dim=2, index=indexes.unsqueeze(2)).sum()
-        probs_local = logprobs.exp().sum(dim=0)                              # (N, K)
-        counts_local = torch.zeros(N, K, device=x.device)
-        counts_local.scatter_add_(1, indexes.t().contiguous(), torch.ones(N, B, device=x.device))
+        num_local, den_local, chosen_local, probs_local, counts_local = q._loss_sums(x, num_iters)
         stats = [num_local.detach().clone().reshape(1), den_local.detach().clone().reshape(1),
                  chosen_local.detach().clone().reshape(1), probs_local.detach().clone(),
                  counts_local.clone(), torch.tensor([float(B)], device=x.device)]
