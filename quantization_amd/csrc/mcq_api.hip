@@ -481,6 +481,36 @@ int mcq_decode(const void *codes, int code_bytes, int codes_per_row, long B, con
     const int Dp = round_up16(D);
     const unsigned grid = (unsigned)((B + 3) / 4);
     const int J = (Dp / 4 + 63) / 64;
+    // XCD-sliced kernel (unpacked codes, batches big enough to fill the chip; MCQ_DECODE_SLICED=0 disables: tuning hook)
+    static const bool sliced_ok = !(getenv("MCQ_DECODE_SLICED") && atoi(getenv("MCQ_DECODE_SLICED")) == 0);
+    if (sliced_ok && rep == 1 && B >= 4096 && K >= 32) {   // (16-entry codebooks: the per-vector kernels measured faster)
+        int lpv = 4;
+        while (lpv * 32 < Dp) lpv *= 2;          // 8 slices x lpv lanes x 4 floats cover Dp
+        if (lpv <= 64) {
+            const int vpw = 64 / lpv;
+            const unsigned g = (unsigned)(((B + 4 * vpw - 1) / (4 * vpw)) * 8);
+#define MCQ_DECS_LAUNCH(T, CHH, LL)                                                                              \
+    hipLaunchKernelGGL((k_decode_sliced<T, CHH, LL>), dim3(g), dim3(256), 0, st, static_cast<const T *>(codes), B, P.C, N, \
+                       K, D, Dp, out)
+#define MCQ_DECS_LPV(T, CHH)                                                                                     \
+    switch (lpv) {                                                                                               \
+        case 4: MCQ_DECS_LAUNCH(T, CHH, 4); break;                                                               \
+        case 8: MCQ_DECS_LAUNCH(T, CHH, 8); break;                                                               \
+        case 16: MCQ_DECS_LAUNCH(T, CHH, 16); break;                                                             \
+        case 32: MCQ_DECS_LAUNCH(T, CHH, 32); break;                                                             \
+        default: MCQ_DECS_LAUNCH(T, CHH, 64); break;                                                             \
+    }
+            if (code_bytes == 1) {
+                if (N <= 4) { MCQ_DECS_LPV(uint8_t, 4) } else if (N <= 8) { MCQ_DECS_LPV(uint8_t, 8) } else { MCQ_DECS_LPV(uint8_t, 16) }
+            } else {
+                if (N <= 4) { MCQ_DECS_LPV(int64_t, 4) } else if (N <= 8) { MCQ_DECS_LPV(int64_t, 8) } else { MCQ_DECS_LPV(int64_t, 16) }
+            }
+#undef MCQ_DECS_LPV
+#undef MCQ_DECS_LAUNCH
+            hipError_t e3 = hipGetLastError();
+            return e3 == hipSuccess ? 0 : (int)e3;
+        }
+    }
 #define MCQ_DEC_CASE(NN, JJ)                                                                                    \
     if (code_bytes == 1 && rep == 1 && N == NN && J == JJ) {                                                    \
         hipLaunchKernelGGL((k_decode_reg<NN, JJ>), dim3(grid), dim3(256), 0, st, static_cast<const uint8_t *>(codes), \

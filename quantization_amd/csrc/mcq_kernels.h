@@ -1380,6 +1380,47 @@ __global__ void k_decode(const CodeT *__restrict__ codes, int per_row, long B, c
     }
 }
 
+// XCD-sliced decode: workgroup id mod 8 (= the XCD it lands on) picks one eighth of the feature axis, so
+// every XCD's L2 only ever holds its own slice of the codebooks (N*K*Dp/8 floats: 0.5 MB at dim 512 / 8
+// codebooks instead of 4 MB, which is the whole L2).  A wave covers 64 / LPV vectors, LPV lanes x float4
+// per vector slice; rows are added n ascending in chunks of CH gathers in flight.  Unpacked codes only.
+template <typename CodeT, int CH, int LPV>
+__global__ void __launch_bounds__(256)
+k_decode_sliced(const CodeT *__restrict__ codes, long B, const float *__restrict__ C, int N, int K, int D, int Dp,
+                float *__restrict__ out) {
+    constexpr int VPW = 64 / LPV;
+    const int slice = blockIdx.x & 7;
+    const long vb = blockIdx.x >> 3;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int v = lane / LPV, q = lane % LPV;
+    const long b = (vb * 4 + wave) * VPW + v;
+    const int off = slice * (LPV * 4) + 4 * q;
+    if (b >= B || off >= Dp) return;
+    const CodeT *cb = codes + b * N;
+    const float *Cq = C + off;
+    f32x4 t = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int n0 = 0; n0 < N; n0 += CH) {
+        f32x4 rows[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int n = (n0 + j < N) ? n0 + j : N - 1;
+            const int k = (int)cb[n] & (K - 1);
+            rows[j] = *reinterpret_cast<const f32x4 *>(Cq + ((long)n * K + k) * Dp);
+        }
+#pragma unroll
+        for (int j = 0; j < CH; ++j)
+            if (n0 + j < N) t = (n0 + j == 0) ? rows[j] : t + rows[j];
+    }
+    float *ob = out + b * D + off;
+    if (((D & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0) && off + 3 < D) {
+        __builtin_nontemporal_store(t, reinterpret_cast<f32x4 *>(ob));   // streamed: keep the L2 for the codebooks
+    } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (off + c < D) ob[c] = t[c];
+    }
+}
+
 // Fast path for unpacked uint8 codes and the common small shapes: all NN x J row pieces of a
 // vector are requested before the first add (16 gathers in flight per lane at dim 512 / 8 codebooks).
 template <int NN, int J>

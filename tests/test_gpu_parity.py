@@ -325,3 +325,20 @@ def test_fp16_frames_are_widened_in_the_load_path(name):
     assert torch.equal(q.encode(xh.cuda(), 5, as_bytes=False), got)
     q.skip_fixed_points = False
     assert torch.equal(q.encode_from_host(xh, 5, as_bytes=False, chunk=300).cuda(), got)
+
+
+@pytest.mark.parametrize("D,K,N", [(40, 64, 8), (30, 32, 4), (100, 256, 2), (512, 256, 8), (1024, 256, 16), (260, 64, 32), (64, 16, 8)])
+def test_decode_of_big_batches_takes_the_xcd_sliced_kernel_and_stays_bit_exact(D, K, N):
+    """B >= 4096 unpacked codes go through k_decode_sliced (feature axis cut in eight, one slice per XCD):
+    same sums in the same order as the oracle, for ragged dims, uint8 and int64 codes, ragged batch sizes"""
+    state = gen.synthetic_state(31, D, K, N)
+    q = load_quantizer(state, D, K, N)
+    oq = OracleQuantizer.from_state_dict(state)
+    B = 5003
+    rng = np.random.default_rng(5)
+    codes = rng.integers(0, K, size=(B, N), dtype=np.int64)
+    want = oq.decode(codes.astype(np.uint8))
+    got8 = q.decode(torch.from_numpy(codes.astype(np.uint8)).cuda())
+    got64 = q.decode(torch.from_numpy(codes).cuda())
+    assert np.array_equal(got8.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    assert torch.equal(got8, got64)
