@@ -1,5 +1,7 @@
 """Parity of the HIP path (through the C ABI) with the CPU oracle and with the
 fixtures captured from the reference.  Run on the MI355X: pytest -m gpu."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -342,3 +344,11 @@ def test_decode_of_big_batches_takes_the_xcd_sliced_kernel_and_stays_bit_exact(D
     got64 = q.decode(torch.from_numpy(codes).cuda())
     assert np.array_equal(got8.cpu().numpy().view(np.uint32), want.view(np.uint32))
     assert torch.equal(got8, got64)
+    # the LDS-resident kernel of very large batches (threshold lowered through its test hook)
+    os.environ["MCQ_DECODE_LDS_MIN"] = "4096"
+    try:
+        lds8 = q.decode(torch.from_numpy(codes.astype(np.uint8)).cuda())
+        lds64 = q.decode(torch.from_numpy(codes).cuda())
+    finally:
+        del os.environ["MCQ_DECODE_LDS_MIN"]
+    assert torch.equal(lds8, got8) and torch.equal(lds64, got8)
