@@ -140,6 +140,15 @@ int mcq_loss_fwd(const float *logits, const int64_t *idx, long B, int N, int K, 
 int mcq_loss_bwd(const float *logits, const int64_t *idx, const float *lse, long B, int N, int K,
                  const float *g_chosen, const float *g_prob, float *grad_logits, void *stream);
 
+/* The (N, K)-sized tail of compute_loss (:217-241) and of the trainer's total loss
+ * rel + logprob + entropy_scale * logits_entropy (:682-683), on DEVICE floats:
+ *   sums = {sum err^2, sum (x-mean)^2, sum_n chosen_sum[n], total batch size}  (all-reduced in DP training)
+ *   losses[4] = rel_reconstruction, logprob, logits_entropy, index_entropy losses;
+ *   g[2] = d total / d sums[0], d total / d sums[2];  g_prob[N][K] = d total / d prob_sum
+ * (g[1] and g_prob feed mcq_loss_bwd; 2 * g[0] scales mcq_decode_backward(err)).                */
+int mcq_loss_tail(const float *sums, const float *prob_sum, const float *count, int N, int K, float entropy_scale,
+                  float *losses, float *g, float *g_prob, void *stream);
+
 /* Reconstruction pieces (:213-217): err[b] = decode(idx[b]) - x[b] (fp32 [B][D]); partial sums over
  * groups of 4 vectors of err^2 (num_part) and (x - mean)^2 (den_part), float[(B + 3) / 4] each, to be
  * summed by the caller; mean = get_data_mean() (:67-75), float[D].  d(sum err^2)/d(centers) is

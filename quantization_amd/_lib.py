@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libmcq_hip.so")
 SYMBOLS = (
     "mcq_abi_version", "mcq_padded_dim", "mcq_prepared_bytes", "mcq_prepare", "mcq_prepare_dev", "mcq_encode_workspace_bytes",
     "mcq_encode", "mcq_encode_ex", "mcq_refine_indexes", "mcq_decode", "mcq_decode_backward", "mcq_logits", "mcq_last_encode_launches", "mcq_profile_encode",
-    "mcq_logits_argmax", "mcq_loss_workspace_bytes", "mcq_loss_fwd", "mcq_loss_bwd", "mcq_recon_fwd",
+    "mcq_logits_argmax", "mcq_loss_workspace_bytes", "mcq_loss_fwd", "mcq_loss_bwd", "mcq_recon_fwd", "mcq_loss_tail",
 )
 
 MCQ_EINVAL, MCQ_EUNSUPPORTED, MCQ_EWORKSPACE = -1, -2, -3
@@ -64,6 +64,8 @@ def lib():
     L.mcq_loss_fwd.argtypes = [vp, vp, i64, i32, i32, vp, vp, vp, vp, vp, sz, vp]
     L.mcq_loss_bwd.restype = i32
     L.mcq_loss_bwd.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp, vp, vp]
+    L.mcq_loss_tail.restype = i32
+    L.mcq_loss_tail.argtypes = [vp, vp, vp, i32, i32, f32, vp, vp, vp, vp]
     L.mcq_recon_fwd.restype = i32
     L.mcq_recon_fwd.argtypes = [vp, vp, i64, vp, vp, i32, i32, i32, vp, vp, vp, vp]
     L.mcq_last_encode_launches.restype = i32

@@ -661,6 +661,16 @@ int mcq_loss_bwd(const float *logits, const int64_t *idx, const float *lse, long
     return 0;
 }
 
+int mcq_loss_tail(const float *sums, const float *prob_sum, const float *count, int N, int K, float entropy_scale,
+                  float *losses, float *g, float *g_prob, void *stream) {
+    if (!is_pow2(K) || K < 16 || K > 256 || N < 1) return MCQ_EUNSUPPORTED;
+    if (!sums || !prob_sum || !count || !losses || !g || !g_prob) return MCQ_EINVAL;
+    hipLaunchKernelGGL(k_loss_tail, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), sums, prob_sum, count, N, K,
+                       entropy_scale, losses, g, g_prob);
+    MCQ_LAUNCH_CHECK();
+    return 0;
+}
+
 int mcq_recon_fwd(const float *x, const int64_t *idx, long B, const void *prepared, const float *mean, int N, int K,
                   int D, float *err, float *num_part, float *den_part, void *stream) {
     if (!domain_ok(N, K, D)) return MCQ_EUNSUPPORTED;

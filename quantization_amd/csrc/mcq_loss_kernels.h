@@ -212,6 +212,51 @@ k_recon_fwd(const float *__restrict__ x, const int64_t *__restrict__ idx, long B
     }
 }
 
+// The (N, K)-sized arithmetic of compute_loss (:217-241) and of QuantizerTrainer.step's total loss (:682-683)
+// from the batch sums, plus the upstream gradients the backward kernels need.  One workgroup.
+//   sums = {num, den, chosen (sum over codebooks), Btot}   (device floats: in data-parallel training the all-reduced ones)
+//   losses[0..3] = rel_reconstruction, logprob, logits_entropy, index_entropy
+//   total = rel + logprob + entropy_scale * logits_entropy:
+//   g[0] = d total / d num = 1 / (den + 1e-20);  g[1] = d total / d chosen = -1 / (Btot * N);
+//   g_prob[n][k] = d total / d prob_sum[n][k] = entropy_scale * (log(pbar) + 1) / (ref * N * Btot)
+__global__ void __launch_bounds__(256)
+k_loss_tail(const float *__restrict__ sums, const float *__restrict__ prob_sum, const float *__restrict__ count, int N,
+            int K, float entropy_scale, float *__restrict__ losses, float *__restrict__ g, float *__restrict__ g_prob) {
+    __shared__ float s_a[256], s_b[256];
+    const int tid = threadIdx.x;
+    const float num = sums[0], den = sums[1], chosen = sums[2], Bt = sums[3];
+    const float ref = logf((float)K);
+    // thread t owns entry k = t of every codebook (K <= 256): per-codebook entropies reduce over threads
+    float h_logits = 0.f, h_index = 0.f;     // sums over n of the per-codebook entropies (thread 0)
+    for (int n = 0; n < N; ++n) {
+        float a = 0.f, b = 0.f;
+        if (tid < K) {
+            const float p = prob_sum[n * K + tid] / Bt + 1.0e-20f;
+            const float lp = logf(p);
+            a = p * lp;
+            g_prob[n * K + tid] = entropy_scale * (lp + 1.0f) / (ref * (float)N * Bt);
+            const float c = count[n * K + tid] / Bt + 1.0e-20f;
+            b = c * logf(c);
+        }
+        s_a[tid] = a; s_b[tid] = b;
+        __syncthreads();
+        for (int m = 128; m >= 1; m >>= 1) {
+            if (tid < m) { s_a[tid] += s_a[tid + m]; s_b[tid] += s_b[tid + m]; }
+            __syncthreads();
+        }
+        if (tid == 0) { h_logits += -s_a[0]; h_index += -s_b[0]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        losses[0] = num / (den + 1.0e-20f);
+        losses[1] = -chosen / (Bt * (float)N);
+        losses[2] = (ref - h_logits / (float)N) / ref;
+        losses[3] = (ref - h_index / (float)N) / ref;
+        g[0] = 1.0f / (den + 1.0e-20f);
+        g[1] = -1.0f / (Bt * (float)N);
+    }
+}
+
 // uint8 working indexes -> int64 (argmax output of mcq_logits_argmax)
 __global__ void k_export_indexes(const uint8_t *__restrict__ in, long n, int64_t *__restrict__ out) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -18,6 +18,21 @@ from torch import Tensor, nn
 from . import _lib
 
 
+# The derived device state (_prepared) is cached per parameter version.  torch's fused optimizers
+# (Adam(fused=True) ...) update parameters WITHOUT bumping Tensor._version (measured: tools/exp_version.py),
+# so every optimizer step, of any optimizer, also advances this epoch, which is part of the cache key.
+_param_epoch = [0]
+
+
+def _note_optimizer_step(*_args, **_kwargs):
+    _param_epoch[0] += 1
+
+
+from torch.optim.optimizer import register_optimizer_step_post_hook as _register_step_hook  # noqa: E402
+
+_register_step_hook(_note_optimizer_step)
+
+
 def _is_pow2(n: int) -> bool:
     return n > 0 and (n & (n - 1)) == 0
 
@@ -71,6 +86,11 @@ class Quantizer(nn.Module):
         self._prep = None
         return ret
 
+    def invalidate_cache(self) -> None:
+        """Drop the cached derived state.  Needed only after parameters were modified in a way torch does not
+        version (in-place edits through `.data`); optimizer steps and load_state_dict are tracked."""
+        self._prep = None
+
     def get_id(self) -> str:
         return self.id_str
 
@@ -95,7 +115,7 @@ class Quantizer(nn.Module):
         the host's by an ulp); decode (`any_flavour`) takes whichever is current."""
         ps = (self.centers, self.centers_scale, self.logits_scale, self.to_logits.weight, self.to_logits.bias)
         training = torch.is_grad_enabled() and any(p.requires_grad for p in ps)
-        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in ps)
+        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in ps) + (_param_epoch[0],)
         if self._prep is not None and self._prep[0] == key and (self._prep[2] == "host" or training or any_flavour):
             return self._prep[1]
         on_device = training
@@ -445,83 +465,104 @@ class _DecodeFn(torch.autograd.Function):
         return None, None, g_centers, g_scale
 
 
+class _LossState:
+    """What the forward loss kernels leave behind for the backward ones."""
+    __slots__ = ("xf", "idx", "err", "logits", "lse", "parts", "chosen_n", "prob_sum", "count")
+
+
+def _loss_forward_kernels(module, x, iters, blob, lscale_exp, flags) -> _LossState:
+    """mcq_logits_argmax (one GEMM gives the logits AND the initial indexes), mcq_refine_indexes,
+    mcq_recon_fwd, mcq_loss_fwd on x (B, dim) fp32/fp16 on the HIP device."""
+    L = _lib.lib()
+    N, K, D = module.num_codebooks, module.codebook_size, module.dim
+    x_fp16 = x.dtype == torch.float16
+    xk = x.detach().contiguous() if x_fp16 else x.detach().to(torch.float32).contiguous()
+    B, dev = xk.shape[0], xk.device
+    f32 = dict(dtype=torch.float32, device=dev)
+    st_ = _LossState()
+    st_.logits = torch.empty((B, N * K), **f32)
+    st_.idx = torch.empty((B, N), dtype=torch.int64, device=dev)
+    ws = module._workspace(B, dev)
+    st_.xf = xk.float() if x_fp16 else xk
+    # get_data_mean() (:67-75) from the scaled centers already sitting in the prepared blob
+    Dp = L.mcq_padded_dim(D)
+    C = blob[:N * K * Dp * 4].view(torch.float32).view(N, K, Dp)
+    mean = C.mean(dim=1).sum(dim=0)[:D].contiguous()
+    st_.err = torch.empty((B, D), **f32)
+    st_.parts = torch.empty((2, (B + 3) // 4), **f32)
+    st_.lse = torch.empty((B, N), **f32)
+    st_.chosen_n = torch.empty((N,), **f32)
+    st_.prob_sum = torch.empty((N, K), **f32)
+    st_.count = torch.empty((N, K), **f32)
+    lws = torch.empty(L.mcq_loss_workspace_bytes(B, N, K), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        st = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(L.mcq_logits_argmax(xk.data_ptr(), B, blob.data_ptr(), lscale_exp, N, K, D, st_.logits.data_ptr(),
+                                       st_.idx.data_ptr(), ws.data_ptr(), ws.numel(), st, flags | (4 if x_fp16 else 0)),
+                   "mcq_logits_argmax")
+        if iters > 0:
+            _lib.check(L.mcq_refine_indexes(st_.xf.data_ptr(), B, blob.data_ptr(), N, K, D, iters, st_.idx.data_ptr(),
+                                            st_.idx.data_ptr(), ws.data_ptr(), ws.numel(), st), "mcq_refine_indexes")
+        _lib.check(L.mcq_recon_fwd(st_.xf.data_ptr(), st_.idx.data_ptr(), B, blob.data_ptr(), mean.data_ptr(), N, K, D,
+                                   st_.err.data_ptr(), st_.parts[0].data_ptr(), st_.parts[1].data_ptr(), st), "mcq_recon_fwd")
+        _lib.check(L.mcq_loss_fwd(st_.logits.data_ptr(), st_.idx.data_ptr(), B, N, K, st_.lse.data_ptr(),
+                                  st_.chosen_n.data_ptr(), st_.prob_sum.data_ptr(), st_.count.data_ptr(), lws.data_ptr(),
+                                  lws.numel(), st), "mcq_loss_fwd")
+    return st_
+
+
+def _loss_backward_kernels(module, st_: _LossState, g_num, g_chosen, g_prob, centers, centers_scale, bias, logits_scale):
+    """Gradients of  g_num * sum err^2 + g_chosen * sum chosen + <g_prob, prob_sum>  w.r.t. (centers, centers_scale,
+    to_logits.weight, to_logits.bias, logits_scale); g_* are device tensors (or None).  Derivation:
+      d sum err^2 / d(scaled centers) = 2 * scatter-add of err (mcq_decode_backward);
+      logits = s (x W^T) + b with s = exp(speed * logits_scale):  dW = s G^T x,  db = sum_b G,
+      d logits_scale = speed * <G, logits - b>,  G = mcq_loss_bwd."""
+    L = _lib.lib()
+    N, K, D = centers.shape
+    B, dev = st_.xf.shape[0], st_.xf.device
+    f32 = dict(dtype=torch.float32, device=dev)
+    g_centers = g_cscale = g_weight = g_bias = g_lscale = None
+    speed = module.scale_speed
+    with torch.cuda.device(dev):
+        st = torch.cuda.current_stream(dev).cuda_stream
+        if g_num is not None:
+            gC = torch.empty((N, K, D), **f32)
+            _lib.check(L.mcq_decode_backward(st_.err.data_ptr(), st_.idx.data_ptr(), B, N, K, D, gC.data_ptr(), st),
+                       "mcq_decode_backward")
+            f = (centers_scale.detach() * speed).exp() * (2.0 * g_num)          # scalar tensor
+            g_centers = gC * f
+            g_cscale = torch.dot(gC.reshape(-1), centers.detach().reshape(-1)) * (f * speed)
+        if g_chosen is not None or g_prob is not None:
+            gc = (g_chosen if g_chosen is not None else torch.zeros((), **f32)).to(torch.float32).reshape(1).contiguous()
+            gp = (g_prob if g_prob is not None else torch.zeros((N, K), **f32)).to(torch.float32).contiguous()
+            G = torch.empty((B, N * K), **f32)
+            _lib.check(L.mcq_loss_bwd(st_.logits.data_ptr(), st_.idx.data_ptr(), st_.lse.data_ptr(), B, N, K, gc.data_ptr(),
+                                      gp.data_ptr(), G.data_ptr(), st), "mcq_loss_bwd")
+            s_ = (logits_scale.detach() * speed).exp()
+            g_weight = torch.mm(G.t(), st_.xf) * s_
+            g_bias = G.sum(dim=0)
+            g_lscale = (torch.dot(G.reshape(-1), st_.logits.reshape(-1)) - torch.dot(g_bias, bias.detach())) * speed
+    return g_centers, g_cscale, g_weight, g_bias, g_lscale
+
+
 class _LossSumsFn(torch.autograd.Function):
-    """Quantizer._loss_sums on the HIP device.  Forward: mcq_logits_argmax (one GEMM gives the logits AND
-    the initial indexes), mcq_refine_indexes, mcq_recon_fwd, mcq_loss_fwd.  Backward, derived by hand:
-      d num / d(scaled centers) = 2 * scatter-add of err (mcq_decode_backward);
-      d / d logits from mcq_loss_bwd;  logits = s * (x W^T) + b with s = exp(speed * logits_scale), so
-      dW = s * G^T x,  db = sum_b G,  d logits_scale = speed * <G, logits - b>."""
+    """Quantizer._loss_sums on the HIP device under autograd: the forward kernels of _loss_forward_kernels,
+    the hand-derived backward of _loss_backward_kernels."""
 
     @staticmethod
     def forward(ctx, module, x, iters, blob, lscale_exp, flags, centers, centers_scale, weight, bias, logits_scale):
-        L = _lib.lib()
-        N, K, D = module.num_codebooks, module.codebook_size, module.dim
-        x_fp16 = x.dtype == torch.float16
-        xk = x.detach().contiguous() if x_fp16 else x.detach().to(torch.float32).contiguous()
-        B, dev = xk.shape[0], xk.device
-        f32 = dict(dtype=torch.float32, device=dev)
-        logits = torch.empty((B, N * K), **f32)
-        idx = torch.empty((B, N), dtype=torch.int64, device=dev)
-        ws = module._workspace(B, dev)
-        xf = xk.float() if x_fp16 else xk
-        # get_data_mean() (:67-75) from the scaled centers already sitting in the prepared blob
-        Dp = L.mcq_padded_dim(D)
-        C = blob[:N * K * Dp * 4].view(torch.float32).view(N, K, Dp)
-        mean = C.mean(dim=1).sum(dim=0)[:D].contiguous()
-        err = torch.empty((B, D), **f32)
-        parts = torch.empty((2, (B + 3) // 4), **f32)
-        lse = torch.empty((B, N), **f32)
-        chosen_n = torch.empty((N,), **f32)
-        prob_sum = torch.empty((N, K), **f32)
-        count = torch.empty((N, K), **f32)
-        lws = torch.empty(L.mcq_loss_workspace_bytes(B, N, K), dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev):
-            st = torch.cuda.current_stream(dev).cuda_stream
-            _lib.check(L.mcq_logits_argmax(xk.data_ptr(), B, blob.data_ptr(), lscale_exp, N, K, D, logits.data_ptr(),
-                                           idx.data_ptr(), ws.data_ptr(), ws.numel(), st, flags | (4 if x_fp16 else 0)),
-                       "mcq_logits_argmax")
-            if iters > 0:
-                _lib.check(L.mcq_refine_indexes(xf.data_ptr(), B, blob.data_ptr(), N, K, D, iters, idx.data_ptr(),
-                                                idx.data_ptr(), ws.data_ptr(), ws.numel(), st), "mcq_refine_indexes")
-            _lib.check(L.mcq_recon_fwd(xf.data_ptr(), idx.data_ptr(), B, blob.data_ptr(), mean.data_ptr(), N, K, D,
-                                       err.data_ptr(), parts[0].data_ptr(), parts[1].data_ptr(), st), "mcq_recon_fwd")
-            _lib.check(L.mcq_loss_fwd(logits.data_ptr(), idx.data_ptr(), B, N, K, lse.data_ptr(), chosen_n.data_ptr(),
-                                      prob_sum.data_ptr(), count.data_ptr(), lws.data_ptr(), lws.numel(), st),
-                       "mcq_loss_fwd")
-        sums = parts.sum(dim=1)
-        num, den, chosen = sums[0], sums[1], chosen_n.sum()
+        st_ = _loss_forward_kernels(module, x, iters, blob, lscale_exp, flags)
+        sums = st_.parts.sum(dim=1)
+        num, den, chosen = sums[0], sums[1], st_.chosen_n.sum()
         ctx.module = module
-        ctx.save_for_backward(xf, idx, err, logits, lse, centers, centers_scale, bias, logits_scale)
-        ctx.mark_non_differentiable(den, count, idx)
-        return num, den, chosen, prob_sum, count, idx
+        ctx.st = st_
+        ctx.save_for_backward(centers, centers_scale, bias, logits_scale)
+        ctx.mark_non_differentiable(den, st_.count, st_.idx)
+        return num, den, chosen, st_.prob_sum, st_.count, st_.idx
 
     @staticmethod
     def backward(ctx, g_num, g_den, g_chosen, g_prob, g_count, g_idx):
-        xf, idx, err, logits, lse, centers, centers_scale, bias, logits_scale = ctx.saved_tensors
-        m = ctx.module
-        L = _lib.lib()
-        N, K, D = centers.shape
-        B, dev = xf.shape[0], xf.device
-        f32 = dict(dtype=torch.float32, device=dev)
-        g_centers = g_cscale = g_weight = g_bias = g_lscale = None
-        with torch.cuda.device(dev):
-            st = torch.cuda.current_stream(dev).cuda_stream
-            if g_num is not None:
-                gC = torch.empty((N, K, D), **f32)
-                _lib.check(L.mcq_decode_backward(err.data_ptr(), idx.data_ptr(), B, N, K, D, gC.data_ptr(), st),
-                           "mcq_decode_backward")
-                scale = (centers_scale.detach() * m.scale_speed).exp()
-                gC = gC * (2.0 * g_num)
-                g_centers = gC * scale
-                g_cscale = (gC * centers.detach()).sum() * scale * m.scale_speed
-            if g_chosen is not None or g_prob is not None:
-                gc = (g_chosen if g_chosen is not None else torch.zeros((), **f32)).to(torch.float32).reshape(1).contiguous()
-                gp = (g_prob if g_prob is not None else torch.zeros((N, K), **f32)).to(torch.float32).contiguous()
-                G = torch.empty((B, N * K), **f32)
-                _lib.check(L.mcq_loss_bwd(logits.data_ptr(), idx.data_ptr(), lse.data_ptr(), B, N, K, gc.data_ptr(),
-                                          gp.data_ptr(), G.data_ptr(), st), "mcq_loss_bwd")
-                s = (logits_scale.detach() * m.scale_speed).exp()
-                g_weight = torch.mm(G.t(), xf) * s
-                g_bias = G.sum(dim=0)
-                g_lscale = (torch.dot(G.reshape(-1), logits.reshape(-1)) - torch.dot(g_bias, bias.detach())) * m.scale_speed
-        return None, None, None, None, None, None, g_centers, g_cscale, g_weight, g_bias, g_lscale
+        centers, centers_scale, bias, logits_scale = ctx.saved_tensors
+        grads = _loss_backward_kernels(ctx.module, ctx.st, g_num, g_chosen, g_prob, centers, centers_scale, bias,
+                                       logits_scale)
+        return (None, None, None, None, None, None) + tuple(grads)

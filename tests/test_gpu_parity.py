@@ -352,3 +352,24 @@ def test_decode_of_big_batches_takes_the_xcd_sliced_kernel_and_stays_bit_exact(D
     finally:
         del os.environ["MCQ_DECODE_LDS_MIN"]
     assert torch.equal(lds8, got8) and torch.equal(lds64, got8)
+
+
+def test_derived_state_follows_fused_optimizer_steps():
+    """Adam(fused=True) updates parameters without bumping Tensor._version; the cached prepared state must not go stale"""
+    fx = fixtures.load("trained_d64_b4_p2")
+    q = load_quantizer(fx["state"], fx["D"], fx["K"], fx["N"])
+    x = torch.from_numpy(fx["x"][:512]).cuda()
+    before = q.encode(x, 2)
+    opt = torch.optim.Adam(q.parameters(), lr=0.05, fused=True)
+    with torch.enable_grad():
+        for p in q.parameters():
+            p.grad = torch.randn_like(p)
+    opt.step()
+    after = q.encode(x, 2)
+    q2 = load_quantizer({k: v.detach().cpu().numpy() for k, v in q.state_dict().items()}, fx["D"], fx["K"], fx["N"])
+    assert torch.equal(after, q2.encode(x, 2)) and not torch.equal(after, before)
+    with torch.no_grad():
+        q.centers.data.mul_(-1.0)          # unversioned edit: the documented escape hatch
+    q.invalidate_cache()
+    q3 = load_quantizer({k: v.detach().cpu().numpy() for k, v in q.state_dict().items()}, fx["D"], fx["K"], fx["N"])
+    assert torch.equal(q.encode(x, 2), q3.encode(x, 2))

@@ -137,3 +137,28 @@ def test_fused_loss_kernels_match_the_torch_op_formulation(D, K, N, B, iters):
     total(lf2).backward()
     gf2 = _grads(q)
     assert all(torch.equal(a, b) for a, b in zip(lf, lf2)) and all(torch.equal(gf[n], gf2[n]) for n in gf)
+
+
+def test_fused_step_equals_the_autograd_step():
+    """QuantizerTrainer.step through _fused_loss_and_grads (forward kernels, mcq_loss_tail, backward kernels)
+    against the same step through compute_loss + backward(): same losses and same parameters after steps in
+    both phases (the phase switch included)."""
+    from quantization_amd import QuantizerTrainer
+    dev = torch.device("cuda:0")
+    runs = []
+    for fused in (True, False):
+        torch.manual_seed(21)
+        random.seed(21)
+        tr = QuantizerTrainer(dim=96, bytes_per_frame=4, device=dev, phase_one_iters=6, phase_two_iters=6)
+        tr.fused_step = fused
+        losses = []
+        for it in range(12):
+            tr.step(torch.from_numpy(gen.make_x(500 + it, 768, 96)).to(dev))
+            losses.append(tr.last_losses)
+        runs.append((np.array(losses), {k: v.detach().cpu().numpy() for k, v in tr.quantizer.state_dict().items()},
+                     tr.quantizer.codebook_size))
+    (lf, pf, kf), (la, pa, ka) = runs
+    assert kf == ka == 256
+    assert np.allclose(lf, la, rtol=2e-4, atol=2e-5), np.abs(lf - la).max()
+    for k in ("centers", "to_logits.weight", "to_logits.bias", "logits_scale", "centers_scale"):
+        assert np.abs(pf[k] - pa[k]).max() <= 2e-4 * max(1e-3, np.abs(pa[k]).max()), (k, np.abs(pf[k] - pa[k]).max())
