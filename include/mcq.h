@@ -156,6 +156,26 @@ int mcq_loss_tail(const float *sums, const float *prob_sum, const float *count, 
 int mcq_recon_fwd(const float *x, const int64_t *idx, long B, const void *prepared, const float *mean, int N,
                   int K, int D, float *err, float *num_part, float *den_part, void *stream);
 
+/* ---- JointCodebookLoss pieces (quantization/prediction.py:9-82) ----------------------
+ * The consumer of the codes: a predictor trained to predict codebook n from its input and the entries of
+ * codebooks 0..n-1.  The GEMMs are library calls on the caller's side; these are the fused non-GEMM parts.
+ *
+ * mcq_jcl_prefix_fwd (:38-66): A[n][b][:] = relu(hp[b] + scale * sum_{m<n} emb[m*K + max(idx[b][m], 0)]),
+ *   summed in codebook order (embedding * scale, cat, cumsum, relu); hp fp32 [B][H] (the output of linear1),
+ *   emb fp32 [(N-1)*K][H], idx int64 [B][N], A fp32 [N][B][H].
+ * mcq_jcl_prefix_bwd: from gA = dL/dA: g_hp [B][H] and gE [N-1][B][H], the gradient of the embedding row frame b
+ *   chose for codebook n (to be scattered with mcq_scatter_rows).
+ * mcq_scatter_rows: out[n][k][:] = sum over b ascending with idx[b*idx_stride + n] == k of
+ *   grad[b*stride_b + n*stride_n + :D] -- mcq_decode_backward with per-(b, n) gradients; negative indexes
+ *   (padding frames) match nothing.  The cross-entropy itself is mcq_loss_fwd / mcq_loss_bwd on [N*B][K] logits,
+ *   whose negative targets contribute nothing (ignore_index, :78-81).                                   */
+int mcq_jcl_prefix_fwd(const float *hp, const float *emb, const int64_t *idx, long B, int N, int K, int H,
+                       float scale, float *A, void *stream);
+int mcq_jcl_prefix_bwd(const float *A, const float *gA, long B, int N, int H, float scale, float *g_hp, float *gE,
+                       void *stream);
+int mcq_scatter_rows(const float *grad, long stride_b, long stride_n, const int64_t *idx, int idx_stride, long B,
+                     int N, int K, int D, float *out, void *stream);
+
 /* ---- test / profiling hooks -------------------------------------------------
  * Logits of Quantizer._logits (:277-279) for a batch, fp32 [B][N*K]; used by the
  * parity tests to localise a divergence.                                       */

@@ -6,5 +6,6 @@ Drop-in for the hot path of danpovey/quantization (`Quantizer.encode/decode`,
 """
 from .quantizer import Quantizer  # noqa: F401
 from .trainer import QuantizerTrainer  # noqa: F401
+from .prediction import JointCodebookLoss  # noqa: F401   (the consumer of the codes, quantization/__init__.py:4)
 
-__all__ = ["Quantizer", "QuantizerTrainer"]
+__all__ = ["Quantizer", "QuantizerTrainer", "JointCodebookLoss"]

@@ -564,7 +564,41 @@ int mcq_decode_backward(const float *grad_out, const int64_t *idx, long B, int N
     const int chunks = (D + 63) / 64;
     const long waves = (long)N * K * chunks;
     hipLaunchKernelGGL(k_decode_backward, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), grad_out, idx, B, N, K, D, chunks, gC);
+                       static_cast<hipStream_t>(stream), grad_out, idx, B, N, K, D, chunks, gC, (long)D, 0L, N);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+int mcq_scatter_rows(const float *grad, long stride_b, long stride_n, const int64_t *idx, int idx_stride, long B, int N,
+                     int K, int D, float *out, void *stream) {
+    if (N <= 0 || K <= 0 || D <= 0 || B < 0 || !out || idx_stride < N) return MCQ_EINVAL;
+    if (B > 0 && (!grad || !idx)) return MCQ_EINVAL;
+    const int chunks = (D + 63) / 64;
+    const long waves = (long)N * K * chunks;
+    hipLaunchKernelGGL(k_decode_backward, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), grad, idx, B, N, K, D, chunks, out, stride_b, stride_n, idx_stride);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+int mcq_jcl_prefix_fwd(const float *hp, const float *emb, const int64_t *idx, long B, int N, int K, int H, float scale,
+                       float *A, void *stream) {
+    if (N < 2 || K < 1 || H < 1 || B < 0) return MCQ_EINVAL;
+    if (B == 0) return 0;
+    if (!hp || !emb || !idx || !A) return MCQ_EINVAL;
+    hipLaunchKernelGGL(k_jcl_prefix_fwd, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), hp,
+                       emb, idx, B, N, K, H, scale, A);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+int mcq_jcl_prefix_bwd(const float *A, const float *gA, long B, int N, int H, float scale, float *g_hp, float *gE,
+                       void *stream) {
+    if (N < 2 || H < 1 || B < 0) return MCQ_EINVAL;
+    if (B == 0) return 0;
+    if (!A || !gA || !g_hp || !gE) return MCQ_EINVAL;
+    hipLaunchKernelGGL(k_jcl_prefix_bwd, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), A,
+                       gA, B, N, H, scale, g_hp, gE);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }

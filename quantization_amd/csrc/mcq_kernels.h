@@ -1511,8 +1511,10 @@ __global__ void k_decode_reg(const uint8_t *__restrict__ codes, long B, const fl
 // 64 at a time (ballot) and add grad_out[b][chunk] for every match in ascending b -- a fixed
 // summation order, so training is bit-reproducible (torch's index_add_ on the device uses atomics).
 // Matching rows are fetched eight at a time so the loads overlap; the adds stay in order.
+// Generalised to per-(vector, codebook) gradients: the value added for vector b into row (n, k) is
+// gout[b * gsb + n * gsn + d] (decode: gsb = D, gsn = 0); idx[b * idx_stride + n]; negative indexes match no row.
 __global__ void k_decode_backward(const float *__restrict__ gout, const int64_t *__restrict__ idx, long B, int N, int K,
-                                  int D, int chunks, float *__restrict__ gC) {
+                                  int D, int chunks, float *__restrict__ gC, long gsb, long gsn, int idx_stride) {
     const long w = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (w >= (long)N * K * chunks) return;
     const int lane = lane_id();
@@ -1524,7 +1526,7 @@ __global__ void k_decode_backward(const float *__restrict__ gout, const int64_t 
     float acc = 0.f;
     for (long b0 = 0; b0 < B; b0 += 64) {
         const long b = b0 + lane;
-        const bool hit = (b < B) && (idx[b * N + n] == k);
+        const bool hit = (b < B) && (idx[b * idx_stride + n] == k);
         unsigned long long m = __ballot(hit);
         while (m) {
             float v[8];
@@ -1534,7 +1536,7 @@ __global__ void k_decode_backward(const float *__restrict__ gout, const int64_t 
                 if (m) {   // wave-uniform
                     const int l = __ffsll((long long)m) - 1;
                     m &= m - 1;
-                    v[u] = gout[(b0 + l) * D + dc];
+                    v[u] = gout[(b0 + l) * gsb + n * gsn + dc];
                 }
             }
 #pragma unroll

@@ -72,17 +72,15 @@ k_loss_fwd(const float *__restrict__ logits, const int64_t *__restrict__ idx, lo
         se = row_sum<KL>(se);
         const float lse = mx + logf(se);
         const int ki = (int)idx[bc * N + n];
-        if (ok) {
+        if (ok && kl == 0) lse_out[b * N + n] = lse;
+        if (ok && ki >= 0) {   // negative target = "no index here" (padding frames of JointCodebookLoss): contributes nothing
 #pragma unroll
             for (int i = 0; i < VPL; ++i) {
                 const float lp = v[i] - lse;
                 acc[i] += expf(lp);
                 if (kl + KL * i == ki) chosen += lp;
             }
-            if (kl == 0) {
-                lse_out[b * N + n] = lse;
-                atomicAdd(&s_count[ki & (K - 1)], 1);   // integer: order-independent
-            }
+            if (kl == 0) atomicAdd(&s_count[ki & (K - 1)], 1);   // integer: order-independent
         }
     }
 #pragma unroll
@@ -174,7 +172,7 @@ k_loss_bwd(const float *__restrict__ logits, const int64_t *__restrict__ idx, co
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
             const float d = (kl + KL * i == ki) ? 1.f : 0.f;
-            grad[rc * (long)K + kl + KL * i] = gc * (d - p[i]) + p[i] * (g[i] - dot);
+            grad[rc * (long)K + kl + KL * i] = (ki < 0) ? 0.f : gc * (d - p[i]) + p[i] * (g[i] - dot);
         }
     }
 }
@@ -254,6 +252,52 @@ k_loss_tail(const float *__restrict__ sums, const float *__restrict__ prob_sum, 
         losses[3] = (ref - h_index / (float)N) / ref;
         g[0] = 1.0f / (den + 1.0e-20f);
         g[1] = -1.0f / (Bt * (float)N);
+    }
+}
+
+// ------------------------------------------------------------ JointCodebookLoss
+// quantization/prediction.py:38-66: the hidden activations that predict codebook n from the predictor and the
+// entries chosen in codebooks 0..n-1.  One wave per frame b:
+//   s_0 = hp[b];  s_n = s_{n-1} + scale * emb[(n-1) * K + max(idx[b][n-1], 0)];  A[n][b] = relu(s_n)
+// (embedding * scale, cat, cumsum over the codebook axis, relu -- in that operation order).  A is laid out
+// [N][B][H]: the per-codebook GEMMs that follow read contiguous batches.
+__global__ void __launch_bounds__(256)
+k_jcl_prefix_fwd(const float *__restrict__ hp /*[B][H]*/, const float *__restrict__ emb /*[(N-1)*K][H]*/,
+                 const int64_t *__restrict__ idx /*[B][N]*/, long B, int N, int K, int H, float scale,
+                 float *__restrict__ A /*[N][B][H]*/) {
+    const long b = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int lane = threadIdx.x & 63;
+    for (int h = lane; h < H; h += 64) {
+        float s = hp[b * H + h];
+        A[b * H + h] = fmaxf(s, 0.f);
+        for (int n = 1; n < N; ++n) {
+            long k = idx[b * N + n - 1];
+            k = k < 0 ? 0 : k;
+            s = s + emb[((long)(n - 1) * K + k) * H + h] * scale;
+            A[((long)n * B + b) * H + h] = fmaxf(s, 0.f);
+        }
+    }
+}
+
+// Backward of the above given gA = dL/dA: with m_n = (A[n][b] > 0) ? gA[n][b] : 0 and the reverse running sum
+// r_n = m_n + r_{n+1}:  d hp[b] = r_0;  gE[n-1][b] = scale * r_n is the gradient of the embedding row chosen by
+// frame b for codebook n-1 (scattered to the table by mcq_scatter_rows).
+__global__ void __launch_bounds__(256)
+k_jcl_prefix_bwd(const float *__restrict__ A, const float *__restrict__ gA, long B, int N, int H, float scale,
+                 float *__restrict__ g_hp /*[B][H]*/, float *__restrict__ gE /*[N-1][B][H]*/) {
+    const long b = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int lane = threadIdx.x & 63;
+    for (int h = lane; h < H; h += 64) {
+        float r = 0.f;
+        for (int n = N - 1; n >= 1; --n) {
+            const long o = ((long)n * B + b) * H + h;
+            r = r + ((A[o] > 0.f) ? gA[o] : 0.f);
+            gE[((long)(n - 1) * B + b) * H + h] = r * scale;
+        }
+        r = r + ((A[b * H + h] > 0.f) ? gA[b * H + h] : 0.f);
+        g_hp[b * H + h] = r;
     }
 }
 

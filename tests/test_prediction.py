@@ -1,0 +1,71 @@
+"""JointCodebookLoss (reference: quantization/prediction.py): drop-in surface on CPU, values and gradients against
+fixtures captured from the reference (tests/golden/make_golden_jcl.py) on the GPU."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FIXTURES = sorted(glob.glob(os.path.join(HERE, "golden", "jcl_*.npz")))
+
+
+def _module(fx, checkpoint):
+    from quantization_amd import JointCodebookLoss
+    m = JointCodebookLoss(predictor_channels=int(fx["pc"]), num_codebooks=int(fx["ncb"]), hidden_channels=int(fx["hidden"]),
+                          codebook_size=int(fx["K"]), reduction=str(fx["reduction"]), checkpoint=checkpoint)
+    sd = {k[len("state."):]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("state.")}
+    assert set(sd) == set(m.state_dict()) and all(tuple(sd[k].shape) == tuple(v.shape) for k, v in m.state_dict().items())
+    m.load_state_dict(sd)       # a reference checkpoint loads unchanged
+    return m
+
+
+def test_surface_and_no_cpu_fallback():
+    assert len(FIXTURES) == 3
+    from quantization_amd import _lib
+    fx = np.load(FIXTURES[0])
+    m = _module(fx, True)
+    with pytest.raises(_lib.McqError):
+        m(torch.from_numpy(fx["predictor"]), torch.from_numpy(fx["indexes"]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p)[:-4] for p in FIXTURES])
+@pytest.mark.parametrize("checkpoint", [True, False])
+def test_loss_and_gradients_match_the_reference(path, checkpoint):
+    fx = np.load(path)
+    m = _module(fx, checkpoint).cuda()
+    pred = torch.from_numpy(fx["predictor"]).cuda().requires_grad_(True)
+    idx = torch.from_numpy(fx["indexes"]).cuda()
+    loss = m(pred, idx)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(fx["loss"])) <= 1e-5 * abs(float(fx["loss"])), (float(loss.detach()), float(fx["loss"]))
+    got = {"grad_predictor": pred.grad}
+    got.update({"grad." + k: p.grad for k, p in m.named_parameters()})
+    for k, g in got.items():
+        ref = fx[k]
+        scale = max(np.abs(ref).max(), 1e-6)
+        err = np.abs(g.cpu().numpy() - ref).max()
+        assert err <= 1e-4 * scale, (k, err, scale)
+    # bit-reproducible (fixed-order scatter and reductions)
+    m.zero_grad()
+    pred2 = pred.detach().clone().requires_grad_(True)
+    loss2 = m(pred2, idx)
+    loss2.backward()
+    assert torch.equal(loss2.detach(), loss.detach()) and torch.equal(pred2.grad, pred.grad)
+
+
+@pytest.mark.gpu
+def test_uint8_codes_from_encode_feed_the_loss():
+    """the step after encode in the reference's integration script (test_train_hdf5.py:120-121)"""
+    from quantization_amd import JointCodebookLoss, Quantizer
+    torch.manual_seed(0)
+    q = Quantizer(64, 256, 4).cuda()
+    x = torch.randn(300, 64, device="cuda")
+    with torch.no_grad():
+        codes = q.encode(x)                       # uint8 (300, 4)
+    m = JointCodebookLoss(predictor_channels=64, num_codebooks=4, hidden_channels=128).cuda()
+    loss = m(x, codes)
+    loss.backward()
+    assert torch.isfinite(loss) and float(loss.detach()) > 0 and all(p.grad is not None for p in m.parameters())
