@@ -96,7 +96,8 @@ def _grads(q):
     return {n: p.grad.detach().clone() for n, p in q.named_parameters()}
 
 
-@pytest.mark.parametrize("D,K,N,B", [(64, 256, 4, 1000), (40, 16, 8, 333), (96, 64, 2, 257), (512, 256, 8, 4096), (128, 16, 16, 2048)])
+@pytest.mark.parametrize("D,K,N,B", [(64, 256, 4, 1000), (40, 16, 8, 333), (96, 64, 2, 257), (512, 256, 8, 4096), (128, 16, 16, 2048),
+                                     (32, 32, 4, 1), (32, 128, 2, 3), (48, 16, 64, 65)])
 @pytest.mark.parametrize("iters", [0, 2])
 def test_fused_loss_kernels_match_the_torch_op_formulation(D, K, N, B, iters):
     """compute_loss through mcq_logits_argmax / mcq_recon_fwd / mcq_loss_fwd / mcq_loss_bwd vs the reference's

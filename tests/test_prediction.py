@@ -69,3 +69,39 @@ def test_uint8_codes_from_encode_feed_the_loss():
     loss = m(x, codes)
     loss.backward()
     assert torch.isfinite(loss) and float(loss.detach()) > 0 and all(p.grad is not None for p in m.parameters())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,P,N,H,K", [(1, 8, 2, 16, 16), (3, 20, 3, 70, 32), (130, 33, 5, 96, 128)])
+def test_ragged_sizes_against_the_torch_op_sequence(B, P, N, H, K):
+    """sizes the fixtures do not hold (single frame, odd channel counts, codebook counts that are not powers of two)
+    against the reference's op sequence (prediction.py:38-81) written with torch ops on the same device"""
+    import torch.nn.functional as F
+    from quantization_amd import JointCodebookLoss
+    torch.manual_seed(B)
+    m = JointCodebookLoss(P, N, H, K, reduction="mean", checkpoint=False).cuda()
+    pred = torch.randn(B, P, device="cuda", requires_grad=True)
+    idx = torch.randint(0, K, (B, N), device="cuda")
+    if B > 2:
+        idx[1] = -100
+
+    def ref():
+        first = idx[:, :-1].clamp(min=0) + torch.arange(0, (N - 1) * K, step=K, device=idx.device)
+        emb = F.embedding(first, m.codebook_embedding.weight) * (0.5 * ((H / N) ** 0.5))
+        a = torch.relu(torch.cumsum(torch.cat((m.linear1(pred).unsqueeze(1), emb), dim=1), dim=1))
+        lp = torch.matmul(a.transpose(0, 1), m.linear2_weight.transpose(1, 2)).transpose(0, 1)
+        lp = lp + torch.matmul(pred, m.linear2b_weight.transpose(1, 2)).transpose(0, 1) + m.linear2_bias
+        return F.cross_entropy(lp.reshape(-1, K), idx.reshape(-1), ignore_index=-100, reduction="mean")
+
+    grads = []
+    for fn in (lambda: m(pred, idx), ref):
+        m.zero_grad()
+        pred.grad = None
+        loss = fn()
+        loss.backward()
+        grads.append((loss.detach(), pred.grad.clone(), {k: p.grad.clone() for k, p in m.named_parameters()}))
+    (la, ga, pa), (lb, gb, pb) = grads
+    assert abs(float(la) - float(lb)) <= 1e-5 * abs(float(lb))
+    assert float((ga - gb).abs().max()) <= 1e-4 * float(gb.abs().max() + 1e-9)
+    for k in pa:
+        assert float((pa[k] - pb[k]).abs().max()) <= 1e-4 * float(pb[k].abs().max() + 1e-9), k
