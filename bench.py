@@ -102,6 +102,9 @@ def main():
     ap.add_argument("--refine-iters", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event pass (for PMC runs)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary figures (skipping mode, host-resident / fp16 input, decode): every kernel "
+                         "launch of the run then has the headline shape (for rocprofv3 averages)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -228,6 +231,12 @@ def main():
                      "avg_launch_ms": round(float(dom_ms), 4)},
         "kernels": kernels,
     }
+    if args.no_secondary:
+        print(json.dumps(out), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     # ---- secondary: the same encode with fixed-point skipping (identical codes, data-dependent cost;
     # never the headline value: BASELINE's metric is the reference's fixed 5-pass work)
     with torch.no_grad():
