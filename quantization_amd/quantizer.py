@@ -11,6 +11,7 @@ import binascii
 import ctypes
 import math
 import os
+import weakref
 
 import torch
 from torch import Tensor, nn
@@ -21,11 +22,33 @@ from . import _lib
 # The derived device state (_prepared) is cached per parameter version.  torch's fused optimizers
 # (Adam(fused=True) ...) update parameters WITHOUT bumping Tensor._version (measured: tools/exp_version.py),
 # so every optimizer step, of any optimizer, also advances this epoch, which is part of the cache key.
+# Only optimizers that hold a Quantizer parameter count: a frozen quantizer used inside the training loop of
+# another model (codes as targets for JointCodebookLoss) keeps its cached state across that model's steps.
 _param_epoch = [0]
+_quantizer_params = {}                      # id(parameter) -> weakref(parameter), filled by Quantizer._prepared
+_optimizer_hits = weakref.WeakKeyDictionary()   # optimizer -> (number of parameters seen, holds a quantizer parameter)
 
 
-def _note_optimizer_step(*_args, **_kwargs):
-    _param_epoch[0] += 1
+def _note_optimizer_step(optimizer, *_args, **_kwargs):
+    try:
+        nparams = sum(len(g["params"]) for g in optimizer.param_groups)
+        known = _optimizer_hits.get(optimizer)
+        if known is None or known[0] != nparams or known[2] != len(_quantizer_params):
+            hit = False
+            for g in optimizer.param_groups:
+                for q in g["params"]:
+                    r = _quantizer_params.get(id(q))
+                    if r is not None and r() is q:
+                        hit = True
+                        break
+                if hit:
+                    break
+            known = (nparams, hit, len(_quantizer_params))
+            _optimizer_hits[optimizer] = known
+        if known[1]:
+            _param_epoch[0] += 1
+    except Exception:                       # an exotic optimizer object: stay on the safe side
+        _param_epoch[0] += 1
 
 
 from torch.optim.optimizer import register_optimizer_step_post_hook as _register_step_hook  # noqa: E402
@@ -115,6 +138,12 @@ class Quantizer(nn.Module):
         the host's by an ulp); decode (`any_flavour`) takes whichever is current."""
         ps = (self.centers, self.centers_scale, self.logits_scale, self.to_logits.weight, self.to_logits.bias)
         training = torch.is_grad_enabled() and any(p.requires_grad for p in ps)
+        for p in ps:
+            if id(p) not in _quantizer_params or _quantizer_params[id(p)]() is not p:
+                if len(_quantizer_params) > 4096:     # drop entries of collected modules
+                    for k_ in [k_ for k_, r_ in _quantizer_params.items() if r_() is None]:
+                        del _quantizer_params[k_]
+                _quantizer_params[id(p)] = weakref.ref(p)
         key = tuple((p.data_ptr(), p._version, str(p.device)) for p in ps) + (_param_epoch[0],)
         if self._prep is not None and self._prep[0] == key and (self._prep[2] == "host" or training or any_flavour):
             return self._prep[1]

@@ -368,6 +368,15 @@ def test_derived_state_follows_fused_optimizer_steps():
     after = q.encode(x, 2)
     q2 = load_quantizer({k: v.detach().cpu().numpy() for k, v in q.state_dict().items()}, fx["D"], fx["K"], fx["N"])
     assert torch.equal(after, q2.encode(x, 2)) and not torch.equal(after, before)
+    # an optimizer that holds no quantizer parameter leaves the cached state alone (frozen quantizer inside
+    # another model's training loop)
+    cached = q._prepared()
+    other = torch.nn.Linear(4, 4).cuda()
+    opt2 = torch.optim.Adam(other.parameters(), fused=True)
+    for p in other.parameters():
+        p.grad = torch.ones_like(p)
+    opt2.step()
+    assert q._prepared() is cached
     with torch.no_grad():
         q.centers.data.mul_(-1.0)          # unversioned edit: the documented escape hatch
     q.invalidate_cache()
