@@ -206,7 +206,8 @@ class Quantizer(nn.Module):
         x2d = x2d.detach().contiguous() if x_fp16 else x2d.detach().to(torch.float32).contiguous()
         B = x2d.shape[0]
         dev = x2d.device
-        blob = self._prepared()
+        with torch.no_grad():       # the public search always uses host-formed scale factors (the reference's, bit for bit),
+            blob = self._prepared()  # whatever the caller's autograd mode; the trainer's own path keeps them on the device
         pack = 2 if (as_bytes and K == 16 and N >= 2) else 1
         if as_bytes:
             out = torch.empty((B, N // pack), dtype=torch.uint8, device=dev)
@@ -302,7 +303,8 @@ class Quantizer(nn.Module):
         out = torch.empty_like(idx)
         if B == 0:
             return out
-        blob = self._prepared()
+        with torch.no_grad():
+            blob = self._prepared()
         ws = self._workspace(B, x2d.device)
         with torch.cuda.device(x2d.device):
             st = torch.cuda.current_stream(x2d.device).cuda_stream

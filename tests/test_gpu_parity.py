@@ -382,3 +382,16 @@ def test_derived_state_follows_fused_optimizer_steps():
     q.invalidate_cache()
     q3 = load_quantizer({k: v.detach().cpu().numpy() for k, v in q.state_dict().items()}, fx["D"], fx["K"], fx["N"])
     assert torch.equal(q.encode(x, 2), q3.encode(x, 2))
+
+
+def test_encode_does_not_depend_on_the_callers_autograd_mode():
+    fx = fixtures.load("trained_d64_b8_p2")
+    q = load_quantizer(fx["state"], fx["D"], fx["K"], fx["N"])
+    x = torch.from_numpy(fx["x"][:777]).cuda()
+    want = q.encode(x, 3)
+    with torch.enable_grad():
+        assert all(p.requires_grad for p in q.parameters())
+        got = q.encode(x, 3)
+        got_idx = q._compute_indexes(x, 3)
+    assert torch.equal(got, want) and torch.equal(got_idx.to(torch.uint8), want)
+    fixtures.check_codes(fx, 5, q.encode(torch.from_numpy(fx["x"]).cuda(), 5).cpu().numpy(), "enable_grad encode")
