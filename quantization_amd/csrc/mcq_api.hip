@@ -220,7 +220,7 @@ int launch_pair_t(const float *C, const uint8_t *idx, const float *E, const uint
                            S_in, B, N, K, Dp, Gout, keep, win, tup_out, S_out, idx_final, nact);                      \
         return 0;                                                                                                     \
     }
-    MCQ_PAIR_ABL_CASE(1) MCQ_PAIR_ABL_CASE(2) MCQ_PAIR_ABL_CASE(3) MCQ_PAIR_ABL_CASE(4)
+    MCQ_PAIR_ABL_CASE(1) MCQ_PAIR_ABL_CASE(2) MCQ_PAIR_ABL_CASE(3) MCQ_PAIR_ABL_CASE(4) MCQ_PAIR_ABL_CASE(5) MCQ_PAIR_ABL_CASE(6)
 #undef MCQ_PAIR_ABL_CASE
     if (xl)
         hipLaunchKernelGGL((k_pair<L, KI, true>), dim3(grid), dim3(64 * wpb), per_wave * wpb, st, C, idx, E, tup_in, S_in, B,

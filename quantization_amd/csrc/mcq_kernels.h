@@ -1115,7 +1115,7 @@ k_pair(const float *__restrict__ C, const uint8_t *__restrict__ idx, const float
     for (int w0 = 0; w0 < (ABL == 1 ? 0 : Dp); w0 += win) {
         const int wlen = (Dp - w0 < win) ? (Dp - w0) : win;
         if (w0 > 0) wave_lds_fence();      // every read of the previous window has been issued
-        stage_old(w0, wlen);
+        if constexpr (ABL != 5) stage_old(w0, wlen);     // 5: old rows left as found (timing only)
         wave_lds_fence();
         const int kb_lo = w0 / 16, nkb = wlen / 16;   // k-blocks of this window
         const float *oldp = oldwin + 4 * ps;          // this lane's piece within a k-block of the window
@@ -1271,7 +1271,12 @@ k_pair(const float *__restrict__ C, const uint8_t *__restrict__ idx, const float
         }
     float ov;
     int op;
-    wave_select_fast<VPL>(sv, sp, keep, M, scratch, ov, op);
+    if constexpr (ABL == 6) {        // 6: no final selection (timing only)
+        ov = sv[0];
+        op = sp[0] & (M - 1);
+    } else {
+        wave_select_fast<VPL>(sv, sp, keep, M, scratch, ov, op);
+    }
     // lane j < keep owns output candidate j = (a, bb) in the input lists
     const int a = (lane < keep ? op : 0) / KI, bb = (lane < keep ? op : 0) % KI;
     uint32_t we = 0, wo = 0;
