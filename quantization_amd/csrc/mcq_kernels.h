@@ -1137,6 +1137,40 @@ k_pair(const float *__restrict__ C, const uint8_t *__restrict__ idx, const float
                         }
             };
             auto compute_batch = [&](const f32x4 (&ra)[UNR][TI][L], const f32x4 (&rb)[UNR][TI][L], int kb0) {
+                if constexpr (XL && ABL == 0) {
+                    // LDS-tile transposition, batched: every `old` read and subtraction of the batch first, then the
+                    // tile writes / reads as VOLATILE accesses (kept in program order by the compiler, executed in
+                    // order by the LDS: a slot is reused by the next k-block without any wait), so the only
+                    // lgkmcnt waits left are the counted ones in front of the MFMAs.
+                    f32x4 d[UNR][2][TI], o[UNR][2][TI];
+#pragma unroll
+                    for (int u = 0; u < UNR; ++u)
+#pragma unroll
+                        for (int ti = 0; ti < TI; ++ti) {
+                            d[u][0][ti] = DeltaBuilder<L>::template build<L>(ra[u][ti], oldp, win, 0, 16 * (kb0 + u));
+                            d[u][1][ti] = DeltaBuilder<L>::template build<L>(rb[u][ti], oldp + L * win, win, 0, 16 * (kb0 + u));
+                        }
+                    typedef __attribute__((address_space(3))) volatile f32x4 lds_vf4;   // keep the accesses DS (not FLAT)
+                    lds_vf4 *vt = (lds_vf4 *)xpose;
+#pragma unroll
+                    for (int u = 0; u < UNR; ++u) {
+#pragma unroll
+                        for (int sd = 0; sd < 2; ++sd)
+#pragma unroll
+                            for (int ti = 0; ti < TI; ++ti) vt[(sd * TI + ti) * 64 + xw] = d[u][sd][ti];
+#pragma unroll
+                        for (int sd = 0; sd < 2; ++sd)
+#pragma unroll
+                            for (int ti = 0; ti < TI; ++ti) {
+                                f32x4 t = vt[(sd * TI + ti) * 64 + xr];
+                                if (KI < 16 && !(sd == 0 ? validA[ti] : validB[ti])) t = (f32x4){0.f, 0.f, 0.f, 0.f};
+                                o[u][sd][ti] = t;
+                            }
+                    }
+#pragma unroll
+                    for (int u = 0; u < UNR; ++u) mfma_block(o[u][0], o[u][1]);
+                    return;
+                }
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
                     f32x4 da[TI], db[TI];
