@@ -239,6 +239,19 @@ int launch_pair(int L, int KI, const float *C, const uint8_t *idx, const float *
     if (L == LL && KI == KK)                                                                                      \
         return launch_pair_t<LL, KK>(C, idx, E, tup_in, S_in, B, N, K, Dp, Gout, keep, tup_out, S_out, idx_final, nact, \
                                      st);
+    // 8-candidate lists (16-entry codebooks): two output groups per wave (MCQ_PAIR8=0: the generic kernel; tuning hook)
+    static const bool pair8 = !(getenv("MCQ_PAIR8") && atoi(getenv("MCQ_PAIR8")) == 0);
+    if (pair8 && KI == 8 && (L == 1 || L == 2)) {
+        const unsigned grid = (unsigned)(B * ((Gout + 1) / 2));
+        if (L == 1)
+            hipLaunchKernelGGL((k_pair8<1>), dim3(grid), dim3(64), kSelectLdsU64 * 8, st, C, idx, E, tup_in, S_in, B, N, K, Dp,
+                               Gout, keep, tup_out, S_out, idx_final, nact);
+        else
+            hipLaunchKernelGGL((k_pair8<2>), dim3(grid), dim3(64), kSelectLdsU64 * 8, st, C, idx, E, tup_in, S_in, B, N, K, Dp,
+                               Gout, keep, tup_out, S_out, idx_final, nact);
+        MCQ_LAUNCH_CHECK();
+        return 0;
+    }
     // K >= 32 ladders: 16,16,32,32,64 ; K == 16 ladders: 8,8,16,16,32,32
     MCQ_PAIR_CASE(1, 16)
     MCQ_PAIR_CASE(2, 16)

@@ -1332,6 +1332,126 @@ k_pair(const float *__restrict__ C, const uint8_t *__restrict__ idx, const float
     }
 }
 
+// ------------------------------------------------- pair combine, 8-candidate lists
+// The ladders of 16-entry codebooks (the trainer's first phase) combine lists of 8 candidates: 8 x 8 scores fill
+// a quarter of a 16 x 16 MFMA tile.  This kernel packs TWO output groups into one wave: MFMA rows 0-7 / columns 0-7
+// belong to output group 2*gp, rows 8-15 / columns 8-15 to group 2*gp + 1 (the off-diagonal blocks are computed and
+// dropped), so a stage needs half the waves and half the MFMAs of k_pair<L, 8>.  Same arithmetic, operand order and
+// selection as k_pair: results are bit-identical.  `old` rows are read straight from L2 (each is shared by the 8
+// rows of its half: two 64-byte segments per load), so there is no staging prologue.  L in {1, 2}.
+template <int L>
+__global__ void __launch_bounds__(64)
+k_pair8(const float *__restrict__ C, const uint8_t *__restrict__ idx, const float *__restrict__ E,
+        const uint8_t *__restrict__ tup_in /*[B][Gin][8][L]*/, const float *__restrict__ S_in /*[B][Gin][8]*/, long B,
+        int N, int K, int Dp, int Gout, int keep, uint8_t *__restrict__ tup_out /*[B][Gout][keep][2L]*/,
+        float *__restrict__ S_out, uint8_t *__restrict__ idx_final, const int *__restrict__ nact) {
+    constexpr int KI = 8;
+    if (nact) B = *nact;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u64 *scratch = reinterpret_cast<u64 *>(smem);
+    const int GP = (Gout + 1) / 2;
+    const int gp = (int)(blockIdx.x % (unsigned)GP);
+    const long b = (long)(blockIdx.x / (unsigned)GP);
+    if (b >= B) return;
+    const int lane = lane_id();
+    const int r = lane & 15, g = lane >> 4;
+    const int Gin = 2 * Gout;
+    // load layout: lane 4*rs + ps reads float4 ps of the k-block of packed row rs (half rs / 8, candidate rs % 8)
+    const int rs = lane >> 2, ps = (lane & 3) ^ ((lane >> 5) << 1);
+    const int perm_addr = (4 * r + (g ^ ((r >> 3) << 1))) << 2;
+    const int hl = rs >> 3, cl = rs & 7;                          // this lane's half / candidate in the load layout
+    const int go_l = (2 * gp + hl < Gout) ? 2 * gp + hl : 2 * gp;   // an absent second half re-reads the first (dropped later)
+    const int n0_l = 2 * go_l * L;
+    const uint8_t *te_l = tup_in + ((b * Gin + 2 * go_l) * KI) * (long)L;
+    const uint8_t *to_l = tup_in + ((b * Gin + 2 * go_l + 1) * KI) * (long)L;
+    uint32_t coff[2][L], ooff[2][L];     // byte offsets of this lane's piece: candidate leaves / old leaves, per side
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+        coff[0][j] = 4u * (uint32_t)(((n0_l + j) * K + te_l[cl * L + j]) * Dp + 4 * ps);
+        coff[1][j] = 4u * (uint32_t)(((n0_l + L + j) * K + to_l[cl * L + j]) * Dp + 4 * ps);
+        ooff[0][j] = 4u * (uint32_t)(((n0_l + j) * K + idx[b * N + n0_l + j]) * Dp + 4 * ps);
+        ooff[1][j] = 4u * (uint32_t)(((n0_l + L + j) * K + idx[b * N + n0_l + L + j]) * Dp + 4 * ps);
+    }
+    // epilogue inputs, requested now: E, and the list scores of this lane's MFMA rows / column
+    const float Eb = E[b];
+    const int hrow = g >> 1, hcol = r >> 3;                     // half of this lane's rows 4g+v / of its column r
+    const int go_row = (2 * gp + hrow < Gout) ? 2 * gp + hrow : 2 * gp;
+    const int go_col = (2 * gp + hcol < Gout) ? 2 * gp + hcol : 2 * gp;
+    float se_pre[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) se_pre[v] = S_in[(b * Gin + 2 * go_row) * (long)KI + ((4 * g + v) & 7)];
+    const float so_pre = S_in[(b * Gin + 2 * go_col + 1) * (long)KI + (r & 7)];
+
+    const char *Cb = reinterpret_cast<const char *>(C);
+    auto gather = [&](f32x4 (&c)[2][L], f32x4 (&o)[2][L], int kb) {
+#pragma unroll
+        for (int sd = 0; sd < 2; ++sd)
+#pragma unroll
+            for (int j = 0; j < L; ++j) {
+                c[sd][j] = *reinterpret_cast<const f32x4 *>(Cb + (coff[sd][j] + (uint32_t)(64 * kb)));
+                o[sd][j] = *reinterpret_cast<const f32x4 *>(Cb + (ooff[sd][j] + (uint32_t)(64 * kb)));
+            }
+    };
+    auto operand = [&](const f32x4 (&c)[L], const f32x4 (&o)[L]) {
+        f32x4 d = c[0] - o[0];                              // leaves c - old (:436-439) ...
+        if constexpr (L == 2) d = d + (c[1] - o[1]);        // ... summed up the combine tree (:538-541)
+        f32x4 t;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t[q] = __int_as_float(__builtin_amdgcn_ds_bpermute(perm_addr, __float_as_int(d[q])));
+        return t;
+    };
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int nkb = Dp / 16;
+    f32x4 c0[2][L], o0[2][L], c1[2][L], o1[2][L];
+    gather(c0, o0, 0);
+    for (int kb = 0; kb < nkb; kb += 2) {
+        const int k1 = (kb + 1 < nkb) ? kb + 1 : kb, k2 = (kb + 2 < nkb) ? kb + 2 : kb;   // clamped: harmless re-reads
+        gather(c1, o1, k1);
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const f32x4 da = operand(c0[0], o0[0]), db = operand(c0[1], o0[1]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(da[i], db[i], acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        gather(c0, o0, k2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kb + 1 < nkb) {   // uniform
+            const f32x4 da = operand(c1[0], o1[0]), db = operand(c1[1], o1[1]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(da[i], db[i], acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // scores of the two diagonal 8 x 8 blocks; one selection per half
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {
+        const int go = 2 * gp + h;
+        if (go >= Gout) break;   // uniform
+        float sv[4];
+        int sp[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int a = 4 * g + v;
+            const bool ok = (hrow == h) && (hcol == h);
+            sv[v] = ok ? ((se_pre[v] + so_pre) - Eb) + 2.0f * acc[v] : INFINITY;
+            sp[v] = ok ? (a & 7) * KI + (r & 7) : kBigPos;
+        }
+        float ov;
+        int op;
+        wave_select_fast<4>(sv, sp, keep, KI * KI, scratch, ov, op);
+        if (lane < keep) {
+            const int a = op / KI, bb = op % KI;
+            const uint8_t *te = tup_in + ((b * Gin + 2 * go) * KI) * (long)L;
+            const uint8_t *to = tup_in + ((b * Gin + 2 * go + 1) * KI) * (long)L;
+            uint8_t *o = (idx_final != nullptr) ? idx_final + b * N : tup_out + ((b * Gout + go) * (long)keep + lane) * (2 * L);
+#pragma unroll
+            for (int j = 0; j < L; ++j) { o[j] = te[a * L + j]; o[L + j] = to[bb * L + j]; }
+            if (idx_final == nullptr) S_out[(b * Gout + go) * (long)keep + lane] = ov;
+        }
+    }
+}
+
 // ------------------------------------------------------- fixed-point skipping
 // _refine_indexes is a deterministic map F of (x, indexes): once F(idx) == idx every later pass
 // returns idx again, so such a vector can leave the active list without changing any result.
