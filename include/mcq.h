@@ -176,6 +176,11 @@ int mcq_jcl_prefix_bwd(const float *A, const float *gA, long B, int N, int H, fl
 int mcq_scatter_rows(const float *grad, long stride_b, long stride_n, const int64_t *idx, int idx_stride, long B,
                      int N, int K, int D, float *out, void *stream);
 
+/* mcq_decode_backward on unpacked uint8 codes [B][N] (K <= 256): same sums in the same order; the kernel is
+ * bound by scanning the index column, which is 8x smaller this way (what the trainer's step uses).      */
+int mcq_decode_backward_u8(const float *grad_out, const uint8_t *codes, long B, int N, int K, int D, float *gC,
+                           void *stream);
+
 /* ---- test / profiling hooks -------------------------------------------------
  * Logits of Quantizer._logits (:277-279) for a batch, fp32 [B][N*K]; used by the
  * parity tests to localise a divergence.                                       */

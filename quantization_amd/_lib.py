@@ -14,7 +14,7 @@ SYMBOLS = (
     "mcq_abi_version", "mcq_padded_dim", "mcq_prepared_bytes", "mcq_prepare", "mcq_prepare_dev", "mcq_encode_workspace_bytes",
     "mcq_encode", "mcq_encode_ex", "mcq_refine_indexes", "mcq_decode", "mcq_decode_backward", "mcq_logits", "mcq_last_encode_launches", "mcq_profile_encode",
     "mcq_logits_argmax", "mcq_loss_workspace_bytes", "mcq_loss_fwd", "mcq_loss_bwd", "mcq_recon_fwd", "mcq_loss_tail",
-    "mcq_jcl_prefix_fwd", "mcq_jcl_prefix_bwd", "mcq_scatter_rows",
+    "mcq_jcl_prefix_fwd", "mcq_jcl_prefix_bwd", "mcq_scatter_rows", "mcq_decode_backward_u8",
 )
 
 MCQ_EINVAL, MCQ_EUNSUPPORTED, MCQ_EWORKSPACE = -1, -2, -3
@@ -73,6 +73,8 @@ def lib():
     L.mcq_jcl_prefix_fwd.argtypes = [vp, vp, vp, i64, i32, i32, i32, f32, vp, vp]
     L.mcq_jcl_prefix_bwd.restype = i32
     L.mcq_jcl_prefix_bwd.argtypes = [vp, vp, i64, i32, i32, f32, vp, vp, vp]
+    L.mcq_decode_backward_u8.restype = i32
+    L.mcq_decode_backward_u8.argtypes = [vp, vp, i64, i32, i32, i32, vp, vp]
     L.mcq_scatter_rows.restype = i32
     L.mcq_scatter_rows.argtypes = [vp, i64, i64, vp, i32, i64, i32, i32, i32, vp, vp]
     L.mcq_last_encode_launches.restype = i32

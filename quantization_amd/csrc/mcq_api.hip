@@ -576,8 +576,20 @@ int mcq_decode_backward(const float *grad_out, const int64_t *idx, long B, int N
     if (B > 0 && (!grad_out || !idx)) return MCQ_EINVAL;
     const int chunks = (D + 63) / 64;
     const long waves = (long)N * K * chunks;
-    hipLaunchKernelGGL(k_decode_backward, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0,
+    hipLaunchKernelGGL((k_decode_backward<int64_t>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), grad_out, idx, B, N, K, D, chunks, gC, (long)D, 0L, N);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+int mcq_decode_backward_u8(const float *grad_out, const uint8_t *codes, long B, int N, int K, int D, float *gC,
+                           void *stream) {
+    if (N <= 0 || K <= 0 || K > 256 || D <= 0 || B < 0 || !gC) return MCQ_EINVAL;
+    if (B > 0 && (!grad_out || !codes)) return MCQ_EINVAL;
+    const int chunks = (D + 63) / 64;
+    const long waves = (long)N * K * chunks;
+    hipLaunchKernelGGL((k_decode_backward<uint8_t>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), grad_out, codes, B, N, K, D, chunks, gC, (long)D, 0L, N);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
@@ -588,7 +600,7 @@ int mcq_scatter_rows(const float *grad, long stride_b, long stride_n, const int6
     if (B > 0 && (!grad || !idx)) return MCQ_EINVAL;
     const int chunks = (D + 63) / 64;
     const long waves = (long)N * K * chunks;
-    hipLaunchKernelGGL(k_decode_backward, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0,
+    hipLaunchKernelGGL((k_decode_backward<int64_t>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), grad, idx, B, N, K, D, chunks, out, stride_b, stride_n, idx_stride);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;

@@ -1672,7 +1672,8 @@ __global__ void k_decode_reg(const uint8_t *__restrict__ codes, long B, const fl
 // Matching rows are fetched eight at a time so the loads overlap; the adds stay in order.
 // Generalised to per-(vector, codebook) gradients: the value added for vector b into row (n, k) is
 // gout[b * gsb + n * gsn + d] (decode: gsb = D, gsn = 0); idx[b * idx_stride + n]; negative indexes match no row.
-__global__ void k_decode_backward(const float *__restrict__ gout, const int64_t *__restrict__ idx, long B, int N, int K,
+template <typename IdxT>   // int64 indexes, or uint8 codes (8x less index traffic: the scan is what bounds this kernel)
+__global__ void k_decode_backward(const float *__restrict__ gout, const IdxT *__restrict__ idx, long B, int N, int K,
                                   int D, int chunks, float *__restrict__ gC, long gsb, long gsn, int idx_stride) {
     const long w = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (w >= (long)N * K * chunks) return;
@@ -1683,23 +1684,35 @@ __global__ void k_decode_backward(const float *__restrict__ gout, const int64_t 
     const int dc = dok ? d : 0;
     const int n = (int)(row / K), k = (int)(row % K);
     float acc = 0.f;
-    for (long b0 = 0; b0 < B; b0 += 64) {
-        const long b = b0 + lane;
-        const bool hit = (b < B) && (idx[b * idx_stride + n] == k);
-        unsigned long long m = __ballot(hit);
-        while (m) {
-            float v[8];
+    // index loads in flight per scan step: with 1-byte codes several steps' worth are fetched together (with
+    // 8-byte indexes that floods the L1 with uncoalesced lines and measured slower)
+    constexpr int SC = sizeof(IdxT) == 1 ? 8 : 1;
+    for (long bs = 0; bs < B; bs += 64 * SC) {
+        long iv[SC];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                v[u] = 0.f;
-                if (m) {   // wave-uniform
-                    const int l = __ffsll((long long)m) - 1;
-                    m &= m - 1;
-                    v[u] = gout[(b0 + l) * gsb + n * gsn + dc];
+        for (int q = 0; q < SC; ++q) {
+            const long b = bs + 64 * q + lane;
+            iv[q] = (long)idx[(b < B ? b : B - 1) * idx_stride + n];
+        }
+#pragma unroll
+        for (int q = 0; q < SC; ++q) {
+            const long b0 = bs + 64 * q;
+            const bool hit = (b0 + lane < B) && (iv[q] == (long)k);
+            unsigned long long m = __ballot(hit);
+            while (m) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    v[u] = 0.f;
+                    if (m) {   // wave-uniform
+                        const int l = __ffsll((long long)m) - 1;
+                        m &= m - 1;
+                        v[u] = gout[(b0 + l) * gsb + n * gsn + dc];
+                    }
                 }
-            }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc = acc + v[u];   // x + 0 is exact: padding slots change nothing
+                for (int u = 0; u < 8; ++u) acc = acc + v[u];   // x + 0 is exact: padding slots change nothing
+            }
         }
     }
     if (dok) gC[row * D + d] = acc;

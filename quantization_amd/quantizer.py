@@ -558,8 +558,9 @@ def _loss_backward_kernels(module, st_: _LossState, g_num, g_chosen, g_prob, cen
         st = torch.cuda.current_stream(dev).cuda_stream
         if g_num is not None:
             gC = torch.empty((N, K, D), **f32)
-            _lib.check(L.mcq_decode_backward(st_.err.data_ptr(), st_.idx.data_ptr(), B, N, K, D, gC.data_ptr(), st),
-                       "mcq_decode_backward")
+            codes = st_.idx.to(torch.uint8)         # the scatter is bound by scanning the index column: 1 byte, not 8
+            _lib.check(L.mcq_decode_backward_u8(st_.err.data_ptr(), codes.data_ptr(), B, N, K, D, gC.data_ptr(), st),
+                       "mcq_decode_backward_u8")
             f = (centers_scale.detach() * speed).exp() * (2.0 * g_num)          # scalar tensor
             g_centers = gC * f
             g_cscale = torch.dot(gC.reshape(-1), centers.detach().reshape(-1)) * (f * speed)
