@@ -215,6 +215,7 @@ int launch_pair_t(const float *C, const uint8_t *idx, const float *E, const uint
     const unsigned grid = (unsigned)(((B + wpb - 1) / wpb) * Gout);
     static const int abl = getenv("MCQ_PAIR_ABL") ? atoi(getenv("MCQ_PAIR_ABL")) : 0;   // timing experiments (wrong results)
 #define MCQ_PAIR_ABL_CASE(A)                                                                                          \
+    if constexpr ((L == 1 && KI == 16) || (L == 2 && KI == 16) || (L == 4 && KI == 32)) /* headline ladder only */      \
     if (abl == A) {                                                                                                   \
         hipLaunchKernelGGL((k_pair<L, KI, false, A>), dim3(grid), dim3(64 * wpb), per_wave * wpb, st, C, idx, E, tup_in,  \
                            S_in, B, N, K, Dp, Gout, keep, win, tup_out, S_out, idx_final, nact);                      \
