@@ -290,6 +290,17 @@ int launch_residual(const float *x, const uint8_t *idx, const float *C, long B, 
     MCQ_RES_CASE(2, 1)
     MCQ_RES_CASE(2, 2)
 #undef MCQ_RES_CASE
+    // long rows (J > 2 float4 columns per lane) with many codebooks: chunked register variant
+    if (J > 2 && N == 16) {
+        hipLaunchKernelGGL((k_residual_regc<16, 2>), grid, block, 0, st, x, idx, C, B, K, D, Dp, xerr, E, R, nact, map, xh);
+        MCQ_LAUNCH_CHECK();
+        return 0;
+    }
+    if (J > 2 && N == 8) {
+        hipLaunchKernelGGL((k_residual_regc<8, 2>), grid, block, 0, st, x, idx, C, B, K, D, Dp, xerr, E, R, nact, map, xh);
+        MCQ_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(k_residual, grid, block, 0, st, x, idx, C, B, N, K, D, Dp, xerr, E, R, nact, map, xh);
     MCQ_LAUNCH_CHECK();
     return 0;

@@ -408,6 +408,79 @@ __global__ void k_residual_reg(const float *__restrict__ x, const uint8_t *__res
     }
 }
 
+// Same, for rows too long to keep whole in registers (dim 1024 with 8 or 16 codebooks): the J float4 columns of a
+// lane are walked in chunks of JC; each chunk's NN x JC row pieces stay in registers between the x_err and the R[n]
+// use.  The per-lane chains of E and R[n] run over ascending q = lane + 64 j exactly as in k_residual.
+template <int NN, int JC>
+__global__ void k_residual_regc(const float *__restrict__ x, const uint8_t *__restrict__ idx,
+                                const float *__restrict__ C, long B, int K, int D, int Dp,
+                                float *__restrict__ xerr, float *__restrict__ E, float *__restrict__ R,
+                                const int *__restrict__ nact, const int *__restrict__ map, int xh /* x is fp16 */) {
+    const long b = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (nact) B = *nact;
+    if (b >= B) return;
+    const int lane = lane_id();
+    const uint8_t *id = idx + b * NN;
+    const float *xb = x + (map ? (long)map[b] : b) * D;
+    const _Float16 *xbh = reinterpret_cast<const _Float16 *>(x) + (map ? (long)map[b] : b) * D;
+    float *xe = xerr + b * Dp;
+    const bool vec_ok = ((D & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & (xh ? 7 : 15)) == 0);
+    const int nq = Dp / 4;
+    const float *rowp[NN];
+#pragma unroll
+    for (int n = 0; n < NN; ++n) rowp[n] = C + ((long)n * K + id[n]) * Dp;
+    float pe = 0.f, pr[NN];
+#pragma unroll
+    for (int n = 0; n < NN; ++n) pr[n] = 0.f;
+    for (int j0 = 0; 64 * j0 < nq; j0 += JC) {
+        f32x4 rows[NN][JC];
+#pragma unroll
+        for (int n = 0; n < NN; ++n)
+#pragma unroll
+            for (int j = 0; j < JC; ++j) {
+                const int q = lane + 64 * (j0 + j);
+                rows[n][j] = *reinterpret_cast<const f32x4 *>(rowp[n] + 4 * (q < nq ? q : 0));
+            }
+#pragma unroll
+        for (int j = 0; j < JC; ++j) {
+            const int q = lane + 64 * (j0 + j);
+            if (q < nq) {
+                f32x4 t = rows[0][j];
+#pragma unroll
+                for (int n = 1; n < NN; ++n) t = t + rows[n][j];
+                f32x4 xv;
+                if (vec_ok && 4 * q + 3 < D) {
+                    xv = xh ? load_h4(xbh + 4 * q) : *reinterpret_cast<const f32x4 *>(xb + 4 * q);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int kc = (4 * q + c < D) ? 4 * q + c : 0;
+                        const float val = xh ? (float)xbh[kc] : xb[kc];
+                        xv[c] = (4 * q + c < D) ? val : 0.f;
+                    }
+                }
+                t = t - xv;
+                *reinterpret_cast<f32x4 *>(xe + 4 * q) = t;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) pe = fmaf(t[c], t[c], pe);
+#pragma unroll
+                for (int n = 0; n < NN; ++n) {
+                    const f32x4 u = t - rows[n][j];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) pr[n] = fmaf(u[c], u[c], pr[n]);
+                }
+            }
+        }
+    }
+    pe = wave_sum_butterfly(pe);
+    if (lane == 0) E[b] = pe;
+#pragma unroll
+    for (int n = 0; n < NN; ++n) {
+        const float v = wave_sum_butterfly(pr[n]);
+        if (lane == 0) R[b * NN + n] = v;
+    }
+}
+
 // ---------------------------------------------------------------------- GEMM
 // out[b][n][k] = dot16(Bm[n][k][:], A_n[b][:]) for a 64-vector tile and one
 // codebook n per workgroup (4 waves, wave w owns vectors 16w..16w+15 and all

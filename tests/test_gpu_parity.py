@@ -182,7 +182,7 @@ def test_refine_indexes_from_given_start():
     assert torch.equal(idx, q._compute_indexes(torch.from_numpy(x).cuda(), 2))
 
 
-@pytest.mark.parametrize("D,K,N", [(1, 16, 2), (3, 32, 4), (17, 256, 2), (100, 16, 8), (130, 256, 8)])
+@pytest.mark.parametrize("D,K,N", [(1, 16, 2), (3, 32, 4), (17, 256, 2), (100, 16, 8), (130, 256, 8), (1000, 64, 8), (778, 32, 16)])
 def test_odd_dims_vs_oracle(D, K, N):
     sd = gen.synthetic_state(900 + D, D, K, N)
     q = load_quantizer(sd, D, K, N)
