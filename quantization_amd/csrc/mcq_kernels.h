@@ -796,8 +796,11 @@ k_gemm8s(const float *__restrict__ Bm, const float *__restrict__ xin, const uint
     store_stage(0);
     __syncthreads();
     if (nkb > 1) load_stage(1);
-    for (int kb = 0; kb < nkb; ++kb) {
-        const f32x4 *sa = lds + (size_t)(kb & 1) * STAGE_UNITS, *sb = sa + A_UNITS;
+    // one k-block: fragments from buffer BUF (a compile-time constant: every LDS address of the loop body is a
+    // loop-invariant register plus an immediate), MFMAs, then the next stage goes to the other buffer
+    auto kstep = [&](int kb, auto BUF) {
+        constexpr int buf = decltype(BUF)::value;
+        const f32x4 *sa = lds + (size_t)buf * STAGE_UNITS, *sb = sa + A_UNITS;
         const f32x4 bf = sb[lds_unit1(VEC, 16 * vg + r, g)];
         f32x4 af[TW];
 #pragma unroll
@@ -807,9 +810,13 @@ k_gemm8s(const float *__restrict__ Bm, const float *__restrict__ xin, const uint
 #pragma unroll
             for (int t = 0; t < TW; ++t)
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t][i], bf[i], acc[t], 0, 0, 0);
-        if (kb + 1 < nkb) store_stage((kb + 1) & 1);
+        if (kb + 1 < nkb) store_stage(buf ^ 1);
         __syncthreads();
         if (kb + 2 < nkb) load_stage(kb + 2);
+    };
+    for (int kb = 0; kb < nkb; kb += 2) {
+        kstep(kb, std::integral_constant<int, 0>{});
+        if (kb + 1 < nkb) kstep(kb + 1, std::integral_constant<int, 1>{});
     }
 
     // epilogue: lane holds, for vector b0 + 16*vg + r, entries 16*(eh*TW+t) + 4g + v
