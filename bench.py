@@ -294,6 +294,27 @@ def main():
     out["decode"] = {"vectors_per_s": round(B / (dec_ms * 1e-3), 1), "ms": round(dec_ms, 4),
                      "hbm_gb_per_s": round(B * (N + 4 * D) / (dec_ms * 1e-3) / 1e9, 1), "peak_gb_per_s": 8000.0,
                      "note": "torch current stream; algorithmic bytes = N + 4*D per vector"}
+    # ---- secondary: QuantizerTrainer.step (BASELINE config E shape on one GPU: dim 512, 8 bytes, batch 4096)
+    if world == 1:
+        import random
+        from quantization_amd import QuantizerTrainer
+        random.seed(0)
+        torch.manual_seed(0)
+        tr = QuantizerTrainer(dim=D, bytes_per_frame=N, device=dev, phase_one_iters=60, phase_two_iters=60)
+        xt = torch.randn(4096, D, device=dev)
+        ms = {}
+        for phase, until in (("phase1_ms_per_step", 60), ("phase2_ms_per_step", 121)):
+            for _ in range(10):
+                tr.step(xt)
+            torch.cuda.synchronize()
+            t4, n0 = time.perf_counter(), tr.cur_iter
+            while tr.cur_iter < until - 5:
+                tr.step(xt)
+            torch.cuda.synchronize()
+            ms[phase] = round((time.perf_counter() - t4) / (tr.cur_iter - n0) * 1e3, 3)
+            while tr.cur_iter < until + (1 if until == 60 else 0):
+                tr.step(xt)
+        out["trainer_step"] = dict(ms, batch=4096, note="QuantizerTrainer.step, fused (autograd-free) path, free-running")
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(state, D)
     print(json.dumps(out), flush=True)
