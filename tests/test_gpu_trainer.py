@@ -163,3 +163,25 @@ def test_fused_step_equals_the_autograd_step():
     assert np.allclose(lf, la, rtol=2e-4, atol=2e-5), np.abs(lf - la).max()
     for k in ("centers", "to_logits.weight", "to_logits.bias", "logits_scale", "centers_scale"):
         assert np.abs(pf[k] - pa[k]).max() <= 2e-4 * max(1e-3, np.abs(pa[k]).max()), (k, np.abs(pf[k] - pa[k]).max())
+
+
+def test_decode_backward_on_uint8_codes_is_bit_identical():
+    from quantization_amd import _lib
+    L = _lib.lib()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(9)
+    for (D, K, N, B) in [(512, 256, 8, 4096), (40, 16, 16, 777), (100, 64, 2, 65)]:
+        g = torch.randn(B, D, device=dev)
+        idx = torch.randint(0, K, (B, N), device=dev)
+        a = torch.empty(N, K, D, device=dev)
+        b = torch.empty(N, K, D, device=dev)
+        st = torch.cuda.current_stream().cuda_stream
+        assert L.mcq_decode_backward(g.data_ptr(), idx.data_ptr(), B, N, K, D, a.data_ptr(), st) == 0
+        codes = idx.to(torch.uint8)
+        assert L.mcq_decode_backward_u8(g.data_ptr(), codes.data_ptr(), B, N, K, D, b.data_ptr(), st) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(a, b)
+        ref = torch.zeros(N * K, D, device=dev, dtype=torch.float64)
+        rows = (idx + torch.arange(N, device=dev) * K).reshape(-1)
+        ref.index_add_(0, rows, g.double().unsqueeze(1).expand(-1, N, -1).reshape(-1, D))
+        assert torch.allclose(a.double().reshape(N * K, D), ref, rtol=1e-5, atol=1e-4)
