@@ -155,16 +155,19 @@ __device__ __forceinline__ void wave_select_fast(const float (&v)[VPL], const in
         u64 lmin = key[0];
 #pragma unroll
         for (int i = 1; i < VPL; ++i) lmin = key[i] < lmin ? key[i] : lmin;
-        bool lc = lmin != kKeyMax;
+        // The candidate set is a wave-uniform 64-bit MASK handled by scalar instructions (a per-lane bool carried
+        // round the loop is materialised as 0/1 VGPRs with v_cndmask / v_cmp pairs and nops on every round: the
+        // selection is bound by exactly that scalar/VALU ping-pong).  Keys are unique, so the lanes above the
+        // pivot are the complement of those below it minus the pivot's lane.
+        u64 cm = __ballot(lmin != kKeyMax);
         u64 T0 = kKeyMax;
-        for (int guard = 0; guard < 65; ++guard) {
-            const u64 cm = __ballot(lc);
-            if (cm == 0) break;
-            const u64 kp = readlane_u64(lmin, __ffsll((long long)cm) - 1);
-            const bool lt = lmin < kp;
-            const int rr = __popcll(__ballot(lt));
+        for (int guard = 0; guard < 65 && cm != 0; ++guard) {
+            const int pl = __ffsll((long long)cm) - 1;
+            const u64 kp = readlane_u64(lmin, pl);
+            const u64 ltm = __ballot(lmin < kp);
+            const int rr = __popcll(ltm);
             if (rr == target) { T0 = kp; break; }
-            lc = lc && (rr > target ? lt : (lmin > kp));
+            cm &= (rr > target) ? ltm : ~(ltm | (1ull << pl));
         }
         int base = 0;
 #pragma unroll
@@ -192,33 +195,34 @@ __device__ __forceinline__ void wave_select_fast(const float (&v)[VPL], const in
         wave_lds_fence();
         return;
     }
-    // quickselect: find the key T with exactly cnt - 1 keys below it
+    // quickselect: find the key T with exactly cnt - 1 keys below it.  Candidate sets as wave-uniform masks, one
+    // per key slot (see the two-level variant above); the pivot is the first candidate of the lowest slot that has one.
     u64 T = 0;
-    for (int guard = 0; guard < 64 * VPL + 1; ++guard) {
-        u64 lk = kKeyMax;
-        bool any_l = false;
+    u64 cmask[VPL];
 #pragma unroll
-        for (int i = VPL - 1; i >= 0; --i) {
-            lk = cand[i] ? key[i] : lk;
-            any_l = any_l || cand[i];
-        }
-        const u64 anym = __ballot(any_l);
-        const int pl = __ffsll((long long)anym) - 1;
-        const u64 kp = readlane_u64(lk, pl < 0 ? 0 : pl);
-        bool lt[VPL];
+    for (int i = 0; i < VPL; ++i) cmask[i] = __ballot(cand[i]);
+    for (int guard = 0; guard < 64 * VPL + 1; ++guard) {
+        u64 kp = kKeyMax;
+        int ps = -1, pl = 0;
+#pragma unroll
+        for (int i = VPL - 1; i >= 0; --i)
+            if (cmask[i] != 0) { ps = i; pl = __ffsll((long long)cmask[i]) - 1; }
+        if (ps < 0) { T = kp; break; }
+#pragma unroll
+        for (int i = 0; i < VPL; ++i)
+            if (i == ps) kp = readlane_u64(key[i], pl);      // uniform branch: one slot matches
+        u64 ltm[VPL];
         int r = 0;
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
-            lt[i] = key[i] < kp;
-            r += __popcll(__ballot(lt[i]));
+            ltm[i] = __ballot(key[i] < kp);
+            r += __popcll(ltm[i]);
         }
-        if (r == target || anym == 0) { T = kp; break; }
-        if (r > target) {
+        if (r == target) { T = kp; break; }
 #pragma unroll
-            for (int i = 0; i < VPL; ++i) cand[i] = cand[i] && lt[i];
-        } else {
-#pragma unroll
-            for (int i = 0; i < VPL; ++i) cand[i] = cand[i] && (key[i] > kp);
+        for (int i = 0; i < VPL; ++i) {
+            const u64 pivot_bit = (i == ps) ? (1ull << pl) : 0ull;
+            cmask[i] &= (r > target) ? ltm[i] : ~(ltm[i] | pivot_bit);
         }
     }
     // compact the cnt selected keys to lds[0..cnt)
