@@ -179,10 +179,17 @@ __device__ __forceinline__ void wave_select_fast(const float (&v)[VPL], const in
             base += __popcll(m);
         }
         const int c0 = base < 64 ? base : 64;
+        // ranking walks the survivors eight at a time; the tail is padded with sentinels (never smaller than a key)
+        // instead of a one-by-one remainder loop that waits out an LDS round trip per element
+        if (lane >= c0 && lane < c0 + 8) ldsA[lane] = kKeyMax;      // may run into ldsB, which is written later
         wave_lds_fence();
         const u64 k = (lane < c0) ? ldsA[lane] : kKeyMax;
         int rnk = 0;
-        for (int j = 0; j < c0; ++j) rnk += (ldsA[j] < k) ? 1 : 0;
+        const int c8 = (c0 + 7) & ~7;
+        for (int j = 0; j < c8; j += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) rnk += (ldsA[j + u] < k) ? 1 : 0;
+        }
         if (lane < c0 && rnk < cnt) ldsB[rnk] = k;
         wave_lds_fence();
         out_v = INFINITY;
@@ -235,10 +242,15 @@ __device__ __forceinline__ void wave_select_fast(const float (&v)[VPL], const in
         if (sel && dst < 64) ldsA[dst] = key[i];
         base += __popcll(m);
     }
+    if (lane >= cnt && lane < cnt + 8) ldsA[lane] = kKeyMax;       // sentinel tail: see the two-level variant
     wave_lds_fence();
     const u64 k = (lane < cnt) ? ldsA[lane] : kKeyMax;
     int rnk = 0;
-    for (int j = 0; j < cnt; ++j) rnk += (ldsA[j] < k) ? 1 : 0;
+    const int c8 = (cnt + 7) & ~7;
+    for (int j = 0; j < c8; j += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) rnk += (ldsA[j + u] < k) ? 1 : 0;
+    }
     if (lane < cnt) ldsB[rnk] = k;
     wave_lds_fence();
     out_v = INFINITY;
