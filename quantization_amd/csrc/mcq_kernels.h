@@ -161,7 +161,7 @@ __device__ __forceinline__ void wave_select_fast(const float (&v)[VPL], const in
         // pivot are the complement of those below it minus the pivot's lane.
         u64 cm = __ballot(lmin != kKeyMax);
         u64 T0 = kKeyMax;
-        for (int guard = 0; guard < 65 && cm != 0; ++guard) {
+        while (cm != 0) {     // every round removes at least the pivot's lane from the candidates: <= 64 rounds
             const int pl = __ffsll((long long)cm) - 1;
             const u64 kp = readlane_u64(lmin, pl);
             const u64 ltm = __ballot(lmin < kp);
@@ -208,7 +208,7 @@ __device__ __forceinline__ void wave_select_fast(const float (&v)[VPL], const in
     u64 cmask[VPL];
 #pragma unroll
     for (int i = 0; i < VPL; ++i) cmask[i] = __ballot(cand[i]);
-    for (int guard = 0; guard < 64 * VPL + 1; ++guard) {
+    for (;;) {                // every round removes at least the pivot from the candidates: <= 64 * VPL rounds
         u64 kp = kKeyMax;
         int ps = -1, pl = 0;
 #pragma unroll
