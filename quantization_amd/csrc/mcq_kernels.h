@@ -1310,8 +1310,8 @@ k_pair(const float *__restrict__ C, const uint8_t *__restrict__ idx, const float
                 for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
                     for (int j = 0; j < L; ++j) {
-                        ta[ti][j] = MCQ_PAIR_GATHER(Cb + (row_off(0, ti, j) + (uint32_t)(64 * (kb_lo + kbi))));
-                        tb[ti][j] = MCQ_PAIR_GATHER(Cb + (row_off(1, ti, j) + (uint32_t)(64 * (kb_lo + kbi))));
+                        ta[ti][j] = MCQ_PAIR_GATHER(Cb + 64 * (size_t)(kb_lo + kbi) + (size_t)row_off(0, ti, j));
+                        tb[ti][j] = MCQ_PAIR_GATHER(Cb + 64 * (size_t)(kb_lo + kbi) + (size_t)row_off(1, ti, j));
                     }
                 f32x4 da[TI], db[TI];
 #pragma unroll
@@ -1331,8 +1331,8 @@ k_pair(const float *__restrict__ C, const uint8_t *__restrict__ idx, const float
                 for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
                     for (int j = 0; j < L; ++j) {
-                        ra[ti][j] = MCQ_PAIR_GATHER(Cb + (row_off(0, ti, j) + (uint32_t)(64 * (kb_lo + kbi))));
-                        rb[ti][j] = MCQ_PAIR_GATHER(Cb + (row_off(1, ti, j) + (uint32_t)(64 * (kb_lo + kbi))));
+                        ra[ti][j] = MCQ_PAIR_GATHER(Cb + 64 * (size_t)(kb_lo + kbi) + (size_t)row_off(0, ti, j));
+                        rb[ti][j] = MCQ_PAIR_GATHER(Cb + 64 * (size_t)(kb_lo + kbi) + (size_t)row_off(1, ti, j));
                     }
             };
             for (int kbi = 0; kbi < nkb; ++kbi) {
@@ -1354,7 +1354,7 @@ k_pair(const float *__restrict__ C, const uint8_t *__restrict__ idx, const float
             auto load_tile = [&](f32x4 (&buf)[L], int side, int ti, int kbi) {
 #pragma unroll
                 for (int j = 0; j < L; ++j)
-                    buf[j] = MCQ_PAIR_GATHER(Cb + (row_off(side, ti, j) + (uint32_t)(64 * (kb_lo + kbi))));
+                    buf[j] = MCQ_PAIR_GATHER(Cb + 64 * (size_t)(kb_lo + kbi) + (size_t)row_off(side, ti, j));
             };
             f32x4 bufA[L], bufB[L];
             load_tile(bufA, 0, 0, 0);
