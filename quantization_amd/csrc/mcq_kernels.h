@@ -534,15 +534,16 @@ k_gemm(const float *__restrict__ Bm /*[N][K][Dp]*/, const float *__restrict__ xi
     constexpr int K = 16 * T;
     if (nact) B = *nact;
     if (lscale_ptr) lscale = *lscale_ptr;
-    if ((long)(blockIdx.x / N) * kGemmVec >= B) return;   // whole tile past the active list (uniform)
+    const int nsh = __builtin_ctz((unsigned)N);    // N is a power of two: shift / mask instead of a division sequence
+    if ((long)(blockIdx.x >> nsh) * kGemmVec >= B) return;   // whole tile past the active list (uniform)
     constexpr int A_UNITS = K * 8;           // 16-byte units of the entries tile per stage
     constexpr int A_PER_THREAD = (A_UNITS + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4 *ldsA = reinterpret_cast<f32x4 *>(smem);
     f32x4 *ldsB = ldsA + A_UNITS;
 
-    const int n = blockIdx.x % N;
-    const long b0 = (long)(blockIdx.x / N) * kGemmVec;
+    const int n = blockIdx.x & (N - 1);
+    const long b0 = (long)(blockIdx.x >> nsh) * kGemmVec;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
 
@@ -725,7 +726,8 @@ k_gemm8s(const float *__restrict__ Bm, const float *__restrict__ xin, const uint
     constexpr bool IS0 = (MODE == MODE_STAGE0) || (MODE == MODE_STAGE0_SEL);
     if (nact) B = *nact;
     if (lscale_ptr) lscale = *lscale_ptr;
-    if ((long)(blockIdx.x / N) * (16 * VGN) >= B) return;   // whole tile past the active list (uniform)
+    const int nsh = __builtin_ctz((unsigned)N);    // N is a power of two: shift / mask instead of a division sequence
+    if ((long)(blockIdx.x >> nsh) * (16 * VGN) >= B) return;   // whole tile past the active list (uniform)
     static_assert(T >= 2 && T % 2 == 0, "k_gemm8s splits the entry tiles over two wave groups");
     constexpr int K = 16 * T;
     constexpr int TW = T / 2;
@@ -738,8 +740,8 @@ k_gemm8s(const float *__restrict__ Bm, const float *__restrict__ xin, const uint
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4 *lds = reinterpret_cast<f32x4 *>(smem);  // [2][STAGE_UNITS]
 
-    const int n = blockIdx.x % N;
-    const long b0 = (long)(blockIdx.x / N) * VEC;
+    const int n = blockIdx.x & (N - 1);
+    const long b0 = (long)(blockIdx.x >> nsh) * VEC;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int vg = wave % VGN, eh = wave / VGN;
     const int r = lane & 15, g = lane >> 4;
@@ -1044,8 +1046,8 @@ k_pair(const float *__restrict__ C, const uint8_t *__restrict__ idx, const float
     // all waves of a workgroup work on the SAME output group for consecutive vectors, and
     // workgroup id mod Gout picks the group: workgroups land on XCD (id mod 8), so each XCD's
     // L2 only ever sees the codebooks of the groups congruent to it (2L*K rows instead of N*K).
-    const int go = (int)(blockIdx.x % (unsigned)Gout);
-    const long b = (long)(blockIdx.x / (unsigned)Gout) * wpb + wave;
+    const int go = (int)(blockIdx.x & (unsigned)(Gout - 1));       // Gout is a power of two
+    const long b = (long)(blockIdx.x >> __builtin_ctz((unsigned)Gout)) * wpb + wave;
     if (b >= B) return;   // no workgroup-wide barrier below: every LDS region is private to its wave
     const int r = lane & 15, g = lane >> 4;
     const int Gin = 2 * Gout;
@@ -1446,8 +1448,8 @@ k_pair8(const float *__restrict__ C, const uint8_t *__restrict__ idx, const floa
     extern __shared__ __attribute__((aligned(16))) char smem[];
     u64 *scratch = reinterpret_cast<u64 *>(smem);
     const int GP = (Gout + 1) / 2;
-    const int gp = (int)(blockIdx.x % (unsigned)GP);
-    const long b = (long)(blockIdx.x / (unsigned)GP);
+    const int gp = (int)(blockIdx.x & (unsigned)(GP - 1));         // GP is a power of two
+    const long b = (long)(blockIdx.x >> __builtin_ctz((unsigned)GP));
     if (b >= B) return;
     const int lane = lane_id();
     const int r = lane & 15, g = lane >> 4;
