@@ -54,7 +54,8 @@ struct Workspace {
     uint8_t *idx, *idxB, *idxC, *final_idx;   // B, C, final: fixed-point skipping only
     int *map[2], *cnt;
     float *xerr, *E, *R, *S0;
-    uint8_t *tup[2];
+    uint8_t *tup[3];   // three-way rotation: a DEDUP pair stage also reads the lists of two stages back
+    uint8_t *pos;      // (a, b) of every candidate kept by the stage before a DEDUP stage
     float *S[2];
 };
 
@@ -67,7 +68,8 @@ bool fused_select(int N, int K) {
 
 size_t workspace_per_vector(int N, int K, int Dp) {
     const size_t s0 = fused_select(N, K) ? 0 : 4 * (size_t)N * K;
-    return 4 * (size_t)N + 8 + 4 * (size_t)Dp + 4 + 4 * (size_t)N + s0 + 2 * 64 * (size_t)N + 2 * 4 * 16 * (size_t)N;
+    return 4 * (size_t)N + 8 + 4 * (size_t)Dp + 4 + 4 * (size_t)N + s0 + 3 * 64 * (size_t)N + 16 * (size_t)N +
+           2 * 4 * 16 * (size_t)N;
 }
 constexpr size_t kWorkspaceSlack = 24 * 256;
 constexpr long kDefaultChunk = 65536;
@@ -87,7 +89,8 @@ Workspace carve(void *ws, long Bc, int N, int K, int Dp) {
     w.E = reinterpret_cast<float *>(take((size_t)Bc * 4));
     w.R = reinterpret_cast<float *>(take((size_t)Bc * N * 4));
     w.S0 = fused_select(N, K) ? nullptr : reinterpret_cast<float *>(take((size_t)Bc * N * K * 4));
-    for (int i = 0; i < 2; ++i) w.tup[i] = reinterpret_cast<uint8_t *>(take((size_t)Bc * N * 64));
+    for (int i = 0; i < 3; ++i) w.tup[i] = reinterpret_cast<uint8_t *>(take((size_t)Bc * N * 64));
+    w.pos = reinterpret_cast<uint8_t *>(take((size_t)Bc * N * 16));
     for (int i = 0; i < 2; ++i) w.S[i] = reinterpret_cast<float *>(take((size_t)Bc * N * 16 * 4));
     return w;
 }
@@ -186,7 +189,8 @@ int launch_prune0(int K, const float *S0, long BN, int keep, uint8_t *tup, float
 template <int L, int KI>
 int launch_pair_t(const float *C, const uint8_t *idx, const float *E, const uint8_t *tup_in, const float *S_in,
                   long B, int N, int K, int Dp, int Gout, int keep, uint8_t *tup_out, float *S_out,
-                  uint8_t *idx_final, const int *nact, hipStream_t st) {
+                  uint8_t *idx_final, const int *nact, hipStream_t st, uint8_t *pos_out, const uint8_t *pos_in,
+                  const uint8_t *tup_prev) {
     // each wave stages its 2L old rows in a private LDS window: whole rows while that stays <= 32 KB
     // per wave (measured best), otherwise `win` floats at a time in windows of <= 16 KB
     const size_t scratch = (size_t)kSelectLdsU64 * 8;
@@ -204,7 +208,10 @@ int launch_pair_t(const float *C, const uint8_t *idx, const float *E, const uint
     static const int xl_env = getenv("MCQ_PAIR_XL") ? atoi(getenv("MCQ_PAIR_XL")) : -1;
     const bool xl = xl_env >= 0 ? xl_env != 0 : (L == 1);
     constexpr int TI = (KI + 15) / 16;
-    const size_t per_wave = (size_t)2 * L * win * 4 + scratch + (xl ? (size_t)2 * TI * 1024 : 0);
+    // DEDUP (32 x 32 four-leaf stage, when the previous stage left its (a, b) positions): MCQ_PAIR_DEDUP=0 disables it
+    static const bool dedup_ok = !(getenv("MCQ_PAIR_DEDUP") && atoi(getenv("MCQ_PAIR_DEDUP")) == 0);
+    const bool dedup = dedup_ok && L == 4 && KI == 32 && pos_in != nullptr && tup_prev != nullptr;
+    const size_t per_wave = (size_t)2 * L * win * 4 + scratch + ((xl || dedup) ? (size_t)2 * TI * 1024 : 0);
     // one wave per workgroup: the waves share nothing (private LDS, no barrier), and single-wave
     // workgroups measured fastest (finer-grained dispatch, LDS released per wave)
     int wpb = 1;
@@ -218,28 +225,37 @@ int launch_pair_t(const float *C, const uint8_t *idx, const float *E, const uint
     if constexpr ((L == 1 && KI == 16) || (L == 2 && KI == 16) || (L == 4 && KI == 32)) /* headline ladder only */      \
     if (abl == A) {                                                                                                   \
         hipLaunchKernelGGL((k_pair<L, KI, false, A>), dim3(grid), dim3(64 * wpb), per_wave * wpb, st, C, idx, E, tup_in,  \
-                           S_in, B, N, K, Dp, Gout, keep, win, tup_out, S_out, idx_final, nact);                      \
+                           S_in, B, N, K, Dp, Gout, keep, win, tup_out, S_out, idx_final, nact, nullptr, nullptr, nullptr); \
         return 0;                                                                                                     \
     }
     MCQ_PAIR_ABL_CASE(1) MCQ_PAIR_ABL_CASE(2) MCQ_PAIR_ABL_CASE(3) MCQ_PAIR_ABL_CASE(4) MCQ_PAIR_ABL_CASE(5) MCQ_PAIR_ABL_CASE(6)
 #undef MCQ_PAIR_ABL_CASE
+    if constexpr (L == 4 && KI == 32) {
+        if (dedup) {
+            hipLaunchKernelGGL((k_pair<L, KI, false, 0, true>), dim3(grid), dim3(64 * wpb), per_wave * wpb, st, C, idx, E, tup_in,
+                               S_in, B, N, K, Dp, Gout, keep, win, tup_out, S_out, idx_final, nact, pos_out, pos_in, tup_prev);
+            MCQ_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     if (xl)
         hipLaunchKernelGGL((k_pair<L, KI, true>), dim3(grid), dim3(64 * wpb), per_wave * wpb, st, C, idx, E, tup_in, S_in, B,
-                           N, K, Dp, Gout, keep, win, tup_out, S_out, idx_final, nact);
+                           N, K, Dp, Gout, keep, win, tup_out, S_out, idx_final, nact, pos_out, nullptr, nullptr);
     else
         hipLaunchKernelGGL((k_pair<L, KI, false>), dim3(grid), dim3(64 * wpb), per_wave * wpb, st, C, idx, E, tup_in, S_in,
-                           B, N, K, Dp, Gout, keep, win, tup_out, S_out, idx_final, nact);
+                           B, N, K, Dp, Gout, keep, win, tup_out, S_out, idx_final, nact, pos_out, nullptr, nullptr);
     MCQ_LAUNCH_CHECK();
     return 0;
 }
 
 int launch_pair(int L, int KI, const float *C, const uint8_t *idx, const float *E, const uint8_t *tup_in,
                 const float *S_in, long B, int N, int K, int Dp, int Gout, int keep, uint8_t *tup_out, float *S_out,
-                uint8_t *idx_final, const int *nact, hipStream_t st) {
+                uint8_t *idx_final, const int *nact, hipStream_t st, uint8_t *pos_out = nullptr,
+                const uint8_t *pos_in = nullptr, const uint8_t *tup_prev = nullptr) {
 #define MCQ_PAIR_CASE(LL, KK)                                                                                     \
     if (L == LL && KI == KK)                                                                                      \
         return launch_pair_t<LL, KK>(C, idx, E, tup_in, S_in, B, N, K, Dp, Gout, keep, tup_out, S_out, idx_final, nact, \
-                                     st);
+                                     st, pos_out, pos_in, tup_prev);
     // 8-candidate lists (16-entry codebooks): two output groups per wave (MCQ_PAIR8=0: the generic kernel; tuning hook)
     static const bool pair8 = !(getenv("MCQ_PAIR8") && atoi(getenv("MCQ_PAIR8")) == 0);
     if (pair8 && KI == 8 && (L == 1 || L == 2)) {
@@ -383,8 +399,15 @@ int run_encode(const float *x, long B, const void *prepared, float lscale, int N
                 const int Gout = G / 2;
                 const int keep = (Gout == 1) ? 1 : k_cutoff(K, 2 * L);
                 if (prof) prof->begin();
-                rc = launch_pair(L, KI, P.C, idx_cur, w.E, w.tup[cur], w.S[cur], Bc, N, K, Dp, Gout, keep,
-                                 w.tup[cur ^ 1], w.S[cur ^ 1], (Gout == 1) ? idx_new : nullptr, nact, st);
+                // tuple lists rotate through three buffers (the lists of two stages back stay readable); scores ping-pong.
+                // A two-leaf 16-candidate stage that keeps 32 records which pairs it kept for the DEDUP stage after it.
+                const int tcur = stage % 3, tnext = (stage + 1) % 3, tprev = (stage + 2) % 3;
+                const bool next_dedup = (L == 2 && KI == 16 && keep == 32 && Gout > 1);
+                const bool this_dedup = (L == 4 && KI == 32 && stage >= 2);
+                rc = launch_pair(L, KI, P.C, idx_cur, w.E, w.tup[tcur], w.S[cur], Bc, N, K, Dp, Gout, keep,
+                                 w.tup[tnext], w.S[cur ^ 1], (Gout == 1) ? idx_new : nullptr, nact, st,
+                                 next_dedup ? w.pos : nullptr, this_dedup ? w.pos : nullptr,
+                                 this_dedup ? w.tup[tprev] : nullptr);
                 if (rc) return rc;
                 if (prof) prof->end(CAT_PAIR0 + stage);
                 G = Gout; L *= 2; KI = keep; cur ^= 1; ++stage;

@@ -1025,14 +1025,24 @@ struct DeltaBuilder {
 #ifndef MCQ_PAIR_UNR
 #define MCQ_PAIR_UNR 2   // k-blocks per software-pipeline batch x leaves (4: deeper prefetch, one wave per SIMD fewer)
 #endif
-template <int L, int KI, bool XL = false, int ABL = 0>
+// DEDUP (L == 4, KI == 32): a candidate of this stage is the sum of two candidates of the stage before the previous
+// one's lists, delta_4 = delta_2P[a] + delta_2Q[b] (:538-541), and only 16 + 16 distinct delta_2 rows feed the 32
+// candidates of a side.  The kernel gathers those 32 two-leaf rows per side (half the row fetches of rebuilding every
+// candidate from its four leaves: this stage is bound by the L1 data rate), forms delta_2 = (c0 - o0) + (c1 - o1)
+// once, parks the four delta_2 tiles in a wave-private LDS tile and builds each MFMA operand row as tile_P[a] +
+// tile_Q[b] with per-lane row addresses -- the same additions in the same order as DeltaBuilder<4>.
+//   pos_in  [B][Gin][KI][2]: (a, b) of every candidate, written by the previous stage (pos_out there)
+//   tup_prev[B][2*Gin][16][2]: the two-leaf lists the previous stage combined
+template <int L, int KI, bool XL = false, int ABL = 0, bool DEDUP = false>
 __global__ void __launch_bounds__(256)
 k_pair(const float *__restrict__ C, const uint8_t *__restrict__ idx, const float *__restrict__ E,
        const uint8_t *__restrict__ tup_in /*[B][Gin][KI][L]*/, const float *__restrict__ S_in /*[B][Gin][KI]*/,
        long B, int N, int K, int Dp, int Gout, int keep, int win /* floats of each old row staged per window */,
        uint8_t *__restrict__ tup_out /*[B][Gout][keep][2L]*/, float *__restrict__ S_out,
        uint8_t *__restrict__ idx_final /* may alias idx: a wave only rewrites its own vector, at the end */,
-       const int *__restrict__ nact) {
+       const int *__restrict__ nact, uint8_t *__restrict__ pos_out /* nullable: [B][Gout][keep][2] */,
+       const uint8_t *__restrict__ pos_in, const uint8_t *__restrict__ tup_prev) {
+    static_assert(!DEDUP || (L == 4 && KI == 32 && ABL == 0 && !XL), "DEDUP is the 32x32 four-leaf stage");
     constexpr int TI = (KI + 15) / 16;
     if (nact) B = *nact;
     constexpr int VPL = TI * TI * 4;
@@ -1058,8 +1068,9 @@ k_pair(const float *__restrict__ C, const uint8_t *__restrict__ idx, const float
     float *oldwin = reinterpret_cast<float *>(smem) + (size_t)wpb * kSelectLdsU64 * 2 + (size_t)wave * 2 * L * win;
     // XL: operands change lane order through a wave-private LDS tile (ds_write_b128 + ds_read_b128:
     // 13.4 + 4.3 LDS cycles per KB) instead of four ds_bpermute (4 x 6.2) -- tools/micro/lds_write_rates.hip
+    constexpr int XP_UNITS = 2 * TI * 64;
     f32x4 *xpose = reinterpret_cast<f32x4 *>(smem + (size_t)wpb * (kSelectLdsU64 * 8 + (size_t)2 * L * win * 4)) +
-                   (size_t)wave * (2 * TI * 64);
+                   (size_t)wave * XP_UNITS;
 
     // Operand rows are LOADED in a coalescing-friendly lane order -- lane 4*rs + ps reads the
     // ps-th float4 of the k-block of candidate row rs, so each quad of lanes covers 64 contiguous
@@ -1067,7 +1078,7 @@ k_pair(const float *__restrict__ C, const uint8_t *__restrict__ idx, const float
     // order (lane 16*g + r holds row r, float4 g) with four ds_bpermute per float4.
     // (quads 8..15 hold their four parts rotated by two so that the 32 lanes of a bpermute
     // half-wave pull from 32 distinct LDS-crossbar banks)
-    const int rs = lane >> 2, ps = XL ? (lane & 3) : ((lane & 3) ^ ((lane >> 5) << 1));
+    const int rs = lane >> 2, ps = (XL || DEDUP) ? (lane & 3) : ((lane & 3) ^ ((lane >> 5) << 1));
     const int perm_addr = (4 * r + (g ^ ((r >> 3) << 1))) << 2;   // byte address of this lane's source lane
     // LDS tile units (16 B): row-major 4 per row, the quad index xor (row / 4) % 4 keeps the 16 lanes of a
     // ds_read_b128 group (fixed g) on 16 distinct bank quads
@@ -1218,7 +1229,78 @@ k_pair(const float *__restrict__ C, const uint8_t *__restrict__ idx, const float
         const int kb_lo = w0 / 16, nkb = wlen / 16;   // k-blocks of this window
         const float *oldp = oldwin + 4 * ps;          // this lane's piece within a k-block of the window
 
-        if constexpr (PIPE) {
+        if constexpr (DEDUP) {
+            typedef __attribute__((address_space(3))) volatile f32x4 lds_vf4;
+            lds_vf4 *vt = (lds_vf4 *)xpose;                      // four tiles [side][P|Q] of 16 rows x 4 units
+            const int Gp = 2 * Gin;                              // groups of the lists two stages back
+            uint32_t doff[2][2][2];                              // [side][P|Q][leaf]: row rs of that two-leaf list
+            int ua[2][TI], ub[2][TI];                            // LDS units of this lane's operand rows
+#pragma unroll
+            for (int sd = 0; sd < 2; ++sd) {
+                const int gs = sd == 0 ? ge : gd;
+#pragma unroll
+                for (int pq = 0; pq < 2; ++pq) {
+                    const uint8_t *tp = tup_prev + ((b * Gp + 2 * gs + pq) * 16 + rs) * 2L;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        doff[sd][pq][j] = 4u * (uint32_t)(((n0 + sd * L + pq * 2 + j) * K + tp[j]) * Dp + 4 * ps);
+                }
+#pragma unroll
+                for (int ti = 0; ti < TI; ++ti) {
+                    const uint8_t *pp = pos_in + ((b * Gin + gs) * KI + 16 * ti + r) * 2L;
+                    const int a = pp[0] & 15, q = pp[1] & 15;
+                    ua[sd][ti] = (sd * 2 + 0) * 64 + 4 * a + (g ^ ((a >> 2) & 3));
+                    ub[sd][ti] = (sd * 2 + 1) * 64 + 4 * q + (g ^ ((q >> 2) & 3));
+                }
+            }
+            const int xwu = 4 * rs + ((lane & 3) ^ ((rs >> 2) & 3));   // (this path loads with ps = lane & 3: see below)
+            auto dgather = [&](f32x4 (&c)[2][2][2], int kbi) {
+#pragma unroll
+                for (int sd = 0; sd < 2; ++sd)
+#pragma unroll
+                    for (int pq = 0; pq < 2; ++pq)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            c[sd][pq][j] = *reinterpret_cast<const f32x4 *>(Cb + 64 * (size_t)(kb_lo + kbi) + (size_t)doff[sd][pq][j]);
+            };
+            auto dcompute = [&](const f32x4 (&c)[2][2][2], int kbi) {
+                f32x4 d2[2][2];
+#pragma unroll
+                for (int sd = 0; sd < 2; ++sd)
+#pragma unroll
+                    for (int pq = 0; pq < 2; ++pq) {
+                        const float *o = oldp + (size_t)(sd * L + pq * 2) * win + 16 * kbi;
+                        const f32x4 o0 = *reinterpret_cast<const f32x4 *>(o), o1 = *reinterpret_cast<const f32x4 *>(o + win);
+                        d2[sd][pq] = (c[sd][pq][0] - o0) + (c[sd][pq][1] - o1);
+                    }
+#pragma unroll
+                for (int sd = 0; sd < 2; ++sd)
+#pragma unroll
+                    for (int pq = 0; pq < 2; ++pq) vt[(sd * 2 + pq) * 64 + xwu] = d2[sd][pq];
+                f32x4 da[TI], db[TI];
+#pragma unroll
+                for (int ti = 0; ti < TI; ++ti) {
+                    const f32x4 pa = vt[ua[0][ti]], qa = vt[ub[0][ti]];
+                    const f32x4 pb = vt[ua[1][ti]], qb = vt[ub[1][ti]];
+                    da[ti] = pa + qa;
+                    db[ti] = pb + qb;
+                }
+                mfma_block(da, db);
+            };
+            f32x4 c0[2][2][2], c1[2][2][2];
+            dgather(c0, 0);
+            for (int kbi = 0; kbi < nkb; kbi += 2) {
+                const int k1 = (kbi + 1 < nkb) ? kbi + 1 : kbi, k2 = (kbi + 2 < nkb) ? kbi + 2 : kbi;   // clamped re-reads
+                dgather(c1, k1);
+                __builtin_amdgcn_sched_barrier(0);
+                dcompute(c0, kbi);
+                __builtin_amdgcn_sched_barrier(0);
+                dgather(c0, k2);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kbi + 1 < nkb) dcompute(c1, kbi + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else if constexpr (PIPE) {
             // Two-deep software pipeline over batches of UNR k-blocks: the gathers of batch c+1 are
             // issued (pinned by sched_barrier) before the arithmetic of batch c.  Inside the
             // steady-state loop every load is unconditional, so the compiler's vmcnt bookkeeping is
@@ -1427,6 +1509,11 @@ k_pair(const float *__restrict__ C, const uint8_t *__restrict__ idx, const float
             for (int j = 0; j < L; ++j) { o[j] = te[a * L + j]; o[L + j] = to[bb * L + j]; }
         }
         if (idx_final == nullptr) S_out[(b * Gout + go) * (long)keep + lane] = ov;
+        if (pos_out != nullptr) {       // which two list entries this candidate combines (read by a DEDUP stage)
+            uint8_t *po = pos_out + ((b * Gout + go) * (long)keep + lane) * 2;
+            po[0] = (uint8_t)a;
+            po[1] = (uint8_t)bb;
+        }
     }
 }
 
