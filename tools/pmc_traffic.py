@@ -4,7 +4,7 @@ usage: pmc_traffic.py gpurun_out/<pmc dir> > profiles/r01_pmc_traffic.json"""
 import collections, csv, glob, json, os, re, sys
 root = sys.argv[1]
 KERNELS = {"logits_argmax": "k_gemm8s<16, 0, 4>", "residual": "k_residual_reg<8, 2>", "stage0_gemm": "k_gemm8s<16, 3, 4>",
-           "pair_L1_K16": "k_pair<1, 16, true, 0>", "pair_L2_K16": "k_pair<2, 16, false, 0>", "pair_L4_K32": "k_pair<4, 32, false, 0>"}
+           "pair_L1_K16": "k_pair<1, 16, true, 0, false>", "pair_L2_K16": "k_pair<2, 16, false, 0, false>", "pair_L4_K32": "k_pair<4, 32, false, 0, true>"}
 vals = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(root, "*", "*", "*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
