@@ -228,7 +228,7 @@ int launch_pair_t(const float *C, const uint8_t *idx, const float *E, const uint
                            S_in, B, N, K, Dp, Gout, keep, win, tup_out, S_out, idx_final, nact, nullptr, nullptr, nullptr); \
         return 0;                                                                                                     \
     }
-    MCQ_PAIR_ABL_CASE(1) MCQ_PAIR_ABL_CASE(2) MCQ_PAIR_ABL_CASE(3) MCQ_PAIR_ABL_CASE(4) MCQ_PAIR_ABL_CASE(5) MCQ_PAIR_ABL_CASE(6)
+    MCQ_PAIR_ABL_CASE(1) MCQ_PAIR_ABL_CASE(2) MCQ_PAIR_ABL_CASE(3) MCQ_PAIR_ABL_CASE(4) MCQ_PAIR_ABL_CASE(5) MCQ_PAIR_ABL_CASE(6) MCQ_PAIR_ABL_CASE(7)
 #undef MCQ_PAIR_ABL_CASE
     if constexpr (L == 4 && KI == 32) {
         if (dedup) {

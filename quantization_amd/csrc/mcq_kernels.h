@@ -1147,10 +1147,10 @@ k_pair(const float *__restrict__ C, const uint8_t *__restrict__ idx, const float
     };
     const char *Cb = reinterpret_cast<const char *>(C);   // byte offsets (< 2^32) from the uniform base
     const f32x4 abl_const = {Eb, Eb + 1.f, Eb + 2.f, Eb + 3.f};
-#define MCQ_PAIR_GATHER(expr) ((ABL == 4) ? abl_const : *reinterpret_cast<const f32x4 *>(expr))
+#define MCQ_PAIR_GATHER(expr) ((ABL == 4 || ABL == 7) ? abl_const : *reinterpret_cast<const f32x4 *>(expr))
     auto to_mfma_order = [&](f32x4 v, int slot) {
         f32x4 o;
-        if constexpr (ABL == 3) {
+        if constexpr (ABL == 3 || ABL == 7) {
             return v;
         } else if constexpr (XL) {
             f32x4 *t = xpose + slot * 64;
@@ -1208,7 +1208,7 @@ k_pair(const float *__restrict__ C, const uint8_t *__restrict__ idx, const float
             for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
                 for (int tj = 0; tj < TI; ++tj) {
-                    if constexpr (ABL == 2) acc[ti][tj][i] += da[ti][i] + db[tj][i];
+                    if constexpr (ABL == 2 || ABL == 7) acc[ti][tj][i] += da[ti][i] + db[tj][i];
                     else acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(da[ti][i], db[tj][i], acc[ti][tj], 0, 0, 0);
                 }
     };
