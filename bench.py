@@ -227,6 +227,7 @@ def main():
         "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2),
                      "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
+                     "measured_issue_ceiling": 152.5,   # TFLOP/s: 33 cycles per v_mfma_f32_16x16x4_f32 at 2.4 GHz (tools/micro/mfma_chain.hip)
                      "gflop_per_launch": round(dom_fl / 1e9, 2),
                      "avg_launch_ms": round(float(dom_ms), 4)},
         "kernels": kernels,
