@@ -220,6 +220,7 @@ int launch_pair_t(const float *C, const uint8_t *idx, const float *E, const uint
         if (v >= 1 && v <= 4 && per_wave * v <= 65536) wpb = v;
     }
     const unsigned grid = (unsigned)(((B + wpb - 1) / wpb) * Gout);
+#ifdef MCQ_ABLATE   // timing experiments with WRONG results: only in the separate library tools/pair_ablate.sh builds
     static const int abl = getenv("MCQ_PAIR_ABL") ? atoi(getenv("MCQ_PAIR_ABL")) : 0;   // timing experiments (wrong results)
 #define MCQ_PAIR_ABL_CASE(A)                                                                                          \
     if constexpr ((L == 1 && KI == 16) || (L == 2 && KI == 16) || (L == 4 && KI == 32)) /* headline ladder only */      \
@@ -230,6 +231,7 @@ int launch_pair_t(const float *C, const uint8_t *idx, const float *E, const uint
     }
     MCQ_PAIR_ABL_CASE(1) MCQ_PAIR_ABL_CASE(2) MCQ_PAIR_ABL_CASE(3) MCQ_PAIR_ABL_CASE(4) MCQ_PAIR_ABL_CASE(5) MCQ_PAIR_ABL_CASE(6) MCQ_PAIR_ABL_CASE(7)
 #undef MCQ_PAIR_ABL_CASE
+#endif
     if constexpr (L == 4 && KI == 32) {
         if (dedup) {
             hipLaunchKernelGGL((k_pair<L, KI, false, 0, true>), dim3(grid), dim3(64 * wpb), per_wave * wpb, st, C, idx, E, tup_in,

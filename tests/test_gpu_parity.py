@@ -157,6 +157,62 @@ def test_full_size_properties_config_b():
     assert 0.0 < rel < 2.0   # untrained synthetic codebooks: sanity only
 
 
+def test_full_size_config_d():
+    """BASELINE config D at its full size (dim 1024, 16 bytes, B = 65,536): sampled rows vs the oracle, chunk
+    independence, decode bit-exact, and the reference fixture's 512 rows (same seeded state) inside the big batch."""
+    D, K, N, B = 1024, 256, 16, 65536
+    fx = fixtures.load("config_d_d1024_n16")
+    sd = fx["state"]
+    q = load_quantizer(sd, D, K, N)
+    o = oracle_of(sd)
+    x = gen.make_gaussian(4321, B, D)
+    x[1000:1000 + fx["B"]] = fx["x"]                      # the fixture's rows ride inside the full batch
+    xd = torch.from_numpy(x).cuda()
+    codes = q.encode(xd, 5)
+    assert tuple(codes.shape) == (B, N) and codes.dtype == torch.uint8
+    c = codes.cpu().numpy()
+    rows = np.random.RandomState(0).choice(B, 512, replace=False)
+    assert np.array_equal(c[rows], o.encode(x[rows], 5))
+    fixtures.check_codes(fx, 5, c[1000:1000 + fx["B"]], "config D full size (HIP vs reference fixture)")
+    part = torch.cat([q.encode(xd[:777], 5), q.encode(xd[777:3000], 5)])
+    assert torch.equal(part, codes[:3000])
+    y = q.decode(codes)
+    assert np.array_equal(y[rows].cpu().numpy(), o.decode(c[rows]))
+    e5 = float(((y - xd) ** 2).sum())
+    e0 = float(((q.decode(q.encode(xd, 0)) - xd) ** 2).sum())
+    assert e5 < e0
+
+
+def test_config_c_shard_of_one_million_vectors():
+    """BASELINE config C's per-GPU share (dim 512, 8 bytes, 1,048,576 vectors = 16 chunks of 65,536 through
+    mcq_encode's chunk loop): rows of the first / a middle / the last chunk vs the oracle, equality with
+    per-chunk calls, and the reference fixture's rows placed across a chunk boundary."""
+    D, K, N, B = 512, 256, 8, 1 << 20
+    fx = fixtures.load("config_b_d512_n8")
+    sd = fx["state"]
+    q = load_quantizer(sd, D, K, N)
+    o = oracle_of(sd)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(77)
+    xd = torch.randn(B, D, generator=g, device="cuda")
+    lo = 65536 * 3 - 2000                                     # 4,096 fixture rows straddle the chunk 2 / chunk 3 border
+    xd[lo:lo + fx["B"]] = torch.from_numpy(fx["x"]).cuda()
+    codes = q.encode(xd, 5)
+    assert tuple(codes.shape) == (B, N)
+    fixtures.check_codes(fx, 5, codes[lo:lo + fx["B"]].cpu().numpy(), "1M shard (HIP vs reference fixture)")
+    rs = np.random.RandomState(5)
+    for c0 in (0, 7, 15):
+        rows = c0 * 65536 + rs.choice(65536, 96, replace=False)
+        want = o.encode(xd[rows].cpu().numpy(), 5)
+        assert np.array_equal(codes[rows].cpu().numpy(), want), c0
+    for c0 in (0, 9, 15):                                     # the chunk loop equals separate calls
+        sl = slice(c0 * 65536, (c0 + 1) * 65536)
+        assert torch.equal(q.encode(xd[sl], 5), codes[sl]), c0
+    y = q.decode(codes)                                       # LDS-resident decode at this size
+    rows = rs.choice(B, 256, replace=False)
+    assert np.array_equal(y[rows].cpu().numpy(), o.decode(codes[rows].cpu().numpy()))
+
+
 def test_cpu_tensor_is_rejected_loudly():
     fx = fixtures.load("synth_d32_k256_n2")
     q = load_quantizer(fx["state"], fx["D"], fx["K"], fx["N"])
