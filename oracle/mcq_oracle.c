@@ -34,6 +34,25 @@
  *   S' = ((Se + So) - E) + 2*dot   (:533-535),  delta = c - old  (:436-439),
  *   delta' = delta_e + delta_o (:538-541), x_err = (old_0 + old_1 + ...) - x.
  *   selections are by (value, position) ascending, lowest position on ties.
+ *
+ * TABLE FORM (2 <= N <= 16; the direct form above stays for N == 1 and N >= 32).
+ * The search's inner products are linear in codebook rows, so they are read from
+ * tables instead of being recomputed per vector and pass (gate run:
+ * tools/exp_gram/results_r02.txt -- same codes as the direct form on every fixture):
+ *   G[r][c]  = dot16(C[r], C[c])        Gram matrix of all N*K scaled centers (per state)
+ *   XC[b][r] = dot16(C[r], x[b])        one GEMM per encode call (x zero padded, unscaled)
+ *   stage 0:  X[b,n,k] = (G[(m0,i_m0)][(n,k)] + G[(m1,i_m1)][(n,k)] + ...) - XC[b][(n,k)],
+ *             m ascending over the codebooks m != n (x_rem = sum_{m != n} old_m - x), then
+ *             S = (R + Q) + 2 X as before; R and E are still computed from x_err directly.
+ *   leaf tables (codebooks n < m, shortlist positions i, j; o_n = current entry of n):
+ *             D[n][m][i][j] = ((G[s_n,i][s_m,j] - G[s_n,i][o_m]) - G[o_n][s_m,j]) + G[o_n][o_m]
+ *             = delta_n[i] . delta_m[j]  with delta = c - old  (:436-439)
+ *   group tables (groups X < Y of l codebooks; candidate i of X is the pair (i0, i1) of
+ *             candidates of its halves X0, X1, likewise j of Y; :538-541 distributes over the dot):
+ *             T_l[X][Y][i][j] = ((T_h[X0][Y0][i0][j0] + T_h[X0][Y1][i0][j1]) + T_h[X1][Y0][i1][j0])
+ *                               + T_h[X1][Y1][i1][j1],   h = l/2,  T_1 = D
+ *   combine of the siblings X = 2g, Y = 2g+1:  S' = ((S_X[i] + S_Y[j]) - E) + 2 T_l[X][Y][i][j].
+ * Every operation is a single IEEE fp32 add/sub in the order written.
  */
 #include <math.h>
 #include <stdint.h>
@@ -52,6 +71,8 @@ typedef struct {
     float *bias;   /* [N*K]                                               */
     float lscale;  /* exp(10*logits_scale), computed by the caller        */
     int *order16;  /* [Dp]                                                */
+    int table_form; /* 2 <= N <= 16: inner products from the Gram matrix  */
+    float *G;      /* [N*K][N*K]   dot16(C[r], C[c]); built on first use  */
 } mcq_oracle;
 
 static int round_up16(int d) { return (d + 15) & ~15; }
@@ -77,6 +98,7 @@ mcq_oracle *mcq_oracle_create(const float *centers, float cscale_exp, const floa
     mcq_oracle *o = (mcq_oracle *)calloc(1, sizeof(mcq_oracle));
     int Dp = round_up16(D);
     o->N = N; o->K = K; o->D = D; o->Dp = Dp; o->lscale = lscale_exp;
+    o->table_form = (N >= 2 && N <= 16);
     o->order16 = (int *)malloc(sizeof(int) * Dp);
     for (int i = 0; i < Dp; i++) {
         int blk = i / 16, w = i % 16;
@@ -109,7 +131,7 @@ mcq_oracle *mcq_oracle_create(const float *centers, float cscale_exp, const floa
 
 void mcq_oracle_free(mcq_oracle *o) {
     if (!o) return;
-    free(o->C); free(o->CT); free(o->Q); free(o->WT); free(o->bias); free(o->order16); free(o);
+    free(o->C); free(o->CT); free(o->Q); free(o->WT); free(o->bias); free(o->order16); free(o->G); free(o);
 }
 
 /* copy of the scaled centers (N,K,D) and their sumsq, for tests */
@@ -337,6 +359,209 @@ static void refine_one(const mcq_oracle *o, const float *x, uint8_t *idx, scratc
     memcpy(idx, tcur, N);
 }
 
+
+/* ---------------------------------------------------------------- table form */
+/* G[r][c] = dot16(C[r], C[c]) for rows in different codebooks (the blocks on the diagonal are never
+ * read and stay zero).  fmaf(a, b, acc) is symmetric in a, b, so G[c][r] == G[r][c] bit for bit. */
+static void build_gram(mcq_oracle *o) {
+    const int N = o->N, K = o->K, Dp = o->Dp;
+    const size_t nk = (size_t)N * K;
+    float *G = (float *)calloc(nk * nk, sizeof(float));
+#pragma omp parallel for schedule(dynamic, 8)
+    for (long r = 0; r < (long)nk; r++) {
+        const float *cr = o->C + (size_t)r * Dp;
+        const int nr = (int)(r / K);
+        for (int m = nr + 1; m < N; m++) {
+            float *acc = G + (size_t)r * nk + (size_t)m * K;
+            for (int i = 0; i < Dp; i++) {
+                const float xv = cr[o->order16[i]];
+                const float *ct = o->CT + ((size_t)m * Dp + i) * K;
+                for (int k = 0; k < K; k++) acc[k] = fmaf(ct[k], xv, acc[k]);
+            }
+        }
+    }
+    for (size_t r = 0; r < nk; r++)
+        for (size_t c = 0; c < (r / K) * K; c++) G[r * nk + c] = G[c * nk + r];
+    o->G = G;
+}
+
+static void ensure_gram(const mcq_oracle *o) {
+    if (o->table_form && !o->G) build_gram((mcq_oracle *)o);
+}
+
+/* XC[r] = dot16(C[r], x) for all N*K rows (x unscaled, zero padded) */
+static void compute_xc(const mcq_oracle *o, const float *x, float *xc) {
+    const int N = o->N, K = o->K, D = o->D, Dp = o->Dp;
+    for (size_t r = 0; r < (size_t)N * K; r++) xc[r] = 0.0f;
+    for (int n = 0; n < N; n++)
+        for (int i = 0; i < Dp; i++) {
+            const int d = o->order16[i];
+            const float xv = (d < D) ? x[d] : 0.0f;
+            const float *ct = o->CT + ((size_t)n * Dp + i) * K;
+            float *acc = xc + (size_t)n * K;
+            for (int k = 0; k < K; k++) acc[k] = fmaf(ct[k], xv, acc[k]);
+        }
+}
+
+#define MCQ_MAX_LEVELS 5   /* candidates of 1, 2, 4, 8, 16 codebooks (N <= 16) */
+typedef struct {
+    int kc[MCQ_MAX_LEVELS];                 /* list length per level                             */
+    uint8_t *ent1;                          /* [N][kc[0]] codebook entries of the level-0 lists  */
+    uint8_t *pos[MCQ_MAX_LEVELS];           /* level v >= 1: [N >> v][kc[v]][2] positions in the halves' lists */
+    float *S[MCQ_MAX_LEVELS];               /* [N >> v][kc[v]] scores                            */
+} tf_lists;
+
+/* T[X][Y] of level v (groups of 2^v codebooks, X < Y), kc[v] x kc[v] floats into `out` */
+static void tf_table(const mcq_oracle *o, const uint8_t *idx, const tf_lists *L, int v, int X, int Y, float *out) {
+    const int K = o->K;
+    const size_t nk = (size_t)o->N * K;
+    const int kc = L->kc[v];
+    if (v == 0) {
+        const float *G = o->G;
+        const size_t on = (size_t)X * K + idx[X], om = (size_t)Y * K + idx[Y];
+        const uint8_t *en = L->ent1 + (size_t)X * kc, *em = L->ent1 + (size_t)Y * kc;
+        const float w = G[on * nk + om];
+        for (int i = 0; i < kc; i++) {
+            const size_t sn = (size_t)X * K + en[i];
+            const float u = G[sn * nk + om];
+            for (int j = 0; j < kc; j++) {
+                const size_t sm = (size_t)Y * K + em[j];
+                out[i * kc + j] = ((G[sn * nk + sm] - u) - G[on * nk + sm]) + w;
+            }
+        }
+        return;
+    }
+    const int kh = L->kc[v - 1];
+    float *t = (float *)malloc(sizeof(float) * 4 * kh * kh);
+    tf_table(o, idx, L, v - 1, 2 * X, 2 * Y, t);
+    tf_table(o, idx, L, v - 1, 2 * X, 2 * Y + 1, t + kh * kh);
+    tf_table(o, idx, L, v - 1, 2 * X + 1, 2 * Y, t + 2 * kh * kh);
+    tf_table(o, idx, L, v - 1, 2 * X + 1, 2 * Y + 1, t + 3 * kh * kh);
+    const uint8_t *px = L->pos[v] + (size_t)X * kc * 2, *py = L->pos[v] + (size_t)Y * kc * 2;
+    for (int i = 0; i < kc; i++) {
+        const int i0 = px[2 * i], i1 = px[2 * i + 1];
+        for (int j = 0; j < kc; j++) {
+            const int j0 = py[2 * j], j1 = py[2 * j + 1];
+            out[i * kc + j] = ((t[i0 * kh + j0] + t[kh * kh + i0 * kh + j1]) + t[2 * kh * kh + i1 * kh + j0]) +
+                              t[3 * kh * kh + i1 * kh + j1];
+        }
+    }
+    free(t);
+}
+
+/* one _refine_indexes pass for one vector in table form; xc = compute_xc(x); idx updated in place */
+static void refine_one_table(const mcq_oracle *o, const float *x, const float *xc, uint8_t *idx, scratch *s,
+                             mcq_trace *tr) {
+    const int N = o->N, K = o->K, D = o->D, Dp = o->Dp;
+    const size_t nk = (size_t)N * K;
+    for (int n = 0; n < N; n++)
+        memcpy(s->old + (size_t)n * Dp, o->C + ((size_t)n * K + idx[n]) * Dp, sizeof(float) * Dp);
+    for (int d = 0; d < Dp; d++) {
+        float t = s->old[d];
+        for (int n = 1; n < N; n++) t = t + s->old[(size_t)n * Dp + d];
+        s->xerr[d] = t - ((d < D) ? x[d] : 0.0f);
+    }
+    const float E = sumsq64(s->xerr, Dp);
+    if (tr && tr->xerr) memcpy(tr->xerr, s->xerr, sizeof(float) * Dp);
+    if (tr && tr->E) tr->E[0] = E;
+
+    /* stage 0 (:403-418) with X from the tables */
+    for (int n = 0; n < N; n++) {
+        const float *old = s->old + (size_t)n * Dp;
+        for (int d = 0; d < Dp; d++) s->xrem[d] = s->xerr[d] - old[d];
+        const float R = sumsq64(s->xrem, Dp);
+        if (tr && tr->R) tr->R[n] = R;
+        float *acc = s->S + (size_t)n * K;
+        const float *Q = o->Q + (size_t)n * K;
+        for (int k = 0; k < K; k++) {
+            float t = 0.0f;
+            int first = 1;
+            for (int m = 0; m < N; m++) {
+                if (m == n) continue;
+                const float g = o->G[((size_t)m * K + idx[m]) * nk + (size_t)n * K + k];
+                t = first ? g : t + g;
+                first = 0;
+            }
+            const float X = t - xc[(size_t)n * K + k];
+            acc[k] = (R + Q[k]) + 2.0f * X;
+        }
+    }
+    if (tr && tr->S0) memcpy(tr->S0, s->S, sizeof(float) * N * K);
+
+    int nlev = 0;
+    while ((1 << nlev) < N) nlev++;                 /* levels 0 .. nlev-1 hold lists; level nlev is the result */
+    tf_lists L;
+    memset(&L, 0, sizeof(L));
+    for (int v = 0; v < nlev; v++) L.kc[v] = k_cutoff(K, 1 << v);
+    L.ent1 = (uint8_t *)malloc((size_t)N * L.kc[0]);
+    for (int v = 0; v < nlev; v++) {
+        L.S[v] = (float *)malloc(sizeof(float) * (N >> v) * L.kc[v]);
+        if (v > 0) L.pos[v] = (uint8_t *)malloc((size_t)(N >> v) * L.kc[v] * 2);
+    }
+    int tr_sel = 0, tr_comb = 0;
+    for (int n = 0; n < N; n++) {                   /* first sort-and-truncate (:470-503) */
+        select_smallest(s->S + (size_t)n * K, K, L.kc[0], s->pos, L.S[0] + (size_t)n * L.kc[0]);
+        for (int j = 0; j < L.kc[0]; j++) {
+            L.ent1[(size_t)n * L.kc[0] + j] = (uint8_t)s->pos[j];
+            if (tr && tr->sel_pos) { tr->sel_pos[tr_sel] = s->pos[j]; tr->sel_val[tr_sel] = L.S[0][(size_t)n * L.kc[0] + j]; tr_sel++; }
+        }
+    }
+    int win = 0;                                    /* position of the winner in the two top-level lists */
+    for (int v = 0; v < nlev; v++) {                /* combine the siblings of level v (:504-547) */
+        const int groups = N >> (v + 1), kc = L.kc[v], M = kc * kc;
+        const int keep = (groups == 1) ? 1 : L.kc[v + 1];
+        for (int g = 0; g < groups; g++) {
+            float *sc = s->S + (size_t)g * M;
+            tf_table(o, idx, &L, v, 2 * g, 2 * g + 1, sc);
+            const float *se = L.S[v] + (size_t)(2 * g) * kc, *so = L.S[v] + (size_t)(2 * g + 1) * kc;
+            for (int a = 0; a < kc; a++)
+                for (int b = 0; b < kc; b++) {
+                    float *q = sc + (size_t)a * kc + b;
+                    *q = ((se[a] + so[b]) - E) + 2.0f * (*q);      /* (:533-535) */
+                }
+            if (tr && tr->comb) { memcpy(tr->comb + tr_comb, sc, sizeof(float) * M); tr_comb += M; }
+        }
+        for (int g = 0; g < groups; g++) {
+            float *sv = (float *)malloc(sizeof(float) * keep);
+            select_smallest(s->S + (size_t)g * M, M, keep, s->pos, sv);
+            for (int j = 0; j < keep; j++) {
+                if (groups > 1) {
+                    L.pos[v + 1][((size_t)g * keep + j) * 2] = (uint8_t)(s->pos[j] / kc);
+                    L.pos[v + 1][((size_t)g * keep + j) * 2 + 1] = (uint8_t)(s->pos[j] % kc);
+                    L.S[v + 1][(size_t)g * keep + j] = sv[j];
+                } else {
+                    win = s->pos[j];
+                }
+                if (tr && tr->sel_pos) { tr->sel_pos[tr_sel] = s->pos[j]; tr->sel_val[tr_sel] = sv[j]; tr_sel++; }
+            }
+            free(sv);
+        }
+    }
+    /* the winner's leaves, codebook by codebook (:468-469): walk down the position tree */
+    uint8_t res[64];
+    for (int n = 0; n < N; n++) {
+        int v = nlev - 1, g = 0;
+        int p = ((n >> v) & 1) ? win % L.kc[v] : win / L.kc[v];   /* position in the level-v list of group n >> v */
+        g = n >> v;
+        while (v > 0) {
+            const int child = (n >> (v - 1)) & 1;
+            p = L.pos[v][((size_t)g * L.kc[v] + p) * 2 + child];
+            v--;
+            g = n >> v;
+        }
+        res[n] = L.ent1[(size_t)n * L.kc[0] + p];
+    }
+    memcpy(idx, res, N);
+    free(L.ent1);
+    for (int v = 0; v < nlev; v++) { free(L.S[v]); free(L.pos[v]); }
+}
+
+/* one pass in whichever form the state uses; xc may be NULL for the direct form */
+static void refine_any(const mcq_oracle *o, const float *x, const float *xc, uint8_t *idx, scratch *s, mcq_trace *tr) {
+    if (o->table_form) refine_one_table(o, x, xc, idx, s, tr);
+    else refine_one(o, x, idx, s, tr);
+}
+
 /* _compute_indexes for a batch (:281-305).  idx: uint8 [B][N]. */
 int mcq_oracle_compute_indexes(const mcq_oracle *o, const float *x, long B, int iters, uint8_t *idx,
                                int nthreads) {
@@ -348,18 +573,21 @@ int mcq_oracle_compute_indexes(const mcq_oracle *o, const float *x, long B, int 
 #else
     (void)nthreads;
 #endif
+    if (iters > 0) ensure_gram(o);
 #pragma omp parallel
     {
         scratch s; scratch_alloc(&s, N, K, Dp);
         float *acc = (float *)malloc(sizeof(float) * N * K);
         float *sx = (float *)malloc(sizeof(float) * Dp);
+        float *xc = (float *)malloc(sizeof(float) * N * K);
 #pragma omp for schedule(dynamic, 8)
         for (long b = 0; b < B; b++) {
             uint8_t *id = idx + (size_t)b * N;
             init_indexes(o, x + (size_t)b * D, id, acc, sx);
-            for (int it = 0; it < iters; it++) refine_one(o, x + (size_t)b * D, id, &s, NULL);
+            if (o->table_form && iters > 0) compute_xc(o, x + (size_t)b * D, xc);
+            for (int it = 0; it < iters; it++) refine_any(o, x + (size_t)b * D, xc, id, &s, NULL);
         }
-        free(acc); free(sx); scratch_free(&s);
+        free(acc); free(sx); free(xc); scratch_free(&s);
     }
     return 0;
 }
@@ -373,13 +601,17 @@ int mcq_oracle_refine(const mcq_oracle *o, const float *x, long B, int iters, ui
 #else
     (void)nthreads;
 #endif
+    if (iters > 0) ensure_gram(o);
 #pragma omp parallel
     {
         scratch s; scratch_alloc(&s, N, K, Dp);
+        float *xc = (float *)malloc(sizeof(float) * N * K);
 #pragma omp for schedule(dynamic, 8)
-        for (long b = 0; b < B; b++)
-            for (int it = 0; it < iters; it++) refine_one(o, x + (size_t)b * D, idx + (size_t)b * N, &s, NULL);
-        scratch_free(&s);
+        for (long b = 0; b < B; b++) {
+            if (o->table_form && iters > 0) compute_xc(o, x + (size_t)b * D, xc);
+            for (int it = 0; it < iters; it++) refine_any(o, x + (size_t)b * D, xc, idx + (size_t)b * N, &s, NULL);
+        }
+        free(xc); scratch_free(&s);
     }
     return 0;
 }
@@ -389,7 +621,11 @@ int mcq_oracle_refine_trace(const mcq_oracle *o, const float *x, uint8_t *idx, f
                             float *R, float *S0, int *sel_pos, float *sel_val, float *comb) {
     scratch s; scratch_alloc(&s, o->N, o->K, o->Dp);
     mcq_trace tr = {xerr, E, R, S0, sel_pos, sel_val, comb};
-    refine_one(o, x, idx, &s, &tr);
+    float *xc = (float *)malloc(sizeof(float) * o->N * o->K);
+    ensure_gram(o);
+    if (o->table_form) compute_xc(o, x, xc);
+    refine_any(o, x, xc, idx, &s, &tr);
+    free(xc);
     scratch_free(&s);
     return 0;
 }
