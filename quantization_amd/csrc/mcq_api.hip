@@ -3,6 +3,7 @@
 #include "../../include/mcq.h"
 #include "mcq_kernels.h"
 #include "mcq_loss_kernels.h"
+#include "mcq_tf_kernels.h"
 
 #include <cstdlib>
 #include <vector>
@@ -23,12 +24,15 @@ int k_cutoff(int K, int L) {
 }
 
 struct Prepared {
-    const float *C, *Q, *W, *bias, *scales;
+    const float *C, *Q, *W, *bias, *scales, *G;
 };
 
 struct PreparedLayout {
-    size_t offC, offQ, offW, offBias, offScales, total;
+    size_t offC, offQ, offW, offBias, offScales, offG, total;
 };
+
+// table form of the refinement (mcq_tf_kernels.h; oracle/mcq_oracle.c "TABLE FORM"): 2 <= N <= 16
+inline bool table_form(int N) { return N >= 2 && N <= 16; }
 
 PreparedLayout prepared_layout(int N, int K, int D) {
     const size_t nk = (size_t)N * K, Dp = round_up16(D);
@@ -38,7 +42,8 @@ PreparedLayout prepared_layout(int N, int K, int D) {
     l.offW = align256(l.offQ + nk * 4);
     l.offBias = align256(l.offW + nk * Dp * 4);
     l.offScales = align256(l.offBias + nk * 4);   // float[2] {cscale_exp, lscale_exp} (mcq_prepare_dev)
-    l.total = align256(l.offScales + 8);
+    l.offG = align256(l.offScales + 8);           // Gram matrix G[nk][nk] of the scaled centers (table form only)
+    l.total = align256(l.offG + (table_form(N) ? nk * nk * 4 : 0));
     return l;
 }
 
@@ -47,13 +52,16 @@ Prepared prepared_view(const void *p, int N, int K, int D) {
     const char *b = static_cast<const char *>(p);
     return Prepared{reinterpret_cast<const float *>(b + l.offC), reinterpret_cast<const float *>(b + l.offQ),
                     reinterpret_cast<const float *>(b + l.offW), reinterpret_cast<const float *>(b + l.offBias),
-                    reinterpret_cast<const float *>(b + l.offScales)};
+                    reinterpret_cast<const float *>(b + l.offScales), reinterpret_cast<const float *>(b + l.offG)};
 }
 
 struct Workspace {
     uint8_t *idx, *idxB, *idxC, *final_idx;   // B, C, final: fixed-point skipping only
     int *map[2], *cnt;
     float *xerr, *E, *R, *S0;
+    // table form: x.C products, the lists of every level, the level-1 tables of cousin groups
+    float *XC, *tabs;
+    TfLists tf;
     uint8_t *tup[3];   // three-way rotation: a DEDUP pair stage also reads the lists of two stages back
     uint8_t *pos;      // (a, b) of every candidate kept by the stage before a DEDUP stage
     float *S[2];
@@ -66,12 +74,20 @@ bool fused_select(int N, int K) {
     return !off && K >= 32 && N >= 2;
 }
 
+int tf_ntab(int N) { return N >= 16 ? 16 : (N >= 8 ? 4 : 0); }
+
 size_t workspace_per_vector(int N, int K, int Dp) {
+    if (table_form(N)) {
+        // idx x4, maps, xerr, E, R, XC, lists (entries / positions / scores: <= 16 + 4*16 B per codebook and level), tabs
+        const int kc1 = k_cutoff(K, 2);
+        return 4 * (size_t)N + 8 + 4 * (size_t)Dp + 4 + 4 * (size_t)N + 4 * (size_t)N * K + kTfLevels * (size_t)N * (16 + 2 * 16 + 4 * 16) +
+               (size_t)tf_ntab(N) * kc1 * kc1 * 4;
+    }
     const size_t s0 = fused_select(N, K) ? 0 : 4 * (size_t)N * K;
     return 4 * (size_t)N + 8 + 4 * (size_t)Dp + 4 + 4 * (size_t)N + s0 + 3 * 64 * (size_t)N + 16 * (size_t)N +
            2 * 4 * 16 * (size_t)N;
 }
-constexpr size_t kWorkspaceSlack = 24 * 256;
+constexpr size_t kWorkspaceSlack = 40 * 256;
 constexpr long kDefaultChunk = 65536;
 
 Workspace carve(void *ws, long Bc, int N, int K, int Dp) {
@@ -88,6 +104,27 @@ Workspace carve(void *ws, long Bc, int N, int K, int Dp) {
     w.xerr = reinterpret_cast<float *>(take((size_t)Bc * Dp * 4));
     w.E = reinterpret_cast<float *>(take((size_t)Bc * 4));
     w.R = reinterpret_cast<float *>(take((size_t)Bc * N * 4));
+    if (table_form(N)) {
+        w.S0 = nullptr;
+        w.XC = reinterpret_cast<float *>(take((size_t)Bc * N * K * 4));
+        for (int v = 0; v < kTfLevels; ++v) {
+            const int kc = k_cutoff(K, 1 << v);
+            w.tf.kc[v] = kc;
+            w.tf.pos[v] = nullptr;
+            w.tf.S[v] = nullptr;
+            if ((N >> v) < 2) continue;                    // no list of that level
+            if (v == 0) w.tf.ent = reinterpret_cast<uint8_t *>(take((size_t)Bc * N * kc));
+            else w.tf.pos[v] = reinterpret_cast<uint8_t *>(take((size_t)Bc * (N >> v) * kc * 2));
+            w.tf.S[v] = reinterpret_cast<float *>(take((size_t)Bc * (N >> v) * kc * 4));
+        }
+        const int kc1 = k_cutoff(K, 2);
+        w.tabs = tf_ntab(N) ? reinterpret_cast<float *>(take((size_t)Bc * tf_ntab(N) * kc1 * kc1 * 4)) : nullptr;
+        for (int i = 0; i < 3; ++i) w.tup[i] = nullptr;
+        w.pos = nullptr;
+        w.S[0] = w.S[1] = nullptr;
+        return w;
+    }
+    w.XC = w.tabs = nullptr;
     w.S0 = fused_select(N, K) ? nullptr : reinterpret_cast<float *>(take((size_t)Bc * N * K * 4));
     for (int i = 0; i < 3; ++i) w.tup[i] = reinterpret_cast<uint8_t *>(take((size_t)Bc * N * 64));
     w.pos = reinterpret_cast<uint8_t *>(take((size_t)Bc * N * 16));
@@ -324,6 +361,92 @@ int launch_residual(const float *x, const uint8_t *idx, const float *C, long B, 
     return 0;
 }
 
+
+// ---------------------------------------------------------------- table form
+#define MCQ_TF_CHECK() MCQ_LAUNCH_CHECK()
+
+template <int K>
+int launch_tf_stage0_k(int N, const float *G, const float *XC, const uint8_t *idx, const float *R, const float *Q, long B,
+                       int keep, uint8_t *ent, float *S, const int *nact, const int *map, hipStream_t st) {
+    const dim3 grid((unsigned)(((B + 3) / 4) * N)), block(256);
+    switch (N) {
+        case 2: hipLaunchKernelGGL((k_tf_stage0<K, 2>), grid, block, 0, st, G, XC, idx, R, Q, B, keep, ent, S, nact, map); break;
+        case 4: hipLaunchKernelGGL((k_tf_stage0<K, 4>), grid, block, 0, st, G, XC, idx, R, Q, B, keep, ent, S, nact, map); break;
+        case 8: hipLaunchKernelGGL((k_tf_stage0<K, 8>), grid, block, 0, st, G, XC, idx, R, Q, B, keep, ent, S, nact, map); break;
+        case 16: hipLaunchKernelGGL((k_tf_stage0<K, 16>), grid, block, 0, st, G, XC, idx, R, Q, B, keep, ent, S, nact, map); break;
+        default: return MCQ_EUNSUPPORTED;
+    }
+    MCQ_TF_CHECK();
+    return 0;
+}
+
+int launch_tf_stage0(int K, int N, const float *G, const float *XC, const uint8_t *idx, const float *R, const float *Q,
+                     long B, int keep, uint8_t *ent, float *S, const int *nact, const int *map, hipStream_t st) {
+    switch (K) {
+        case 16: return launch_tf_stage0_k<16>(N, G, XC, idx, R, Q, B, keep, ent, S, nact, map, st);
+        case 32: return launch_tf_stage0_k<32>(N, G, XC, idx, R, Q, B, keep, ent, S, nact, map, st);
+        case 64: return launch_tf_stage0_k<64>(N, G, XC, idx, R, Q, B, keep, ent, S, nact, map, st);
+        case 128: return launch_tf_stage0_k<128>(N, G, XC, idx, R, Q, B, keep, ent, S, nact, map, st);
+        case 256: return launch_tf_stage0_k<256>(N, G, XC, idx, R, Q, B, keep, ent, S, nact, map, st);
+        default: return MCQ_EUNSUPPORTED;
+    }
+}
+
+// the combines of one refinement pass in table form; lists of K >= 32 hold 16, 16, 32, 32 candidates, of K == 16: 8, 8, 16, 16
+int run_tf_combines(const float *G, const uint8_t *idx_cur, uint8_t *idx_new, const Workspace &w, long B, int N, int K,
+                    const int *nact, hipStream_t st, Prof *prof) {
+    const bool small = (K == 16);
+    const TfLists &L = w.tf;
+    // level 0: single codebooks
+    {
+        const int keep = (N == 2) ? 1 : L.kc[1];
+        uint8_t *fin = (N == 2) ? idx_new : nullptr;
+        const dim3 grid((unsigned)(B * (N / 2)));
+        if (prof) prof->begin();
+        if (small) hipLaunchKernelGGL((k_tf_pair0<8>), grid, dim3(64), 0, st, G, idx_cur, w.E, L, B, N, K, keep, fin, nact);
+        else hipLaunchKernelGGL((k_tf_pair0<16>), grid, dim3(64), 0, st, G, idx_cur, w.E, L, B, N, K, keep, fin, nact);
+        MCQ_TF_CHECK();
+        if (prof) prof->end(4);
+    }
+    if (N >= 4) {   // level 1: pairs of codebooks
+        const int keep = (N == 4) ? 1 : L.kc[2];
+        uint8_t *fin = (N == 4) ? idx_new : nullptr;
+        const dim3 grid((unsigned)(B * (N / 4)));
+        if (prof) prof->begin();
+        if (small) hipLaunchKernelGGL((k_tf_pair1<8, 8>), grid, dim3(64), 0, st, G, idx_cur, w.E, L, B, N, K, keep, fin, nact);
+        else hipLaunchKernelGGL((k_tf_pair1<16, 16>), grid, dim3(64), 0, st, G, idx_cur, w.E, L, B, N, K, keep, fin, nact);
+        MCQ_TF_CHECK();
+        if (prof) prof->end(5);
+    }
+    if (N >= 8) {   // level 2: the level-1 tables of the cousins, then the groups of four
+        const int ntab = 4 * (N / 8);
+        const int keep = (N == 8) ? 1 : L.kc[3];
+        uint8_t *fin = (N == 8) ? idx_new : nullptr;
+        if (prof) prof->begin();
+        if (small) hipLaunchKernelGGL((k_tf_table1<8, 8>), dim3((unsigned)(B * ntab)), dim3(64), 0, st, G, idx_cur, L, B, N, K, ntab, 0, w.tabs, nact);
+        else hipLaunchKernelGGL((k_tf_table1<16, 16>), dim3((unsigned)(B * ntab)), dim3(64), 0, st, G, idx_cur, L, B, N, K, ntab, 0, w.tabs, nact);
+        MCQ_TF_CHECK();
+        if (prof) { prof->end(6); prof->begin(); }
+        const dim3 grid((unsigned)(B * (N / 8)));
+        if (small) hipLaunchKernelGGL((k_tf_comb2<8, 16>), grid, dim3(64), 0, st, idx_cur, w.E, L, B, N, keep, ntab, w.tabs, fin, nact);
+        else hipLaunchKernelGGL((k_tf_comb2<16, 32>), grid, dim3(64), 0, st, idx_cur, w.E, L, B, N, keep, ntab, w.tabs, fin, nact);
+        MCQ_TF_CHECK();
+        if (prof) prof->end(7);
+    }
+    if (N >= 16) {  // level 3: sixteen level-1 tables, then the two groups of eight
+        if (prof) prof->begin();
+        if (small) hipLaunchKernelGGL((k_tf_table1<8, 8>), dim3((unsigned)(B * 16)), dim3(64), 0, st, G, idx_cur, L, B, N, K, 16, 1, w.tabs, nact);
+        else hipLaunchKernelGGL((k_tf_table1<16, 16>), dim3((unsigned)(B * 16)), dim3(64), 0, st, G, idx_cur, L, B, N, K, 16, 1, w.tabs, nact);
+        MCQ_TF_CHECK();
+        if (prof) { prof->end(8); prof->begin(); }
+        if (small) hipLaunchKernelGGL((k_tf_comb3<8, 16, 16>), dim3((unsigned)B), dim3(64), 0, st, idx_cur, w.E, L, B, N, w.tabs, idx_new, nact);
+        else hipLaunchKernelGGL((k_tf_comb3<16, 32, 32>), dim3((unsigned)B), dim3(64), 0, st, idx_cur, w.E, L, B, N, w.tabs, idx_new, nact);
+        MCQ_TF_CHECK();
+        if (prof) prof->end(9);
+    }
+    return 0;
+}
+
 // categories for profiling
 enum { CAT_LOGITS = 0, CAT_RESIDUAL = 1, CAT_STAGE0 = 2, CAT_PRUNE0 = 3, CAT_PAIR0 = 4 };
 
@@ -367,6 +490,14 @@ int run_encode(const float *x, long B, const void *prepared, float lscale, int N
             if (rc) return rc;
             if (prof) prof->end(CAT_LOGITS);
         }
+        const bool tf = table_form(N);
+        if (tf && iters > 0) {   // x.C products of the chunk, once (the table form's only per-vector GEMM besides the logits)
+            if (prof) prof->begin();
+            rc = launch_gemm<MODE_XC>(K, P.C, xc, nullptr, 1.0f, nullptr, nullptr, nullptr, Bc, N, D, Dp, nullptr, w.XC, st,
+                                      0, nullptr, nullptr, xh);
+            if (rc) return rc;
+            if (prof) prof->end(CAT_PRUNE0);
+        }
         // without skipping: indexes are refined in place in w.idx, nothing is packed
         uint8_t *idx_cur = w.idx, *idx_new = skip ? w.idxB : w.idx, *idx_pk = w.idxC;
         const int *map_cur = nullptr, *nact = nullptr;
@@ -380,7 +511,13 @@ int run_encode(const float *x, long B, const void *prepared, float lscale, int N
             rc = launch_residual(xc, idx_cur, P.C, Bc, N, K, D, Dp, w.xerr, w.E, w.R, st, nact, map_cur, xh);
             if (rc) return rc;
             if (prof) { prof->end(CAT_RESIDUAL); prof->begin(); }
-            if (fused_select(N, K)) {
+            if (tf) {
+                rc = launch_tf_stage0(K, N, P.G, w.XC, idx_cur, w.R, P.Q, Bc, w.tf.kc[0], w.tf.ent, w.tf.S[0], nact, map_cur, st);
+                if (rc) return rc;
+                if (prof) prof->end(CAT_STAGE0);
+                rc = run_tf_combines(P.G, idx_cur, idx_new, w, Bc, N, K, nact, st, prof);
+                if (rc) return rc;
+            } else if (fused_select(N, K)) {
                 // stage-0 scores never reach HBM: the first sort-and-truncate runs in the GEMM epilogue
                 rc = launch_gemm<MODE_STAGE0_SEL>(K, P.C, w.xerr, idx_cur, 0.f, nullptr, w.R, P.Q, Bc, N, D, Dp,
                                                   w.tup[0], w.S[0], st, first_keep, nact);
@@ -396,7 +533,7 @@ int run_encode(const float *x, long B, const void *prepared, float lscale, int N
                 if (rc) return rc;
                 if (prof) prof->end(CAT_PRUNE0);
             }
-            int G = N, L = 1, KI = first_keep, cur = 0, stage = 0;
+            int G = tf ? 1 : N, L = 1, KI = first_keep, cur = 0, stage = 0;
             while (G > 1) {
                 const int Gout = G / 2;
                 const int keep = (Gout == 1) ? 1 : k_cutoff(K, 2 * L);
@@ -475,6 +612,13 @@ static int prepare_impl(const float *centers, float cscale_exp, const float *sca
     if (scales_dev) {
         e = hipMemcpyAsync(b + l.offScales, scales_dev, 8, hipMemcpyDeviceToDevice, st);
         if (e != hipSuccess) return (int)e;
+    }
+    if (weight && table_form(N)) {
+        // Gram matrix of the scaled centers: the same GEMM kernel with the padded rows themselves as the "vectors"
+        const float *C = reinterpret_cast<const float *>(b + l.offC);
+        const int rc = launch_gemm<MODE_XC>(K, C, C, nullptr, 1.0f, nullptr, nullptr, nullptr, rows, N, Dp, Dp, nullptr,
+                                            reinterpret_cast<float *>(b + l.offG), st);
+        if (rc) return rc;
     }
     return 0;
 }

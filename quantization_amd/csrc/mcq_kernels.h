@@ -510,7 +510,9 @@ __global__ void k_residual_regc(const float *__restrict__ x, const uint8_t *__re
 //   MODE_STAGE0_SEL: MODE_STAGE0 + the first sort-and-truncate (:470-503) in the epilogue: the scores
 //                 go through LDS to one wave per vector and only the `keep` survivors reach HBM
 //                 (k_gemm8s only)
-enum { MODE_LOGITS = 0, MODE_STAGE0 = 1, MODE_LOGITS_OUT = 2, MODE_STAGE0_SEL = 3 };
+//   MODE_XC     : A_n[b] = x[b] as is; epilogue: the raw products dot16(Bm[n][k], x[b]) are stored.  Builds the
+//                 table form's XC (Bm = C) and, with the scaled centers themselves as "vectors", the Gram matrix.
+enum { MODE_LOGITS = 0, MODE_STAGE0 = 1, MODE_LOGITS_OUT = 2, MODE_STAGE0_SEL = 3, MODE_XC = 4 };
 
 constexpr int kGemmVec = 64;  // vectors per workgroup
 constexpr int kGemmBK = 32;   // floats of the feature axis per LDS stage (2 k-blocks)
@@ -633,7 +635,7 @@ k_gemm(const float *__restrict__ Bm /*[N][K][Dp]*/, const float *__restrict__ xi
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int f = tid + 256 * s;
-            const f32x4 v = (MODE == MODE_STAGE0) ? (stB[s] - stO[s]) : (stB[s] * lscale);
+            const f32x4 v = (MODE == MODE_STAGE0) ? (stB[s] - stO[s]) : (MODE == MODE_XC ? stB[s] : stB[s] * lscale);
             ldsB[lds_unit(kGemmVec, f >> 3, (f & 7) >> 2, f & 3)] = v;
         }
         __syncthreads();
@@ -668,6 +670,11 @@ k_gemm(const float *__restrict__ Bm /*[N][K][Dp]*/, const float *__restrict__ xi
                 for (int v = 0; v < 4; ++v) s[v] = (Rv + q[v]) + 2.0f * acc[t][v];
                 *reinterpret_cast<f32x4 *>(o + 16 * t + 4 * g) = s;
             }
+        }
+    } else if (MODE == MODE_XC) {
+        if (b < B) {
+#pragma unroll
+            for (int t = 0; t < T; ++t) *reinterpret_cast<f32x4 *>(out + (b * N + n) * (long)K + 16 * t + 4 * g) = acc[t];
         }
     } else {
         float best = -INFINITY;
@@ -805,7 +812,7 @@ k_gemm8s(const float *__restrict__ Bm, const float *__restrict__ xin, const uint
             if (f < A_UNITS) sa[lds_unit1(K, f >> 2, f & 3)] = stA[s];
         }
         if (has_b) {
-            const f32x4 v = IS0 ? (stB - stO) : (stB * lscale);
+            const f32x4 v = IS0 ? (stB - stO) : (MODE == MODE_XC ? stB : stB * lscale);
             sb[lds_unit1(VEC, tid >> 2, tid & 3)] = v;
         }
     };
@@ -908,6 +915,12 @@ k_gemm8s(const float *__restrict__ Bm, const float *__restrict__ xin, const uint
                 for (int v = 0; v < 4; ++v) sv[v] = (Rv + q[v]) + 2.0f * acc[t][v];
                 *reinterpret_cast<f32x4 *>(o + k0) = sv;
             }
+        }
+    } else if (MODE == MODE_XC) {
+        if (b < B) {
+#pragma unroll
+            for (int t = 0; t < TW; ++t)
+                *reinterpret_cast<f32x4 *>(out + (b * N + n) * (long)K + 16 * (eh * TW + t) + 4 * g) = acc[t];
         }
     } else {
         float best = -INFINITY;

@@ -1,0 +1,417 @@
+// mcq_tf_kernels.h -- gfx950 kernels of the TABLE FORM of the refinement pass (2 <= N <= 16 codebooks).
+//
+// Every inner product of _refine_indexes (/root/reference/quantization/quantization.py:403-416, :533-535) is linear
+// in codebook rows, so it is READ from two tables instead of being recomputed per vector and pass:
+//   G[r][c]  = dot16(C[r], C[c])   Gram matrix of the N*K scaled centers, part of the prepared state
+//   XC[b][r] = dot16(C[r], x[b])   one GEMM per encode call (k_gemm8s<MODE_XC>)
+// Numeric contract: oracle/mcq_oracle.c, "TABLE FORM" (single IEEE fp32 adds / subs in the order written there).
+//   stage 0   X = (sum over m != n ascending of G[(m, idx_m)][(n, k)]) - XC[b][(n, k)];  S = (R + Q) + 2 X
+//   leaf      D[n][m][i][j] = ((G[s_n,i][s_m,j] - G[s_n,i][o_m]) - G[o_n][s_m,j]) + G[o_n][o_m]
+//   group     T_l[X][Y][i][j] = ((T_h[X0][Y0][i0][j0] + T_h[X0][Y1][i0][j1]) + T_h[X1][Y0][i1][j0]) + T_h[X1][Y1][i1][j1]
+//   combine   S' = ((S_X[i] + S_Y[j]) - E) + 2 T_l[X][Y][i][j]        (siblings X = 2g, Y = 2g + 1)
+// Lists: level v holds, per group of 2^v codebooks, kc[v] = K_cutoff(K, 2^v) candidates; level 0 as codebook
+// entries `ent`, level v >= 1 as the pair of positions in the two halves' lists `pos`.  The result is read off
+// the position tree (tf_emit).  What moves per vector and pass is a few thousand 4-byte table reads served by
+// the XCD's L2 (workgroup id mod #groups picks the group / table, so an XCD only touches its own blocks of G)
+// instead of 768 KB of gathered codebook rows: no MFMA, no operand staging.
+#pragma once
+#include "mcq_kernels.h"
+
+namespace mcq {
+
+constexpr int kTfLevels = 4;   // lists of candidates over 1, 2, 4, 8 codebooks (N <= 16)
+
+struct TfLists {
+    uint8_t *ent;               // [B][N][kc[0]]            level-0 lists: codebook entries
+    uint8_t *pos[kTfLevels];    // [B][N >> v][kc[v]][2]    level v >= 1: positions in the halves' lists
+    float *S[kTfLevels];        // [B][N >> v][kc[v]]       scores
+    int kc[kTfLevels];
+};
+
+__device__ __forceinline__ float shfl_f(float v, int src) {
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(src << 2, __float_as_int(v)));
+}
+
+// ------------------------------------------------------------------ stage 0
+// One wave per (vector, codebook n): the K scores of :418 from N - 1 row segments of G, the vector's XC segment and
+// Q, then the first sort-and-truncate (:470-503).  Workgroup id mod N = n: an XCD's L2 holds G[:, segment n] only.
+template <int K, int N>
+__global__ void __launch_bounds__(256)
+k_tf_stage0(const float *__restrict__ G, const float *__restrict__ XC, const uint8_t *__restrict__ idx,
+            const float *__restrict__ R, const float *__restrict__ Q, long B, int keep,
+            uint8_t *__restrict__ ent_out, float *__restrict__ S_out, const int *__restrict__ nact,
+            const int *__restrict__ map) {
+    constexpr int VPL = (K >= 64) ? K / 64 : 1;
+    constexpr int NK = N * K;
+    __shared__ u64 sel[4][kSelectLdsU64];
+    if (nact) B = *nact;
+    const int n = blockIdx.x & (N - 1);
+    const long b = (long)(blockIdx.x / N) * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int lane = lane_id();
+    const bool act = VPL * lane < K;
+    const int k0 = act ? VPL * lane : 0;
+    const uint8_t *id = idx + b * N;
+    float gv[N - 1][VPL];
+#pragma unroll
+    for (int j = 0; j < N - 1; ++j) {
+        const int m = j < n ? j : j + 1;                    // m ascending over the codebooks other than n
+        const float *p = G + ((size_t)(m * K + id[m]) * NK + n * K + k0);
+        if constexpr (VPL == 4) {
+            const f32x4 t4 = *reinterpret_cast<const f32x4 *>(p);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) gv[j][i] = t4[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) gv[j][i] = p[i];
+        }
+    }
+    const float *xc = XC + ((size_t)(map ? (long)map[b] : b) * NK + n * K + k0);
+    const float *q = Q + n * K + k0;
+    const float Rv = R[b * N + n];
+    float sv[VPL];
+    int sp[VPL];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        float t = gv[0][i];
+#pragma unroll
+        for (int j = 1; j < N - 1; ++j) t = t + gv[j][i];
+        const float X = t - xc[i];
+        sv[i] = act ? (Rv + q[i]) + 2.0f * X : INFINITY;
+        sp[i] = act ? k0 + i : kBigPos;
+    }
+    float ov;
+    int op;
+    wave_select_fast<VPL>(sv, sp, keep, K, sel[threadIdx.x >> 6], ov, op);
+    if (lane < keep) {
+        ent_out[(b * N + n) * keep + lane] = (uint8_t)op;
+        S_out[(b * N + n) * keep + lane] = ov;
+    }
+}
+
+// ---------------------------------------------------------------- leaf table
+// D[n][m] (codebooks n < m) over the two level-0 lists of KC entries: lane holds positions p = VPL*lane + v
+// (row i = p / KC, column j = p % KC).  KC*KC core reads plus one read per lane for the 2*KC + 1 border values
+// G[s_n,i][o_m] (lanes 0..KC-1), G[o_n][s_m,j] (KC..2KC-1), G[o_n][o_m] (lane 2KC), handed round by ds_bpermute.
+template <int KC, int NKc = 0>
+__device__ __forceinline__ void tf_leaf(const float *__restrict__ G, int NK, int K, int n, int m,
+                                        const uint8_t *__restrict__ en, const uint8_t *__restrict__ em, int old_n,
+                                        int old_m, float (&d)[KC * KC / 64]) {
+    constexpr int VPL = KC * KC / 64;
+    const int lane = lane_id();
+    const int i = (VPL * lane) / KC, j0 = (VPL * lane) % KC;
+    const uint32_t rown = (uint32_t)(n * K), colm = (uint32_t)(m * K);
+    const uint32_t si = rown + en[i];
+    float g[VPL];
+    if constexpr (VPL == 4) {
+        const uint32_t w4 = *reinterpret_cast<const uint32_t *>(em + j0);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) g[v] = G[si * (uint32_t)NK + colm + ((w4 >> (8 * v)) & 0xffu)];
+    } else {
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) g[v] = G[si * (uint32_t)NK + colm + em[j0 + v]];
+    }
+    const int bl = lane < 2 * KC ? lane : 2 * KC;
+    const uint32_t br = bl < KC ? rown + en[bl < KC ? bl : 0] : rown + (uint32_t)old_n;
+    const uint32_t bc = (bl >= KC && bl < 2 * KC) ? colm + em[(bl >= KC && bl < 2 * KC) ? bl - KC : 0] : colm + (uint32_t)old_m;
+    const float bv = G[br * (uint32_t)NK + bc];
+    const float u = shfl_f(bv, i), w = shfl_f(bv, 2 * KC);
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+        const float vj = shfl_f(bv, KC + j0 + v);
+        d[v] = ((g[v] - u) - vj) + w;
+    }
+}
+
+// The winner's leaves, codebook by codebook (:468-469): lane n walks down the position tree.
+// `win` = position a*kc + b of the winner among the pairs of the two top-level lists.
+__device__ __forceinline__ void tf_emit(const TfLists &L, long b, int N, int nlev, int win, uint8_t *__restrict__ idx_out) {
+    const int n = lane_id();
+    if (n >= N) return;
+    int v = nlev - 1;
+    int g = n >> v;
+    int p = (g & 1) ? win % L.kc[v] : win / L.kc[v];
+    while (v > 0) {
+        const int child = (n >> (v - 1)) & 1;
+        p = L.pos[v][((b * (N >> v) + g) * L.kc[v] + p) * 2 + child];
+        --v;
+        g = n >> v;
+    }
+    idx_out[b * N + n] = L.ent[(b * N + n) * L.kc[0] + p];
+}
+
+// select `keep` of the wave's scores and write the next level's list (or, for the last combine, the result)
+template <int VPL>
+__device__ __forceinline__ void tf_finish(const float (&sv)[VPL], const int (&sp)[VPL], int keep, int KCin, u64 *scratch,
+                                          const TfLists &L, int vout /* level of the list written */, long b, int N,
+                                          int gout, uint8_t *__restrict__ idx_final) {
+    float ov;
+    int op;
+    wave_select_fast<VPL>(sv, sp, keep, KCin * KCin, scratch, ov, op);
+    if (idx_final != nullptr) {     // one group left, keep == 1: lane 0 holds the winner
+        const int win = __builtin_amdgcn_readfirstlane(op);
+        tf_emit(L, b, N, vout, win, idx_final);
+        return;
+    }
+    if (lane_id() < keep) {
+        const long o = (b * (N >> vout) + gout) * keep + lane_id();
+        L.pos[vout][2 * o] = (uint8_t)(op / KCin);
+        L.pos[vout][2 * o + 1] = (uint8_t)(op % KCin);
+        L.S[vout][o] = ov;
+    }
+}
+
+// ------------------------------------------------------- combine of level 0
+// Siblings n = 2g, m = 2g + 1 (single codebooks): scores straight from the leaf table.  One wave per (b, g).
+template <int KC>
+__global__ void __launch_bounds__(64)
+k_tf_pair0(const float *__restrict__ G, const uint8_t *__restrict__ idx, const float *__restrict__ E, TfLists L, long B,
+           int N, int K, int keep, uint8_t *__restrict__ idx_final, const int *__restrict__ nact) {
+    constexpr int VPL = KC * KC / 64;
+    __shared__ u64 scratch[kSelectLdsU64];
+    if (nact) B = *nact;
+    const int Gout = N >> 1;
+    const int g = (int)(blockIdx.x & (unsigned)(Gout - 1));
+    const long b = (long)(blockIdx.x >> __builtin_ctz((unsigned)Gout));
+    if (b >= B) return;
+    const int lane = lane_id();
+    const int n = 2 * g, m = n + 1;
+    const uint8_t *en = L.ent + (b * N + n) * KC, *em = L.ent + (b * N + m) * KC;
+    const int i = (VPL * lane) / KC, j0 = (VPL * lane) % KC;
+    const float Eb = E[b];
+    const float se = L.S[0][(b * N + n) * KC + i];
+    float so[VPL];
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) so[v] = L.S[0][(b * N + m) * KC + j0 + v];
+    float d[VPL];
+    tf_leaf<KC>(G, N * K, K, n, m, en, em, idx[b * N + n], idx[b * N + m], d);
+    float sv[VPL];
+    int sp[VPL];
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+        sv[v] = ((se + so[v]) - Eb) + 2.0f * d[v];
+        sp[v] = VPL * lane + v;
+    }
+    tf_finish<VPL>(sv, sp, keep, KC, scratch, L, 1, b, N, g, idx_final);
+}
+
+// ------------------------------------------------------------ level-1 tables
+// T_1[X][Y] of two groups of two codebooks (X < Y) over their lists of KC candidates: the four leaf tables of
+// (2X | 2X+1) x (2Y | 2Y+1) go to LDS, every entry is then four LDS reads.  Lane holds positions p = VPL*lane + v.
+template <int KCH, int KC>
+__device__ __forceinline__ void tf_table1(const float *__restrict__ G, const uint8_t *__restrict__ idx, const TfLists &L,
+                                          long b, int N, int K, int X, int Y, float *leaf /* LDS [4][KCH*KCH] */,
+                                          float (&t)[KC * KC / 64]) {
+    constexpr int VPLH = KCH * KCH / 64, VPL = KC * KC / 64, MH = KCH * KCH;
+    const int lane = lane_id();
+    const uint8_t *id = idx + b * N;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int n = 2 * X + a, m = 2 * Y + c;
+            float d[VPLH];
+            tf_leaf<KCH>(G, N * K, K, n, m, L.ent + (b * N + n) * KCH, L.ent + (b * N + m) * KCH, id[n], id[m], d);
+            float *dst = leaf + (a * 2 + c) * MH + VPLH * lane;
+            if constexpr (VPLH == 4) {
+                *reinterpret_cast<f32x4 *>(dst) = (f32x4){d[0], d[1], d[2], d[3]};
+            } else {
+#pragma unroll
+                for (int v = 0; v < VPLH; ++v) dst[v] = d[v];
+            }
+        }
+    wave_lds_fence();
+    const int G1 = N >> 1;
+    const uint8_t *px = L.pos[1] + ((b * G1 + X) * KC) * 2, *py = L.pos[1] + ((b * G1 + Y) * KC) * 2;
+    const int i = (VPL * lane) / KC, j0 = (VPL * lane) % KC;
+    const int i0 = px[2 * i], i1 = px[2 * i + 1];
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+        const int jj0 = py[2 * (j0 + v)], jj1 = py[2 * (j0 + v) + 1];
+        t[v] = ((leaf[i0 * KCH + jj0] + leaf[MH + i0 * KCH + jj1]) + leaf[2 * MH + i1 * KCH + jj0]) +
+               leaf[3 * MH + i1 * KCH + jj1];
+    }
+}
+
+// combine of level 1: siblings X = 2g, Y = 2g + 1 (pairs of codebooks).  One wave per (b, g).
+template <int KCH, int KC>
+__global__ void __launch_bounds__(64)
+k_tf_pair1(const float *__restrict__ G, const uint8_t *__restrict__ idx, const float *__restrict__ E, TfLists L, long B,
+           int N, int K, int keep, uint8_t *__restrict__ idx_final, const int *__restrict__ nact) {
+    constexpr int VPL = KC * KC / 64;
+    __shared__ u64 scratch[kSelectLdsU64];
+    __shared__ __attribute__((aligned(16))) float leaf[4 * KCH * KCH];
+    if (nact) B = *nact;
+    const int Gout = N >> 2;
+    const int g = (int)(blockIdx.x & (unsigned)(Gout - 1));
+    const long b = (long)(blockIdx.x >> __builtin_ctz((unsigned)Gout));
+    if (b >= B) return;
+    const int lane = lane_id();
+    const int X = 2 * g, Y = X + 1, G1 = N >> 1;
+    const int i = (VPL * lane) / KC, j0 = (VPL * lane) % KC;
+    const float Eb = E[b];
+    const float se = L.S[1][(b * G1 + X) * KC + i];
+    float so[VPL];
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) so[v] = L.S[1][(b * G1 + Y) * KC + j0 + v];
+    float t[VPL];
+    tf_table1<KCH, KC>(G, idx, L, b, N, K, X, Y, leaf, t);
+    float sv[VPL];
+    int sp[VPL];
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+        sv[v] = ((se + so[v]) - Eb) + 2.0f * t[v];
+        sp[v] = VPL * lane + v;
+    }
+    tf_finish<VPL>(sv, sp, keep, KC, scratch, L, 2, b, N, g, idx_final);
+}
+
+// T_1 of COUSIN pairs (needed by the combines of levels 2 and 3) -> tabs[b][t][KC*KC].  One wave per (b, t);
+// workgroup id mod ntab = t, so an XCD reads the leaf blocks of its own tables only.
+//   quads == 0: the cousins under the level-2 siblings P = 2h, Q = 2h + 1:  t = 4h + 2a + c -> X = 4h + a, Y = 4h + 2 + c
+//   quads == 1: (N = 16, level-3 siblings) all X in 0..3 against Y in 4..7:  t = 4X + (Y - 4)
+template <int KCH, int KC>
+__global__ void __launch_bounds__(64)
+k_tf_table1(const float *__restrict__ G, const uint8_t *__restrict__ idx, TfLists L, long B, int N, int K, int ntab,
+            int quads, float *__restrict__ tabs, const int *__restrict__ nact) {
+    constexpr int VPL = KC * KC / 64;
+    __shared__ __attribute__((aligned(16))) float leaf[4 * KCH * KCH];
+    if (nact) B = *nact;
+    const int t = (int)(blockIdx.x & (unsigned)(ntab - 1));
+    const long b = (long)(blockIdx.x >> __builtin_ctz((unsigned)ntab));
+    if (b >= B) return;
+    const int lane = lane_id();
+    int X, Y;
+    if (quads) { X = t >> 2; Y = 4 + (t & 3); }
+    else { X = 4 * (t >> 2) + ((t >> 1) & 1); Y = 4 * (t >> 2) + 2 + (t & 1); }
+    float tv[VPL];
+    tf_table1<KCH, KC>(G, idx, L, b, N, K, X, Y, leaf, tv);
+    float *dst = tabs + ((size_t)(b * ntab + t) * (KC * KC) + VPL * lane);
+    if constexpr (VPL == 4) {
+        *reinterpret_cast<f32x4 *>(dst) = (f32x4){tv[0], tv[1], tv[2], tv[3]};
+    } else {
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) dst[v] = tv[v];
+    }
+}
+
+// copy `count` tables of M floats each from global memory to LDS (wave-cooperative)
+template <int M>
+__device__ __forceinline__ void tf_load_tables(const float *__restrict__ src, float *dst, int count) {
+    const int lane = lane_id();
+    if constexpr (M % 256 == 0) {
+        for (int u = lane; u < count * (M / 4); u += 64)
+            reinterpret_cast<f32x4 *>(dst)[u] = reinterpret_cast<const f32x4 *>(src)[u];
+    } else {
+        for (int u = lane; u < count * M; u += 64) dst[u] = src[u];
+    }
+}
+
+// T of a pair of groups over lists of KC candidates from the four tables of their halves (KH x KH each, in LDS):
+// lane holds positions p = VPL*lane + v.  px / py: the groups' position lists.
+template <int KH, int KC>
+__device__ __forceinline__ void tf_up(const float *t00, const float *t01, const float *t10, const float *t11,
+                                      const uint8_t *__restrict__ px, const uint8_t *__restrict__ py,
+                                      float (&t)[KC * KC / 64]) {
+    constexpr int VPL = KC * KC / 64;
+    const int lane = lane_id();
+    const int i = (VPL * lane) / KC, j0 = (VPL * lane) % KC;
+    const int i0 = px[2 * i], i1 = px[2 * i + 1];
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+        const int jj0 = py[2 * (j0 + v)], jj1 = py[2 * (j0 + v) + 1];
+        t[v] = ((t00[i0 * KH + jj0] + t01[i0 * KH + jj1]) + t10[i1 * KH + jj0]) + t11[i1 * KH + jj1];
+    }
+}
+
+// ------------------------------------------------------- combine of level 2
+// Siblings P = 2h, Q = 2h + 1 (groups of four codebooks, lists of KC2): the four level-1 tables of their halves
+// come from tabs.  One wave per (b, h).
+template <int KC1, int KC2>
+__global__ void __launch_bounds__(64)
+k_tf_comb2(const uint8_t *__restrict__ idx, const float *__restrict__ E, TfLists L, long B, int N, int keep, int ntab,
+           const float *__restrict__ tabs, uint8_t *__restrict__ idx_final, const int *__restrict__ nact) {
+    constexpr int VPL = KC2 * KC2 / 64, M1 = KC1 * KC1;
+    __shared__ u64 scratch[kSelectLdsU64];
+    __shared__ __attribute__((aligned(16))) float t1[4 * M1];
+    if (nact) B = *nact;
+    const int Gout = N >> 3;
+    const int h = (int)(blockIdx.x & (unsigned)(Gout - 1));
+    const long b = (long)(blockIdx.x >> __builtin_ctz((unsigned)Gout));
+    if (b >= B) return;
+    const int lane = lane_id();
+    const int P = 2 * h, Q = P + 1, G2 = N >> 2;
+    tf_load_tables<M1>(tabs + (size_t)(b * ntab + 4 * h) * M1, t1, 4);
+    const int i = (VPL * lane) / KC2, j0 = (VPL * lane) % KC2;
+    const float Eb = E[b];
+    const float se = L.S[2][(b * G2 + P) * KC2 + i];
+    float so[VPL];
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) so[v] = L.S[2][(b * G2 + Q) * KC2 + j0 + v];
+    wave_lds_fence();
+    float t[VPL];
+    tf_up<KC1, KC2>(t1, t1 + M1, t1 + 2 * M1, t1 + 3 * M1, L.pos[2] + ((b * G2 + P) * KC2) * 2,
+                    L.pos[2] + ((b * G2 + Q) * KC2) * 2, t);
+    float sv[VPL];
+    int sp[VPL];
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+        sv[v] = ((se + so[v]) - Eb) + 2.0f * t[v];
+        sp[v] = VPL * lane + v;
+    }
+    tf_finish<VPL>(sv, sp, keep, KC2, scratch, L, 3, b, N, h, idx_final);
+}
+
+// ------------------------------------------------------- combine of level 3
+// N = 16: the two groups of eight codebooks.  16 level-1 tables (tabs, quads layout) -> the four level-2 tables of
+// (groups 0 | 1) x (2 | 3) in LDS -> the KC3 x KC3 scores.  One wave per vector; always the last combine.
+template <int KC1, int KC2, int KC3>
+__global__ void __launch_bounds__(64)
+k_tf_comb3(const uint8_t *__restrict__ idx, const float *__restrict__ E, TfLists L, long B, int N,
+           const float *__restrict__ tabs, uint8_t *__restrict__ idx_final, const int *__restrict__ nact) {
+    constexpr int VPL2 = KC2 * KC2 / 64, VPL = KC3 * KC3 / 64, M1 = KC1 * KC1, M2 = KC2 * KC2;
+    __shared__ u64 scratch[kSelectLdsU64];
+    __shared__ __attribute__((aligned(16))) float t1[16 * M1];
+    __shared__ __attribute__((aligned(16))) float t2[4 * M2];
+    if (nact) B = *nact;
+    const long b = blockIdx.x;
+    if (b >= B) return;
+    const int lane = lane_id();
+    tf_load_tables<M1>(tabs + (size_t)b * 16 * M1, t1, 16);
+    const int i = (VPL * lane) / KC3, j0 = (VPL * lane) % KC3;
+    const float Eb = E[b];
+    const float se = L.S[3][(b * 2 + 0) * KC3 + i];
+    float so[VPL];
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) so[v] = L.S[3][(b * 2 + 1) * KC3 + j0 + v];
+    wave_lds_fence();
+    const int G2 = N >> 2;   // 4 level-2 groups
+#pragma unroll
+    for (int xc = 0; xc < 2; ++xc)
+#pragma unroll
+        for (int yc = 0; yc < 2; ++yc) {
+            // level-2 groups xc and 2 + yc; their halves are the level-1 groups 2xc, 2xc+1 and 4+2yc, 4+2yc+1
+            const int X0 = 2 * xc, Y0 = 2 * yc;      // Y0 relative to 4
+            float tv[VPL2];
+            tf_up<KC1, KC2>(t1 + (4 * X0 + Y0) * M1, t1 + (4 * X0 + Y0 + 1) * M1, t1 + (4 * (X0 + 1) + Y0) * M1,
+                            t1 + (4 * (X0 + 1) + Y0 + 1) * M1, L.pos[2] + ((b * G2 + xc) * KC2) * 2,
+                            L.pos[2] + ((b * G2 + 2 + yc) * KC2) * 2, tv);
+            float *dst = t2 + (xc * 2 + yc) * M2 + VPL2 * lane;
+#pragma unroll
+            for (int v = 0; v < VPL2; ++v) dst[v] = tv[v];
+        }
+    wave_lds_fence();
+    float t[VPL];
+    tf_up<KC2, KC3>(t2, t2 + M2, t2 + 2 * M2, t2 + 3 * M2, L.pos[3] + ((b * 2 + 0) * KC3) * 2,
+                    L.pos[3] + ((b * 2 + 1) * KC3) * 2, t);
+    float sv[VPL];
+    int sp[VPL];
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+        sv[v] = ((se + so[v]) - Eb) + 2.0f * t[v];
+        sp[v] = VPL * lane + v;
+    }
+    tf_finish<VPL>(sv, sp, 1, KC3, scratch, L, 4, b, N, 0, idx_final);
+}
+
+}  // namespace mcq
