@@ -11,22 +11,27 @@ encodes its own shard -- no collective on the data path (weak scaling).  Rank 0 
 ONE JSON line.  `roofline` is for the dominant kernel, from per-launch HIP events on the
 launch stream (mcq_profile_encode); `cpu_baseline` times the torch-CPU restatement of the
 reference's op sequence (oracle/torch_port.py) on this host's cores on a bounded sample.
+Secondary objects: `parity` (sampled rows vs the oracle, the 4,096 reference-fixture rows),
+`configs` (BASELINE configs A, D and config C's per-GPU shard), `decode`, `trainer_step`,
+and -- under WORLD_SIZE > 1 -- `dp_trainer` (QuantizerTrainer.step with the RCCL all-reduce).
 """
 import argparse
 import ctypes
 import json
 import os
+import random
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+PEAK_HBM_GBPS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec
+NEAR_TIE = 2e-6                # tests/golden/fixtures.py
 
 
 def k_cutoff(K, L):
@@ -37,22 +42,70 @@ def k_cutoff(K, L):
     return min(kc, 128)
 
 
-def kernel_flops(B, D, N, K):
-    """matmul FLOPs (2*m*n*k) of ONE launch of each kernel category, SURVEY.md 8(d)."""
-    cats = [("logits_argmax", 2.0 * D * N * K * B), ("residual", 0.0), ("stage0_gemm", 2.0 * D * N * K * B),
-            ("prune0", 0.0)]
+def reference_flops_per_vector(D, N, K, iters):
+    """matmul FLOPs (2*m*n*k) of the REFERENCE algorithm per vector, SURVEY.md 8(d): logits, and per pass the
+    stage-0 GEMM plus every pair stage."""
+    per_pass = 2.0 * D * N * K
     G, L, KI = N, 1, (1 if N == 1 else k_cutoff(K, 1))
     while G > 1:
         Gout = G // 2
-        cats.append((f"pair_L{L}_K{KI}", Gout * KI * KI * 2.0 * D * B))
+        per_pass += Gout * KI * KI * 2.0 * D
+        KI = 1 if Gout == 1 else k_cutoff(K, 2 * L)
+        G, L = Gout, 2 * L
+    return 2.0 * D * N * K + iters * per_pass
+
+
+def kernel_work(B, D, N, K):
+    """Per launch of each kernel category of mcq_profile_encode (in its order): (name, launches per encode as
+    'once' | 'pass', algorithmic FLOPs, algorithmic bytes).  Table form (2 <= N <= 16): the two GEMMs are the only
+    MFMA work; the table kernels read 4-byte Gram entries (bytes = entries read x 4 + lists and tables written)."""
+    gemm = 2.0 * D * N * K * B
+    kc = [k_cutoff(K, 1 << v) for v in range(4)]
+    if 2 <= N <= 16:
+        leaf = (kc[0] * kc[0] + 2 * kc[0] + 1) * 4.0           # one leaf table's Gram reads
+        cats = [("logits_gemm_argmax", "once", gemm, 0.0),
+                ("residual", "pass", 0.0, B * ((N + 1) * D * 4.0 + D * 4.0)),
+                ("stage0_tables", "pass", 0.0, B * N * ((N + 1) * K * 4.0 + kc[0] * 5.0)),
+                ("xc_gemm", "once", gemm, 0.0),
+                ("combine_level0", "pass", 0.0, B * (N / 2) * (leaf + kc[1] * 6.0))]
+        if N >= 4:
+            cats.append(("combine_level1", "pass", 0.0, B * (N / 4) * (4 * leaf + kc[2] * 6.0)))
+        if N >= 8:
+            cats.append(("tables_level1", "pass", 0.0, B * 4 * (N / 8) * (4 * leaf + kc[1] * kc[1] * 4.0)))
+            cats.append(("combine_level2", "pass", 0.0, B * (N / 8) * (4 * kc[1] * kc[1] * 4.0 + kc[3] * 6.0)))
+        if N >= 16:
+            cats.append(("tables_level1_quads", "pass", 0.0, B * 16 * (4 * leaf + kc[1] * kc[1] * 4.0)))
+            cats.append(("combine_level3", "pass", 0.0, B * 16 * kc[1] * kc[1] * 4.0))
+        return cats
+    cats = [("logits_gemm_argmax", "once", gemm, 0.0), ("residual", "pass", 0.0, B * (N + 2) * D * 4.0),
+            ("stage0_gemm", "pass", gemm, 0.0), ("prune0", "pass", 0.0, 0.0)]
+    G, L, KI = N, 1, (1 if N == 1 else k_cutoff(K, 1))
+    while G > 1:
+        Gout = G // 2
+        cats.append((f"pair_L{L}_K{KI}", "pass", Gout * KI * KI * 2.0 * D * B, 0.0))
         KI = 1 if Gout == 1 else k_cutoff(K, 2 * L)
         G, L = Gout, 2 * L
     return cats
 
 
-def total_flops_per_vector(D, N, K, iters):
-    cats = kernel_flops(1, D, N, K)
-    return cats[0][1] + iters * sum(f for _, f in cats[1:])
+def load_quantizer(state, D, K, N, dev):
+    from quantization_amd import Quantizer
+    q = Quantizer(D, K, N)
+    sd = q.state_dict()
+    for k, v in state.items():
+        sd[k] = torch.from_numpy(np.asarray(v))
+    q.load_state_dict(sd)
+    return q.to(dev)
+
+
+def timed(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t) / reps
 
 
 def cpu_baseline(state, D, budget_s=12.0):
@@ -91,6 +144,50 @@ def cpu_baseline(state, D, budget_s=12.0):
                       f"(best of a short sweep), {dt:.1f} s"}
 
 
+def fixture_parity(q, dev, iters):
+    """HIP codes against the 4,096 rows the REFERENCE itself encoded (tests/golden/config_b_d512_n8.npz: data only)."""
+    from quantization_amd import synthetic as gen
+    path = os.path.join(ROOT, "tests", "golden", "config_b_d512_n8.npz")
+    if not os.path.exists(path) or iters != 5:
+        return None
+    z = np.load(path)
+    x = gen.make_gaussian(int(z["x_seed"]), int(z["B"]), int(z["D"]))
+    assert gen.checksum(x) == float(z["x_checksum"])
+    with torch.no_grad():
+        got = q.encode(torch.from_numpy(x).to(dev), 5).cpu().numpy()
+    bad = (got != z["codes_it5"]).any(axis=1)
+    margin = z["margin_it5"]
+    return {"rows": int(len(bad)), "mismatches": int(bad.sum()),
+            "near_tie_mismatches": int((bad & (margin < NEAR_TIE)).sum()),
+            "clear_margin_mismatches": int((bad & (margin >= NEAR_TIE)).sum()),
+            "note": "codes the reference's Quantizer.encode returned for the same seeded state and inputs; a near tie "
+                    "has an fp64 decision margin < 2e-6 (the reference's own code flips under a re-ordered fp32 sum)"}
+
+
+def trainer_leg(dev, D, N, batch, p_iters, process_group=None, data_parallel=False):
+    """ms per QuantizerTrainer.step in both phases (free-running, no host sync per step)."""
+    from quantization_amd import QuantizerTrainer
+    random.seed(0)
+    torch.manual_seed(0)
+    tr = QuantizerTrainer(dim=D, bytes_per_frame=N, device=dev, phase_one_iters=p_iters, phase_two_iters=p_iters,
+                          process_group=process_group, data_parallel=data_parallel)
+    xt = torch.randn(batch, D, device=dev)
+    ms = {}
+    for phase, until in (("phase1_ms_per_step", p_iters), ("phase2_ms_per_step", 2 * p_iters + 1)):
+        for _ in range(10):
+            tr.step(xt)
+        torch.cuda.synchronize()
+        t4, n0 = time.perf_counter(), tr.cur_iter
+        while tr.cur_iter < until - 5:
+            tr.step(xt)
+        torch.cuda.synchronize()
+        ms[phase] = round((time.perf_counter() - t4) / (tr.cur_iter - n0) * 1e3, 3)
+        while tr.cur_iter < until + (1 if until == p_iters else 0):
+            tr.step(xt)
+    nparam = sum(p.numel() for p in tr.quantizer.parameters())
+    return ms, nparam
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -102,34 +199,37 @@ def main():
     ap.add_argument("--refine-iters", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event pass (for PMC runs)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for a dry run)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="dry run of the N > 1 path on a 1-GPU box: every rank uses cuda:0")
     ap.add_argument("--no-secondary", action="store_true",
-                    help="skip the secondary figures (skipping mode, host-resident / fp16 input, decode): every kernel "
-                         "launch of the run then has the headline shape (for rocprofv3 averages)")
+                    help="skip the secondary figures (other configs, skipping mode, host-resident / fp16 input, decode, "
+                         "trainer): every kernel launch of the run then has the headline shape (for rocprofv3 averages)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py measures the HIP path: it needs an MI355X"
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-    from golden import gen
-    from quantization_amd import Quantizer, _lib
+    from quantization_amd import synthetic as gen
+    from quantization_amd import _lib
 
     D, N, K, B, iters = args.dim, args.num_codebooks, 256, args.batch_per_gpu, args.refine_iters
     state = gen.synthetic_state(103, D, K, N)      # same seeded state as the config_b fixture
-    q = Quantizer(D, K, N)
-    sd = q.state_dict()
-    for k, v in state.items():
-        sd[k] = torch.from_numpy(np.asarray(v))
-    q.load_state_dict(sd)
-    q = q.to(dev)
+    q = load_quantizer(state, D, K, N, dev)
     g = torch.Generator(device=dev)
     g.manual_seed(rank)
     x = torch.randn(B, D, generator=g, device=dev, dtype=torch.float32)   # resident in HBM
@@ -156,19 +256,35 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # ---- data-parallel trainer (BASELINE config E): every rank takes part in the collectives
+    dp = None
+    if dist is not None and not args.no_secondary:
+        dp = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend()}
+        for tag, per_gpu in (("global_batch_4096", max(4096 // world, 64)), ("per_gpu_batch_4096", 4096)):
+            ms, nparam = trainer_leg(dev, D, N, per_gpu, 40, data_parallel=True)
+            tt = torch.tensor([ms["phase1_ms_per_step"], ms["phase2_ms_per_step"]], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dp[tag] = {"per_gpu_batch": per_gpu, "global_batch": per_gpu * world,
+                       "phase1_ms_per_step": round(float(tt[0]), 3), "phase2_ms_per_step": round(float(tt[1]), 3),
+                       "all_reduce_bytes_per_step_phase2": 4 * nparam + 4 * (N * K * 2 + 4)}
+        dp["note"] = ("QuantizerTrainer.step, data_parallel=True: one flat gradient all-reduce (RCCL) + one small "
+                      "forward all-reduce of the batch sums per step; max over ranks")
+
     if rank != 0:
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
         return
 
-    # ---- parity spot check (outside the timed region): sampled rows vs the CPU oracle
+    # ---- parity (outside the timed region): sampled rows vs the CPU oracle, fixture rows vs the reference
     from oracle.oracle import OracleQuantizer
     o = OracleQuantizer(state["centers"], float(state["centers_scale"]), state["to_logits.weight"],
                         state["to_logits.bias"], float(state["logits_scale"]))
-    rows = np.random.RandomState(1).choice(B, 256, replace=False)
+    rows = np.random.RandomState(1).choice(B, min(256, B), replace=False)
     want = o.encode(x[rows].cpu().numpy(), iters)
-    parity_ok = bool(np.array_equal(codes[rows].cpu().numpy(), want))
+    parity = {"sampled_rows_vs_oracle": int(len(rows)), "bit_exact": bool(np.array_equal(codes[rows].cpu().numpy(), want))}
+    if (D, N, K) == (512, 8, 256):
+        parity["vs_reference_fixture"] = fixture_parity(q, dev, iters)
 
     # ---- per-kernel HIP-event timing on the launch stream (same inputs, same process)
     L = _lib.lib()
@@ -186,31 +302,46 @@ def main():
         acc[:ncat] += np.array(ms[:ncat])
     acc /= reps
     acc = np.maximum(acc, 1e-9)
-    cats = kernel_flops(B, D, N, K)
+    cats = kernel_work(B, D, N, K)
     kernels = {}
-    for i, (name, fl) in enumerate(cats):
-        launches = 1 if i == 0 else iters
+    for i, (name, when, fl, by) in enumerate(cats):
+        launches = 1 if when == "once" else iters
         avg_ms = acc[i] / launches
         kernels[name] = {"launches_per_encode": launches, "avg_ms": round(float(avg_ms), 4),
-                         "gflop_per_launch": round(fl / 1e9, 2),
-                         "tflops": round(fl / (avg_ms * 1e-3) / 1e12, 2) if avg_ms > 0 and fl > 0 else 0.0,
                          "ms_per_encode": round(float(acc[i]), 3)}
+        if fl > 0:
+            kernels[name].update(gflop_per_launch=round(fl / 1e9, 2), tflops=round(fl / (avg_ms * 1e-3) / 1e12, 2))
+        if by > 0:
+            kernels[name].update(gbyte_per_launch=round(by / 1e9, 3), gbytes_per_s=round(by / (avg_ms * 1e-3) / 1e9, 1))
     dom = max(range(len(cats)), key=lambda i: acc[i])
-    dom_name, dom_fl = cats[dom]
-    dom_ms = acc[dom] / (1 if dom == 0 else iters)
-    achieved = dom_fl / (dom_ms * 1e-3) / 1e12 if dom_fl > 0 else 0.0
-
+    dom_name, dom_when, dom_fl, dom_by = cats[dom]
+    dom_ms = acc[dom] / (1 if dom_when == "once" else iters)
     # HBM-side traffic of the dominant kernel: from the committed rocprofv3 --pmc passes of this same
-    # workload (counters cannot be collected from inside the timed process); null for other shapes
+    # workload (counters cannot be collected from inside the timed process); null for other shapes / kernels
     traffic, traffic_note = None, None
-    pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    pmc_file = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
     if (D, N, K, B, iters) == (512, 8, 256, 65536, 5) and os.path.exists(pmc_file):
         pmc = json.load(open(pmc_file))
         if dom_name in pmc:
             traffic = pmc[dom_name]["traffic_bytes"]
-            traffic_note = "bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from profiles/r01_pmc_traffic.json"
+            traffic_note = "bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from profiles/r02_pmc_traffic.json"
+    if dom_fl > 0:
+        achieved = dom_fl / (dom_ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                    "traffic_note": traffic_note, "gflop_per_launch": round(dom_fl / 1e9, 2),
+                    "avg_launch_ms": round(float(dom_ms), 4)}
+    else:
+        achieved = dom_by / (dom_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": PEAK_HBM_GBPS,
+                    "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBPS, 4), "traffic": traffic,
+                    "traffic_note": traffic_note, "gbyte_per_launch": round(dom_by / 1e9, 3),
+                    "avg_launch_ms": round(float(dom_ms), 4),
+                    "note": "a table kernel: its algorithmic bytes are 4-byte Gram entries served by the XCD's L2, "
+                            "priced against the HBM peak as the contract asks"}
 
-    fpv = total_flops_per_vector(D, N, K, iters)
+    fpv = reference_flops_per_vector(D, N, K, iters)
+    exec_fpv = 2 * 2.0 * D * N * K if 2 <= N <= 16 else fpv     # table form: the logits and x.C GEMMs only
     value = world * B * args.steps / dt
     out = {
         "metric": "vectors encoded/sec at dim=512, 8 codebooks; uint8 codes bit-exact vs ref",
@@ -221,34 +352,70 @@ def main():
                                f"refine_indexes_iters={iters}, batch={B} fp32 Gaussian vectors per GPU "
                                f"(BASELINE.json configs[1]), seeded synthetic codebooks",
                    "global_batch": world * B, "parallelism": f"batch-sharded x{world}, no collective"},
-        "parity": {"sampled_rows_vs_oracle": 256, "bit_exact": parity_ok},
-        "whole_encode": {"flop_per_vector": fpv, "tflops": round(value / world * fpv / 1e12, 2),
-                         "frac_of_f32_mfma_peak": round(value / world * fpv / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
-        "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2),
-                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
-                     "measured_issue_ceiling": 152.5,   # TFLOP/s: 33 cycles per v_mfma_f32_16x16x4_f32 at 2.4 GHz (tools/micro/mfma_chain.hip)
-                     "gflop_per_launch": round(dom_fl / 1e9, 2),
-                     "avg_launch_ms": round(float(dom_ms), 4)},
+        "parity": parity,
+        "whole_encode": {"reference_flop_per_vector": fpv, "executed_mfma_flop_per_vector": exec_fpv,
+                         "reference_tflops": round(value / world * fpv / 1e12, 2),
+                         "frac_of_f32_mfma_peak": round(value / world * fpv / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                         "note": "reference_* prices the matmul FLOPs of the reference algorithm (SURVEY.md 8d: 6.12 M "
+                                 "vectors/s at the fp32-MFMA peak); the table form executes only the logits and x.C GEMMs "
+                                 "and reads the other inner products from the Gram matrix, so this fraction can exceed 1"},
+        "roofline": roofline,
         "kernels": kernels,
     }
+    if dp is not None:
+        out["dp_trainer"] = dp
     if args.no_secondary:
         print(json.dumps(out), flush=True)
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
         return
+
+    # ---- decode (gather-sum, HBM-write-bound by its algorithmic bytes N + 4*D per vector)
+    with torch.no_grad():
+        for _ in range(2):
+            y = q.decode(codes)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            y = q.decode(codes)
+        e1.record()
+        torch.cuda.synchronize()
+        dec_ms = e0.elapsed_time(e1) / 10
+    dec_gbps = B * (N + 4 * D) / (dec_ms * 1e-3) / 1e9
+    out["decode"] = {"vectors_per_s": round(B / (dec_ms * 1e-3), 1), "ms": round(dec_ms, 4),
+                     "hbm_gb_per_s": round(dec_gbps, 1), "peak_gb_per_s": PEAK_HBM_GBPS, "frac": round(dec_gbps / PEAK_HBM_GBPS, 4),
+                     "note": "torch current stream; algorithmic bytes = N + 4*D per vector"}
+
+    # ---- the other BASELINE shapes on one GPU (same code path; parity for them is in tests/ -m gpu)
+    if world == 1:
+        cfgs = {}
+        for name, d_, n_, b_, reps in (("A_dim256_bytes4", 256, 4, 65536, 3), ("D_dim1024_bytes16", 1024, 16, 65536, 2),
+                                        ("C_shard_dim512_bytes8_1M", 512, 8, 1 << 20, 1)):
+            qc = q if (d_, n_) == (D, N) else load_quantizer(gen.synthetic_state(103, d_, 256, n_), d_, 256, n_, dev)
+            xc_ = torch.randn(b_, d_, device=dev)
+            with torch.no_grad():
+                t_enc = timed(lambda: qc.encode(xc_, 5), reps)
+                cc = qc.encode(xc_, 5)
+                t_dec = timed(lambda: qc.decode(cc), 5)
+            f_ = reference_flops_per_vector(d_, n_, 256, 5)
+            cfgs[name] = {"batch": b_, "encode_vectors_per_s": round(b_ / t_enc, 1), "encode_ms": round(t_enc * 1e3, 2),
+                          "frac_of_f32_mfma_peak_reference_flops": round(b_ / t_enc * f_ / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                          "decode_gb_per_s": round(b_ * (n_ + 4 * d_) / t_dec / 1e9, 1),
+                          "decode_frac": round(b_ * (n_ + 4 * d_) / t_dec / 1e9 / PEAK_HBM_GBPS, 4)}
+            del xc_, cc
+            if qc is not q:
+                del qc
+            torch.cuda.empty_cache()
+        out["configs"] = cfgs
+
     # ---- secondary: the same encode with fixed-point skipping (identical codes, data-dependent cost;
     # never the headline value: BASELINE's metric is the reference's fixed 5-pass work)
     with torch.no_grad():
         q.skip_fixed_points = True
         c2 = q.encode(x, iters)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(3):
-            c2 = q.encode(x, iters)
-        torch.cuda.synchronize()
-        skip_dt = (time.perf_counter() - t1) / 3
+        skip_dt = timed(lambda: q.encode(x, iters), 3)
         q.skip_fixed_points = False
     out["fixed_point_skipping"] = {"vectors_per_s": round(B / skip_dt, 1), "ms_per_step": round(skip_dt * 1e3, 3),
                                    "codes_identical": bool(torch.equal(c2, codes)),
@@ -267,55 +434,20 @@ def main():
                                   "codes_identical": bool(torch.equal(ch[:B], codes.cpu())),
                                   "note": "PCIe-inclusive (pinned host batch of 2x65,536 vectors, double-buffered "
                                           "H2D on a copy stream); never the headline value"}
+    del xh
 
     # ---- secondary: fp16 frames resident in HBM, widened in the kernels' load path (same codes by construction)
     with torch.no_grad():
         x16 = x.to(torch.float16)
         c16 = q.encode(x16, iters)
-        torch.cuda.synchronize()
-        t3 = time.perf_counter()
-        for _ in range(3):
-            q.encode(x16, iters)
-        torch.cuda.synchronize()
-        out["fp16_input"] = {"vectors_per_s": round(3 * B / (time.perf_counter() - t3), 1),
+        t16 = timed(lambda: q.encode(x16, iters), 3)
+        out["fp16_input"] = {"vectors_per_s": round(B / t16, 1),
                              "codes_equal_widened_input": bool(torch.equal(c16, q.encode(x16.float(), iters)))}
 
-    # ---- decode (HBM-write-bound gather-sum), secondary figure
-    with torch.no_grad():
-        for _ in range(2):
-            y = q.decode(codes)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(10):
-            y = q.decode(codes)
-        e1.record()
-        torch.cuda.synchronize()
-        dec_ms = e0.elapsed_time(e1) / 10
-    out["decode"] = {"vectors_per_s": round(B / (dec_ms * 1e-3), 1), "ms": round(dec_ms, 4),
-                     "hbm_gb_per_s": round(B * (N + 4 * D) / (dec_ms * 1e-3) / 1e9, 1), "peak_gb_per_s": 8000.0,
-                     "note": "torch current stream; algorithmic bytes = N + 4*D per vector"}
     # ---- secondary: QuantizerTrainer.step (BASELINE config E shape on one GPU: dim 512, 8 bytes, batch 4096)
     if world == 1:
-        import random
-        from quantization_amd import QuantizerTrainer
-        random.seed(0)
-        torch.manual_seed(0)
-        tr = QuantizerTrainer(dim=D, bytes_per_frame=N, device=dev, phase_one_iters=60, phase_two_iters=60)
-        xt = torch.randn(4096, D, device=dev)
-        ms = {}
-        for phase, until in (("phase1_ms_per_step", 60), ("phase2_ms_per_step", 121)):
-            for _ in range(10):
-                tr.step(xt)
-            torch.cuda.synchronize()
-            t4, n0 = time.perf_counter(), tr.cur_iter
-            while tr.cur_iter < until - 5:
-                tr.step(xt)
-            torch.cuda.synchronize()
-            ms[phase] = round((time.perf_counter() - t4) / (tr.cur_iter - n0) * 1e3, 3)
-            while tr.cur_iter < until + (1 if until == 60 else 0):
-                tr.step(xt)
-        out["trainer_step"] = dict(ms, batch=4096, note="QuantizerTrainer.step, fused (autograd-free) path, free-running")
+        ms_t, _ = trainer_leg(dev, D, N, 4096, 60)
+        out["trainer_step"] = dict(ms_t, batch=4096, note="QuantizerTrainer.step, fused (autograd-free) path, free-running")
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(state, D)
     print(json.dumps(out), flush=True)

@@ -3,7 +3,7 @@ import sys, os, time, json, random
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
-from golden import gen
+from quantization_amd import synthetic as gen
 from quantization_amd import Quantizer, QuantizerTrainer
 
 def load(D, K, N, seed=103):

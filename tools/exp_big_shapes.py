@@ -2,7 +2,7 @@ import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
-from golden import gen
+from quantization_amd import synthetic as gen
 from quantization_amd import Quantizer
 from oracle.oracle import OracleQuantizer
 for (D, K, N, B, it) in [(1024, 16, 64, 48, 1), (768, 256, 32, 48, 1), (2048, 256, 8, 100, 2), (4096, 256, 4, 70, 2), (1000, 128, 16, 64, 2), (520, 64, 2, 200, 3)]:

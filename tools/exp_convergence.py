@@ -3,7 +3,8 @@ import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
-from golden import gen, fixtures
+from quantization_amd import synthetic as gen
+from golden import fixtures
 from quantization_amd import Quantizer
 
 def load(st, D, K, N):

@@ -3,7 +3,7 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np, torch
-from golden import gen
+from quantization_amd import synthetic as gen
 from quantization_amd import Quantizer
 for (D, K, N, B) in [(512, 256, 8, 65536), (512, 256, 8, 1048576), (256, 256, 4, 1048576), (1024, 256, 16, 262144), (512, 16, 16, 1048576), (40, 64, 8, 1048576)]:
     q = Quantizer(D, K, N)

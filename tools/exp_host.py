@@ -2,7 +2,7 @@
 import time, torch, sys
 import numpy as np
 sys.path.insert(0, ".")
-from tests.golden import gen
+from quantization_amd import synthetic as gen
 from quantization_amd import Quantizer
 D, N, K, B = 512, 8, 256, 131072
 q = Quantizer(D, K, N)

@@ -1,7 +1,7 @@
 import sys, os
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
 import numpy as np, torch
-from golden import gen
+from quantization_amd import synthetic as gen
 from quantization_amd import Quantizer
 for (D,K,N) in [(64,256,8),(64,16,16),(32,256,1)]:
     st = gen.synthetic_state(1, D, K, N)

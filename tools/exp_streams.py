@@ -4,7 +4,7 @@ import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
-from golden import gen
+from quantization_amd import synthetic as gen
 from quantization_amd import Quantizer, _lib
 
 D, N, K, B = 512, 8, 256, 65536
