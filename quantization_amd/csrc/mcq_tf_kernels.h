@@ -93,7 +93,7 @@ k_tf_stage0(const float *__restrict__ G, const float *__restrict__ XC, const uin
 // D[n][m] (codebooks n < m) over the two level-0 lists of KC entries: lane holds positions p = VPL*lane + v
 // (row i = p / KC, column j = p % KC).  KC*KC core reads plus one read per lane for the 2*KC + 1 border values
 // G[s_n,i][o_m] (lanes 0..KC-1), G[o_n][s_m,j] (KC..2KC-1), G[o_n][o_m] (lane 2KC), handed round by ds_bpermute.
-template <int KC, int NKc = 0>
+template <int KC>
 __device__ __forceinline__ void tf_leaf(const float *__restrict__ G, int NK, int K, int n, int m,
                                         const uint8_t *__restrict__ en, const uint8_t *__restrict__ em, int old_n,
                                         int old_m, float (&d)[KC * KC / 64]) {
@@ -196,42 +196,108 @@ k_tf_pair0(const float *__restrict__ G, const uint8_t *__restrict__ idx, const f
 }
 
 // ------------------------------------------------------------ level-1 tables
-// T_1[X][Y] of two groups of two codebooks (X < Y) over their lists of KC candidates: the four leaf tables of
-// (2X | 2X+1) x (2Y | 2Y+1) go to LDS, every entry is then four LDS reads.  Lane holds positions p = VPL*lane + v.
+// T_1[X][Y] of two groups of two codebooks (X < Y) over their lists of KC candidates, each entry the sum of four
+// leaf-table entries.  Lane holds positions p = VPL*lane + v.
+//
+// Lists of 16 (K >= 32): only the leaf entries the candidates USE are read.  A list's 16 candidates are pairs of
+// positions in the two halves' level-0 lists, and on average only 7.5 of the 16 positions of a half occur
+// (measured on the bench workload), so a leaf table is needed on a |A| x |B| sub-grid (56 entries instead of 256,
+// plus the border).  The sets come from a 16-lane OR-reduction of position bits, the compact rank of a position is
+// a popcount, and the four compact leaf tables live in LDS.  Every entry is computed by the same formula as in the
+// full table, so the results are identical.
 template <int KCH, int KC>
 __device__ __forceinline__ void tf_table1(const float *__restrict__ G, const uint8_t *__restrict__ idx, const TfLists &L,
-                                          long b, int N, int K, int X, int Y, float *leaf /* LDS [4][KCH*KCH] */,
+                                          long b, int N, int K, int X, int Y, float *leaf /* LDS [4][KCH*KCH + 64] */,
                                           float (&t)[KC * KC / 64]) {
     constexpr int VPLH = KCH * KCH / 64, VPL = KC * KC / 64, MH = KCH * KCH;
     const int lane = lane_id();
     const uint8_t *id = idx + b * N;
+    const int G1 = N >> 1;
+    const uint8_t *px = L.pos[1] + ((b * G1 + X) * KC) * 2, *py = L.pos[1] + ((b * G1 + Y) * KC) * 2;
+    if constexpr (KCH == 16 && KC == 16) {
+        constexpr int LS = MH + 64;                      // per leaf table: 256 entries + 33 border values
+        int *cent = reinterpret_cast<int *>(leaf + 4 * LS);   // [4][16] compact list -> codebook entry
+        int *crank = cent + 64;                               // [4][16] candidate -> compact rank of its leaf
+        const int NK = N * K;
+        // quarter w of the wave = one of the four halves' lists: 0, 1 = the halves of X, 2, 3 = those of Y
+        const int w = lane >> 4, c = lane & 15;
+        const int mypos = (w < 2 ? px : py)[2 * c + (w & 1)];
+        const int cb = (w < 2) ? 2 * X + w : 2 * Y + (w - 2);      // this quarter's codebook
+        const int myent = L.ent[(b * N + cb) * KCH + c];            // entry at level-0 position c of that codebook
+        uint32_t m = 1u << mypos;
+        m |= (uint32_t)dpp_i<0x121>((int)m);     // row_ror 1, 2, 4, 8: OR over the 16 lanes of the quarter
+        m |= (uint32_t)dpp_i<0x122>((int)m);
+        m |= (uint32_t)dpp_i<0x124>((int)m);
+        m |= (uint32_t)dpp_i<0x128>((int)m);
+        crank[lane] = __popc(m & ((1u << mypos) - 1u));
+        if ((m >> c) & 1u) cent[w * 16 + __popc(m & ((1u << c) - 1u))] = myent;
+        uint32_t mq[4];
+        mq[0] = (uint32_t)__builtin_amdgcn_readlane((int)m, 0);
+        mq[1] = (uint32_t)__builtin_amdgcn_readlane((int)m, 16);
+        mq[2] = (uint32_t)__builtin_amdgcn_readlane((int)m, 32);
+        mq[3] = (uint32_t)__builtin_amdgcn_readlane((int)m, 48);
+        wave_lds_fence();
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const int n = 2 * X + a, m = 2 * Y + c;
-            float d[VPLH];
-            tf_leaf<KCH>(G, N * K, K, n, m, L.ent + (b * N + n) * KCH, L.ent + (b * N + m) * KCH, id[n], id[m], d);
-            float *dst = leaf + (a * 2 + c) * MH + VPLH * lane;
-            if constexpr (VPLH == 4) {
-                *reinterpret_cast<f32x4 *>(dst) = (f32x4){d[0], d[1], d[2], d[3]};
-            } else {
+            for (int cc = 0; cc < 2; ++cc) {
+                const int n = 2 * X + a, mcb = 2 * Y + cc;
+                const int na = __popc(mq[a]), nc = __popc(mq[2 + cc]);
+                const uint32_t rown = (uint32_t)(n * K), colm = (uint32_t)(mcb * K);
+                float *lt = leaf + (a * 2 + cc) * LS;
+                // border: lanes [0, na) G[s_i][o_m], [na, na + nc) G[o_n][s_j], the others G[o_n][o_m]
+                const bool isu = lane < na, isv = lane >= na && lane < na + nc;
+                const uint32_t br = rown + (uint32_t)(isu ? cent[a * 16 + lane] : id[n]);
+                const uint32_t bc = colm + (uint32_t)(isv ? cent[(2 + cc) * 16 + (lane - na)] : id[mcb]);
+                const float bv = G[br * (uint32_t)NK + bc];
+                if (lane <= na + nc) lt[MH + lane] = bv;
+                wave_lds_fence();
+                const float wv = lt[MH + na + nc];
+                const float rnc = 1.0f / (float)nc;
+                for (int q = lane; q < na * nc; q += 64) {
+                    int ra = (int)((float)q * rnc);               // q / nc for q < 256 (corrected below)
+                    ra -= (ra * nc > q);
+                    ra += ((ra + 1) * nc <= q);
+                    const int rc = q - ra * nc;
+                    const float g = G[(rown + (uint32_t)cent[a * 16 + ra]) * (uint32_t)NK + colm + (uint32_t)cent[(2 + cc) * 16 + rc]];
+                    lt[ra * 16 + rc] = ((g - lt[MH + ra]) - lt[MH + na + rc]) + wv;
+                }
+            }
+        wave_lds_fence();
+        const int i = lane >> 2, j0 = 4 * (lane & 3);
+        const int ri0 = crank[i], ri1 = crank[16 + i];
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+            const int rj0 = crank[32 + j0 + v], rj1 = crank[48 + j0 + v];
+            t[v] = ((leaf[ri0 * 16 + rj0] + leaf[LS + ri0 * 16 + rj1]) + leaf[2 * LS + ri1 * 16 + rj0]) +
+                   leaf[3 * LS + ri1 * 16 + rj1];
+        }
+        return;
+    } else {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int n = 2 * X + a, m = 2 * Y + c;
+                float d[VPLH];
+                tf_leaf<KCH>(G, N * K, K, n, m, L.ent + (b * N + n) * KCH, L.ent + (b * N + m) * KCH, id[n], id[m], d);
+                float *dst = leaf + (a * 2 + c) * MH + VPLH * lane;
 #pragma unroll
                 for (int v = 0; v < VPLH; ++v) dst[v] = d[v];
             }
-        }
-    wave_lds_fence();
-    const int G1 = N >> 1;
-    const uint8_t *px = L.pos[1] + ((b * G1 + X) * KC) * 2, *py = L.pos[1] + ((b * G1 + Y) * KC) * 2;
-    const int i = (VPL * lane) / KC, j0 = (VPL * lane) % KC;
-    const int i0 = px[2 * i], i1 = px[2 * i + 1];
+        wave_lds_fence();
+        const int i = (VPL * lane) / KC, j0 = (VPL * lane) % KC;
+        const int i0 = px[2 * i], i1 = px[2 * i + 1];
 #pragma unroll
-    for (int v = 0; v < VPL; ++v) {
-        const int jj0 = py[2 * (j0 + v)], jj1 = py[2 * (j0 + v) + 1];
-        t[v] = ((leaf[i0 * KCH + jj0] + leaf[MH + i0 * KCH + jj1]) + leaf[2 * MH + i1 * KCH + jj0]) +
-               leaf[3 * MH + i1 * KCH + jj1];
+        for (int v = 0; v < VPL; ++v) {
+            const int jj0 = py[2 * (j0 + v)], jj1 = py[2 * (j0 + v) + 1];
+            t[v] = ((leaf[i0 * KCH + jj0] + leaf[MH + i0 * KCH + jj1]) + leaf[2 * MH + i1 * KCH + jj0]) +
+                   leaf[3 * MH + i1 * KCH + jj1];
+        }
     }
 }
+
+constexpr int tf_leaf_lds_floats(int KCH) { return 4 * (KCH * KCH + 64) + 128; }
 
 // combine of level 1: siblings X = 2g, Y = 2g + 1 (pairs of codebooks).  One wave per (b, g).
 template <int KCH, int KC>
@@ -240,7 +306,7 @@ k_tf_pair1(const float *__restrict__ G, const uint8_t *__restrict__ idx, const f
            int N, int K, int keep, uint8_t *__restrict__ idx_final, const int *__restrict__ nact) {
     constexpr int VPL = KC * KC / 64;
     __shared__ u64 scratch[kSelectLdsU64];
-    __shared__ __attribute__((aligned(16))) float leaf[4 * KCH * KCH];
+    __shared__ __attribute__((aligned(16))) float leaf[tf_leaf_lds_floats(KCH)];
     if (nact) B = *nact;
     const int Gout = N >> 2;
     const int g = (int)(blockIdx.x & (unsigned)(Gout - 1));
@@ -275,7 +341,7 @@ __global__ void __launch_bounds__(64)
 k_tf_table1(const float *__restrict__ G, const uint8_t *__restrict__ idx, TfLists L, long B, int N, int K, int ntab,
             int quads, float *__restrict__ tabs, const int *__restrict__ nact) {
     constexpr int VPL = KC * KC / 64;
-    __shared__ __attribute__((aligned(16))) float leaf[4 * KCH * KCH];
+    __shared__ __attribute__((aligned(16))) float leaf[tf_leaf_lds_floats(KCH)];
     if (nact) B = *nact;
     const int t = (int)(blockIdx.x & (unsigned)(ntab - 1));
     const long b = (long)(blockIdx.x >> __builtin_ctz((unsigned)ntab));
