@@ -13,16 +13,22 @@
  *    (torch `tensor.data_ptr()`), contiguous, alive until the stream has drained;
  *  - every function only enqueues work on `stream` (a hipStream_t passed as void*;
  *    NULL = the default stream) and returns immediately: no allocation, no
- *    synchronisation, no global mutable state, re-entrant per (device, stream);
+ *    synchronisation, re-entrant per (device, stream).  Process-wide state is limited to
+ *    read-only tuning hooks (environment variables latched on first use; DESIGN.md lists
+ *    them; none changes a result) and a thread-local launch counter
+ *    (mcq_last_encode_launches);
  *  - return value: 0 = ok; MCQ_E* < 0 = rejected argument; > 0 = hipError_t of a
  *    failed launch.  Nothing is thrown across the boundary.
  *  - supported domain: codebook_size K a power of two in [16, 256], num_codebooks N
- *    a power of two in [1, 64], any dim D >= 1 (rows are zero-padded to a multiple
- *    of 16 inside `prepared`).  The reference crashes for K < 16
+ *    a power of two, N <= 64 for K == 16 and N <= 32 for K >= 32 (what the reference's
+ *    trainer can produce: bytes_per_frame <= 32, quantization/quantization.py:614), any
+ *    dim D >= 1 (rows are zero-padded to a multiple of 16 inside `prepared`).  The reference crashes for K < 16
  *    (quantization/quantization.py:506) and needs K <= 256 for byte output (:271).
  *
  * Numerics: bit-identical to oracle/mcq_oracle.c (see its header for the spec:
- * v_mfma_f32_16x16x4_f32 k-order fmaf chains, wave64 butterfly reductions).
+ * v_mfma_f32_16x16x4_f32 k-order fmaf chains, wave64 butterfly reductions; for
+ * 2 <= N <= 16 the TABLE FORM: the search's inner products are read from the Gram
+ * matrix of the centers kept in `prepared` and from one x.C GEMM per call).
  */
 #ifndef MCQ_H
 #define MCQ_H
@@ -38,7 +44,7 @@ extern "C" {
 #define MCQ_EUNSUPPORTED (-2) /* outside the supported (K, N) domain             */
 #define MCQ_EWORKSPACE (-3) /* workspace smaller than mcq_encode_workspace_bytes */
 
-#define MCQ_ABI_VERSION 2
+#define MCQ_ABI_VERSION 3   /* 3: `prepared` also holds the Gram matrix (mcq_prepared_bytes grew) */
 int mcq_abi_version(void);
 
 /* D rounded up to the padded row length used inside `prepared` and workspaces. */
@@ -48,7 +54,9 @@ int mcq_padded_dim(int D);
  * Replaces Quantizer.get_centers() (quantization/quantization.py:77-79, recomputed
  * on every call there) and the parameter reads of Quantizer._logits (:277-279).
  * `prepared` receives: scaled centers C[N][K][Dp] = cscale_exp * centers, their
- * sum of squares Q[N][K] (:411), to_logits.weight padded to Dp and the bias.
+ * sum of squares Q[N][K] (:411), to_logits.weight padded to Dp and the bias, and -- when
+ * weight is given and 2 <= N <= 16 -- the Gram matrix G[N*K][N*K] of the scaled centers
+ * (16 MB at 8 x 256; what the table form of the search reads).
  * cscale_exp / lscale_exp = exp(10*centers_scale) / exp(10*logits_scale), formed
  * by the caller in fp32 exactly as the reference does (:78, :278).
  * weight/bias may be NULL when only decode is needed.                          */

@@ -31,9 +31,9 @@ typedef struct {
 
 static int is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 static int domain_ok(int N, int K, int D) {
-    return is_pow2(K) && K >= 16 && K <= 256 && is_pow2(N) && N <= 64 && D >= 1;
+    return is_pow2(K) && K >= 16 && K <= 256 && is_pow2(N) && N <= (K == 16 ? 64 : 32) && D >= 1;
 }
-static int domain_err(int N, int K) { return (K < 16 || K > 256 || N > 64) ? MCQ_EUNSUPPORTED : MCQ_EINVAL; }
+static int domain_err(int N, int K) { return (K < 16 || K > 256 || N > (K == 16 ? 64 : 32)) ? MCQ_EUNSUPPORTED : MCQ_EINVAL; }
 
 size_t mcq_prepared_bytes_host(int N, int K, int D) {
     size_t nk = (size_t)N * K;

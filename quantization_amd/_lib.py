@@ -80,7 +80,7 @@ def lib():
     L.mcq_last_encode_launches.restype = i32
     L.mcq_profile_encode.restype = i32
     L.mcq_profile_encode.argtypes = [vp, i64, vp, f32, i32, i32, i32, i32, vp, sz, vp, ctypes.POINTER(f32), i32]
-    assert L.mcq_abi_version() == 2
+    assert L.mcq_abi_version() == 3
     _lib = L
     return L
 

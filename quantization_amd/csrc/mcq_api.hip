@@ -132,9 +132,11 @@ Workspace carve(void *ws, long Bc, int N, int K, int Dp) {
     return w;
 }
 
+// N <= 64 for 16-entry codebooks, N <= 32 otherwise (what QuantizerTrainer can produce: bytes_per_frame <= 32)
 bool domain_ok(int N, int K, int D) {
-    return is_pow2(K) && K >= 16 && K <= 256 && is_pow2(N) && N <= 64 && D >= 1;
+    return is_pow2(K) && K >= 16 && K <= 256 && is_pow2(N) && N <= (K == 16 ? 64 : 32) && D >= 1;
 }
+int domain_err(int N, int K) { return (K < 16 || K > 256 || N > (K == 16 ? 64 : 32)) ? MCQ_EUNSUPPORTED : MCQ_EINVAL; }
 
 // optional per-launch timing (mcq_profile_encode)
 struct Prof {
@@ -454,7 +456,7 @@ int run_encode(const float *x, long B, const void *prepared, float lscale, int N
                uint8_t *out_u8, int64_t *out_i64, void *workspace, size_t workspace_bytes, hipStream_t st,
                Prof *prof, const int64_t *init_idx = nullptr, unsigned flags = 0) {
     g_last_launches = 0;
-    if (!domain_ok(N, K, D)) return (K < 16 || K > 256 || N > 64) ? MCQ_EUNSUPPORTED : MCQ_EINVAL;
+    if (!domain_ok(N, K, D)) return domain_err(N, K);
     if (B < 0 || iters < 0 || iters > 60 || (out_u8 == nullptr) == (out_i64 == nullptr)) return MCQ_EINVAL;
     if (B == 0) return 0;
     if (!x || !prepared || !workspace) return MCQ_EINVAL;
@@ -588,7 +590,7 @@ size_t mcq_prepared_bytes(int N, int K, int D) {
 
 static int prepare_impl(const float *centers, float cscale_exp, const float *scales_dev, const float *weight,
                         const float *bias, int N, int K, int D, void *prepared, void *stream) {
-    if (!domain_ok(N, K, D)) return (K < 16 || K > 256 || N > 64) ? MCQ_EUNSUPPORTED : MCQ_EINVAL;
+    if (!domain_ok(N, K, D)) return domain_err(N, K);
     if (!centers || !prepared || ((weight == nullptr) != (bias == nullptr))) return MCQ_EINVAL;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const PreparedLayout l = prepared_layout(N, K, D);
@@ -663,7 +665,7 @@ int mcq_refine_indexes(const float *x, long B, const void *prepared, int N, int 
 
 int mcq_decode(const void *codes, int code_bytes, int codes_per_row, long B, const void *prepared, int N, int K, int D,
                float *out, void *stream) {
-    if (!domain_ok(N, K, D)) return (K < 16 || K > 256 || N > 64) ? MCQ_EUNSUPPORTED : MCQ_EINVAL;
+    if (!domain_ok(N, K, D)) return domain_err(N, K);
     if (B < 0 || codes_per_row <= 0 || N % codes_per_row != 0) return MCQ_EINVAL;
     const int rep = N / codes_per_row;
     if (!(rep == 1 || rep == 2 || rep == 4 || rep == 8 || rep == 16)) return MCQ_EINVAL;

@@ -183,7 +183,8 @@ class Quantizer(nn.Module):
         assert 16 <= self.codebook_size <= 256, (
             "the index search needs 16 <= codebook_size <= 256 (the reference itself fails below 16, "
             "quantization.py:506, and needs <= 256 for byte codes, :271)")
-        assert self.num_codebooks <= 64
+        assert self.num_codebooks <= (64 if self.codebook_size == 16 else 32), (
+            "num_codebooks <= 64 for codebook_size 16, <= 32 otherwise (bytes_per_frame <= 32, quantization.py:614)")
 
     def _workspace(self, B: int, dev) -> Tensor:
         L = _lib.lib()

@@ -50,5 +50,5 @@ def check_codes(fx, it, codes, what):
     assert not hard.any(), (f"{what}: {int(hard.sum())} vectors differ from the reference with a clear margin, "
                             f"first at {np.flatnonzero(hard)[:5]}")
     # near-tie differences must stay rare, or the comparison means nothing
-    assert bad.sum() <= max(2, 0.005 * len(ref)), f"{what}: {int(bad.sum())} near-tie differences of {len(ref)}"
+    assert bad.sum() <= max(2, 0.0005 * len(ref)), f"{what}: {int(bad.sum())} near-tie differences of {len(ref)}"
     return int(bad.sum())
