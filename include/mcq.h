@@ -164,6 +164,42 @@ int mcq_loss_tail(const float *sums, const float *prob_sum, const float *count, 
 int mcq_recon_fwd(const float *x, const int64_t *idx, long B, const void *prepared, const float *mean, int N,
                   int K, int D, float *err, float *num_part, float *den_part, void *stream);
 
+
+/* ---- parameter update of QuantizerTrainer.step (:708-715, :722-730) ------------------------
+ * mcq_weight_grad: the autograd of Quantizer._logits (:277-279) w.r.t. to_logits: with G = dL/dlogits fp32 [B][M]
+ *   (M = N*K, from mcq_loss_bwd) and the frames x fp32 [B][D]:  gW[M][D] = s * G^T x,  gb[M] = column sums of G,
+ *   s = exp(10*logits_scale) read from DEVICE memory (scale_dev).  fp32 MFMA over splits of the batch whose partial
+ *   tiles (workspace) are added in a fixed order.
+ * mcq_adam_step: torch.optim.Adam's update (weight decay as L2 term, no amsgrad) on one flat bucket of n floats:
+ *   parameters p, gradients g, moments m / v; bias_correction1 = 1 - beta1^t and sqrt(1 - beta2^t) formed by the caller.
+ * mcq_loss_head: head[4] = {sum num_part, sum den_part, sum chosen_n, batch}: mcq_loss_tail's `sums` from the
+ *   partials of mcq_recon_fwd / mcq_loss_fwd without host or library reductions.
+ * mcq_scales_exp: out2 = {exp(speed * centers_scale), exp(speed * logits_scale)} on the device (the `scales_exp`
+ *   of mcq_prepare_dev).                                                                          */
+size_t mcq_weight_grad_workspace_bytes(long B, int M, int D);   /* partial tiles of the batch splits */
+int mcq_weight_grad(const float *G, const float *x, long B, int M, int D, const float *scale_dev, float *gW, float *gb,
+                    void *workspace, size_t workspace_bytes, void *stream);
+int mcq_adam_step(float *p, const float *g, float *m, float *v, long n, double lr, double beta1, double beta2, double eps,
+                  double weight_decay, double bias_correction1, double bias_correction2_sqrt, void *stream);
+int mcq_loss_head(const float *num_part, const float *den_part, long nparts, const float *chosen_n, int N, float batch,
+                  float *head, void *stream);
+int mcq_scales_exp(const float *centers_scale, const float *logits_scale, float speed, float *out2, void *stream);
+
+/* The scalar gradients without library reductions.  mcq_decode_backward_u8_ex: mcq_decode_backward_u8 whose stored
+ * rows are scaled by sa[0]*sb[0]*sc (device floats sa, sb; host float sc) and which also leaves, per wave, the share of
+ * <unscaled sums, dotw> (dotw fp32 [N][K][D]) in dot_part[mcq_decode_backward_waves(N, K, D)].  mcq_loss_bwd_ex:
+ * mcq_loss_bwd that also leaves sum grad * (logit - bias) per wave in dot_part[mcq_loss_bwd_waves(B, N, K)].
+ * mcq_grad_tail reduces both partial arrays in a fixed order:
+ *   out_c = (sum part_c) * sa[0]*sb[0]*sc * speed   (d/d centers_scale),   out_l = (sum part_l) * speed   (d/d logits_scale). */
+long mcq_decode_backward_waves(int N, int K, int D);
+int mcq_decode_backward_u8_ex(const float *grad_out, const uint8_t *codes, long B, int N, int K, int D, float *gC,
+                              const float *sa, const float *sb, float sc, const float *dotw, float *dot_part, void *stream);
+long mcq_loss_bwd_waves(long B, int N, int K);
+int mcq_loss_bwd_ex(const float *logits, const int64_t *idx, const float *lse, long B, int N, int K, const float *g_chosen,
+                    const float *g_prob, float *grad_logits, const float *bias, float *dot_part, void *stream);
+int mcq_grad_tail(const float *part_c, long n_c, const float *sa, const float *sb, float sc, const float *part_l, long n_l,
+                  float speed, float *out_c, float *out_l, void *stream);
+
 /* ---- JointCodebookLoss pieces (quantization/prediction.py:9-82) ----------------------
  * The consumer of the codes: a predictor trained to predict codebook n from its input and the entries of
  * codebooks 0..n-1.  The GEMMs are library calls on the caller's side; these are the fused non-GEMM parts.

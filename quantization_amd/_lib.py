@@ -15,6 +15,8 @@ SYMBOLS = (
     "mcq_encode", "mcq_encode_ex", "mcq_refine_indexes", "mcq_decode", "mcq_decode_backward", "mcq_logits", "mcq_last_encode_launches", "mcq_profile_encode",
     "mcq_logits_argmax", "mcq_loss_workspace_bytes", "mcq_loss_fwd", "mcq_loss_bwd", "mcq_recon_fwd", "mcq_loss_tail",
     "mcq_jcl_prefix_fwd", "mcq_jcl_prefix_bwd", "mcq_scatter_rows", "mcq_decode_backward_u8",
+    "mcq_weight_grad", "mcq_weight_grad_workspace_bytes", "mcq_adam_step", "mcq_loss_head", "mcq_scales_exp",
+    "mcq_decode_backward_waves", "mcq_decode_backward_u8_ex", "mcq_loss_bwd_waves", "mcq_loss_bwd_ex", "mcq_grad_tail",
 )
 
 MCQ_EINVAL, MCQ_EUNSUPPORTED, MCQ_EWORKSPACE = -1, -2, -3
@@ -77,6 +79,27 @@ def lib():
     L.mcq_decode_backward_u8.argtypes = [vp, vp, i64, i32, i32, i32, vp, vp]
     L.mcq_scatter_rows.restype = i32
     L.mcq_scatter_rows.argtypes = [vp, i64, i64, vp, i32, i64, i32, i32, i32, vp, vp]
+    L.mcq_weight_grad.restype = i32
+    L.mcq_weight_grad.argtypes = [vp, vp, i64, i32, i32, vp, vp, vp, vp, sz, vp]
+    L.mcq_weight_grad_workspace_bytes.restype = sz
+    L.mcq_weight_grad_workspace_bytes.argtypes = [i64, i32, i32]
+    f64 = ctypes.c_double
+    L.mcq_adam_step.restype = i32
+    L.mcq_adam_step.argtypes = [vp, vp, vp, vp, i64, f64, f64, f64, f64, f64, f64, f64, vp]
+    L.mcq_loss_head.restype = i32
+    L.mcq_loss_head.argtypes = [vp, vp, i64, vp, i32, f32, vp, vp]
+    L.mcq_scales_exp.restype = i32
+    L.mcq_scales_exp.argtypes = [vp, vp, f32, vp, vp]
+    L.mcq_decode_backward_waves.restype = i64
+    L.mcq_decode_backward_waves.argtypes = [i32, i32, i32]
+    L.mcq_decode_backward_u8_ex.restype = i32
+    L.mcq_decode_backward_u8_ex.argtypes = [vp, vp, i64, i32, i32, i32, vp, vp, vp, f32, vp, vp, vp]
+    L.mcq_loss_bwd_waves.restype = i64
+    L.mcq_loss_bwd_waves.argtypes = [i64, i32, i32]
+    L.mcq_loss_bwd_ex.restype = i32
+    L.mcq_loss_bwd_ex.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp, vp, vp, vp, vp]
+    L.mcq_grad_tail.restype = i32
+    L.mcq_grad_tail.argtypes = [vp, i64, vp, vp, f32, vp, i64, f32, vp, vp, vp]
     L.mcq_last_encode_launches.restype = i32
     L.mcq_profile_encode.restype = i32
     L.mcq_profile_encode.argtypes = [vp, i64, vp, f32, i32, i32, i32, i32, vp, sz, vp, ctypes.POINTER(f32), i32]

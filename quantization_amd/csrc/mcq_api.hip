@@ -4,6 +4,7 @@
 #include "mcq_kernels.h"
 #include "mcq_loss_kernels.h"
 #include "mcq_tf_kernels.h"
+#include "mcq_train_kernels.h"
 
 #include <cstdlib>
 #include <vector>
@@ -921,6 +922,126 @@ int mcq_recon_fwd(const float *x, const int64_t *idx, long B, const void *prepar
     const Prepared P = prepared_view(prepared, N, K, D);
     hipLaunchKernelGGL(k_recon_fwd, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), x, idx, B,
                        P.C, mean, N, K, D, round_up16(D), err, num_part, den_part);
+    MCQ_LAUNCH_CHECK();
+    return 0;
+}
+
+
+// ------------------------------------------------------------ parameter update
+namespace {
+int wgrad_splits(long B, int M, int D) {
+    const long tiles = (long)((M + 63) / 64) * ((D + 63) / 64);
+    long s = 2048 / tiles;                 // ~8 workgroups per CU
+    const long max_s = (B + 127) / 128;    // at least 128 rows of the batch per split
+    s = s > max_s ? max_s : s;
+    return (int)(s < 1 ? 1 : (s > 64 ? 64 : s));
+}
+}  // namespace
+
+size_t mcq_weight_grad_workspace_bytes(long B, int M, int D) {
+    if (B <= 0 || M <= 0 || D <= 0) return 256;
+    return (size_t)wgrad_splits(B, M, D) * ((size_t)M * D + M) * sizeof(float) + 256;
+}
+
+int mcq_weight_grad(const float *G, const float *x, long B, int M, int D, const float *scale_dev, float *gW, float *gb,
+                    void *workspace, size_t workspace_bytes, void *stream) {
+    if (B <= 0 || M <= 0 || D <= 0 || (M & 15) != 0) return MCQ_EINVAL;
+    if (!G || !x || !scale_dev || !gW || !gb || !workspace) return MCQ_EINVAL;
+    if (workspace_bytes < mcq_weight_grad_workspace_bytes(B, M, D)) return MCQ_EWORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int splits = wgrad_splits(B, M, D);
+    long rps = (B + splits - 1) / splits;
+    rps = (rps + 15) / 16 * 16;
+    float *part = static_cast<float *>(workspace);
+    float *partb = part + (size_t)splits * M * D;
+    const unsigned grid = (unsigned)(((M + 63) / 64) * ((D + 63) / 64) * splits);
+    hipLaunchKernelGGL(k_wgrad_tn, dim3(grid), dim3(256), 0, st, G, x, B, M, D, rps, part, partb);
+    MCQ_LAUNCH_CHECK();
+    const long MN = (long)M * D;
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((MN / 4 + 255) / 256)), dim3(256), 0, st, part, partb, splits, MN, M,
+                       scale_dev, gW, gb);
+    MCQ_LAUNCH_CHECK();
+    return 0;
+}
+
+int mcq_adam_step(float *p, const float *g, float *m, float *v, long n, double lr, double beta1, double beta2, double eps,
+                  double weight_decay, double bias_correction1, double bias_correction2_sqrt, void *stream) {
+    if (n < 0 || (n > 0 && (!p || !g || !m || !v))) return MCQ_EINVAL;
+    if (n == 0) return 0;
+    long blocks = (n / 4 + 255) / 256;
+    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), p, g, m, v, n,
+                       (float)(lr / bias_correction1), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
+                       (float)weight_decay, (float)bias_correction2_sqrt);
+    MCQ_LAUNCH_CHECK();
+    return 0;
+}
+
+int mcq_loss_head(const float *num_part, const float *den_part, long nparts, const float *chosen_n, int N, float batch,
+                  float *head, void *stream) {
+    if (nparts <= 0 || N <= 0 || !num_part || !den_part || !chosen_n || !head) return MCQ_EINVAL;
+    hipLaunchKernelGGL(k_loss_head, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), num_part, den_part, nparts, chosen_n,
+                       N, batch, head);
+    MCQ_LAUNCH_CHECK();
+    return 0;
+}
+
+int mcq_scales_exp(const float *centers_scale, const float *logits_scale, float speed, float *out2, void *stream) {
+    if (!centers_scale || !logits_scale || !out2) return MCQ_EINVAL;
+    hipLaunchKernelGGL(k_scales, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), centers_scale, logits_scale, speed, out2);
+    MCQ_LAUNCH_CHECK();
+    return 0;
+}
+
+// decode_backward_u8 with the trainer's epilogue: rows scaled by sa[0]*sb[0]*sc (device floats), and per-wave partials
+// of <unscaled sums, dotw> in dot_part[mcq_decode_backward_waves(N, K, D)]
+long mcq_decode_backward_waves(int N, int K, int D) { return (long)N * K * ((D + 63) / 64); }
+
+int mcq_decode_backward_u8_ex(const float *grad_out, const uint8_t *codes, long B, int N, int K, int D, float *gC,
+                              const float *sa, const float *sb, float sc, const float *dotw, float *dot_part, void *stream) {
+    if (N <= 0 || K <= 0 || K > 256 || D <= 0 || B < 0 || !gC) return MCQ_EINVAL;
+    if (B > 0 && (!grad_out || !codes)) return MCQ_EINVAL;
+    if ((dotw == nullptr) != (dot_part == nullptr)) return MCQ_EINVAL;
+    const int chunks = (D + 63) / 64;
+    const long waves = (long)N * K * chunks;
+    hipLaunchKernelGGL((k_decode_backward<uint8_t>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), grad_out, codes, B, N, K, D, chunks, gC, (long)D, 0L, N, sa, sb, sc,
+                       dotw, dot_part);
+    MCQ_LAUNCH_CHECK();
+    return 0;
+}
+
+long mcq_loss_bwd_waves(long B, int N, int K) {
+    const int rpw = K < 64 ? 64 / K : 1;
+    const long rows = B * N;
+    return ((rows + (long)kLossWaves * rpw - 1) / ((long)kLossWaves * rpw)) * kLossWaves;
+}
+
+int mcq_loss_bwd_ex(const float *logits, const int64_t *idx, const float *lse, long B, int N, int K, const float *g_chosen,
+                    const float *g_prob, float *grad_logits, const float *bias, float *dot_part, void *stream) {
+    if (!is_pow2(K) || K < 16 || K > 256 || N < 1) return MCQ_EUNSUPPORTED;
+    if (B <= 0) return MCQ_EINVAL;
+    if (!logits || !idx || !lse || !g_chosen || !g_prob || !grad_logits || !bias || !dot_part) return MCQ_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int rpw = K < 64 ? 64 / K : 1;
+    const long rows = B * N;
+    const dim3 grid((unsigned)((rows + (long)kLossWaves * rpw - 1) / ((long)kLossWaves * rpw))), block(64 * kLossWaves);
+#define MCQ_LOSS_CASE(KK)                                                                                             \
+    case KK: hipLaunchKernelGGL((k_loss_bwd<KK>), grid, block, 0, st, logits, idx, lse, B, N, g_chosen, g_prob, grad_logits, bias, dot_part); break;
+    switch (K) {
+        MCQ_LOSS_CASE(16) MCQ_LOSS_CASE(32) MCQ_LOSS_CASE(64) MCQ_LOSS_CASE(128) MCQ_LOSS_CASE(256)
+        default: return MCQ_EUNSUPPORTED;
+    }
+#undef MCQ_LOSS_CASE
+    MCQ_LAUNCH_CHECK();
+    return 0;
+}
+
+int mcq_grad_tail(const float *part_c, long n_c, const float *sa, const float *sb, float sc, const float *part_l, long n_l,
+                  float speed, float *out_c, float *out_l, void *stream) {
+    if (n_c < 0 || n_l < 0 || (n_c > 0 && !part_c) || (n_l > 0 && !part_l)) return MCQ_EINVAL;
+    hipLaunchKernelGGL(k_grad_tail, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), part_c, n_c, sa, sb, sc, part_l, n_l,
+                       speed, out_c, out_l);
     MCQ_LAUNCH_CHECK();
     return 0;
 }

@@ -1872,7 +1872,9 @@ __global__ void k_decode_reg(const uint8_t *__restrict__ codes, long B, const fl
 // gout[b * gsb + n * gsn + d] (decode: gsb = D, gsn = 0); idx[b * idx_stride + n]; negative indexes match no row.
 template <typename IdxT>   // int64 indexes, or uint8 codes (8x less index traffic: the scan is what bounds this kernel)
 __global__ void k_decode_backward(const float *__restrict__ gout, const IdxT *__restrict__ idx, long B, int N, int K,
-                                  int D, int chunks, float *__restrict__ gC, long gsb, long gsn, int idx_stride) {
+                                  int D, int chunks, float *__restrict__ gC, long gsb, long gsn, int idx_stride,
+                                  const float *__restrict__ sa = nullptr, const float *__restrict__ sb = nullptr, float sc = 1.0f,
+                                  const float *__restrict__ dotw = nullptr, float *__restrict__ dot_part = nullptr) {
     const long w = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (w >= (long)N * K * chunks) return;
     const int lane = lane_id();
@@ -1913,7 +1915,15 @@ __global__ void k_decode_backward(const float *__restrict__ gout, const IdxT *__
             }
         }
     }
-    if (dok) gC[row * D + d] = acc;
+    // optional epilogue (trainer): the stored rows are scaled by f = sa[0] * sb[0] * sc, and the wave's share of
+    // <sum, dotw> (the UNscaled sums against another [N*K][D] table) goes to dot_part[w] for a fixed-order reduction
+    const float f = (sa ? *sa : 1.0f) * (sb ? *sb : 1.0f) * sc;
+    if (dok) gC[row * D + d] = (sa || sb || sc != 1.0f) ? acc * f : acc;
+    if (dot_part != nullptr) {
+        float pd = dok ? acc * dotw[row * D + d] : 0.f;
+        pd = wave_sum_butterfly(pd);
+        if (lane == 0) dot_part[w] = pd;
+    }
 }
 
 }  // namespace mcq

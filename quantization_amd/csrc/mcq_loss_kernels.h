@@ -148,7 +148,8 @@ template <int K>
 __global__ void __launch_bounds__(64 * kLossWaves)
 k_loss_bwd(const float *__restrict__ logits, const int64_t *__restrict__ idx, const float *__restrict__ lse_in,
            long B, int N, const float *__restrict__ g_chosen /*[1]*/, const float *__restrict__ g_prob /*[N][K]*/,
-           float *__restrict__ grad /*[B][N][K]*/) {
+           float *__restrict__ grad /*[B][N][K]*/, const float *__restrict__ bias = nullptr /*[N][K]*/,
+           float *__restrict__ dot_part = nullptr /*[waves]: sum grad * (z - bias), for d/d logits_scale*/) {
     constexpr int KL = K < 64 ? K : 64, VPL = K / KL, RPW = 64 / KL;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane / KL, kl = lane % KL;
@@ -168,12 +169,19 @@ k_loss_bwd(const float *__restrict__ logits, const int64_t *__restrict__ idx, co
         dot += p[i] * g[i];
     }
     dot = row_sum<KL>(dot);
+    float ls = 0.f;
     if (ok) {
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
             const float d = (kl + KL * i == ki) ? 1.f : 0.f;
-            grad[rc * (long)K + kl + KL * i] = (ki < 0) ? 0.f : gc * (d - p[i]) + p[i] * (g[i] - dot);
+            const float gv = (ki < 0) ? 0.f : gc * (d - p[i]) + p[i] * (g[i] - dot);
+            grad[rc * (long)K + kl + KL * i] = gv;
+            if (dot_part != nullptr) ls += gv * (z[kl + KL * i] - bias[n * K + kl + KL * i]);
         }
+    }
+    if (dot_part != nullptr) {
+        ls = wave_sum_butterfly(ls);
+        if (lane == 0) dot_part[(long)blockIdx.x * kLossWaves + wave] = ls;
     }
 }
 

@@ -1,0 +1,229 @@
+// mcq_train_kernels.h -- gfx950 kernels of QuantizerTrainer.step's parameter update
+// (/root/reference/quantization/quantization.py:708-715, :722-730), the rest of SURVEY.md 8(f)-1:
+//   k_wgrad_tn   dW = s * G^T x  and  db = column sums of G   (autograd of _logits, :277-279)
+//   k_adam       torch.optim.Adam's update on one flat parameter / gradient / moment bucket (:712, :722-727)
+//   k_loss_head  the four batch sums mcq_loss_tail consumes, from the forward kernels' partials
+//   k_scales     exp(speed * scale) of the two scale parameters, on the device
+// Reductions have a fixed order (no float atomics): a training run is bit-reproducible.
+#pragma once
+#include "mcq_kernels.h"
+
+namespace mcq {
+
+// ------------------------------------------------------------------ dW, db
+// gW[m][n] = s * sum_b G[b][m] * x[b][n]   (m: logits row n*K + k, n: feature), gb[m] = sum_b G[b][m].
+// Both operands are contiguous along the OUTPUT axes and strided along the contraction axis b, so tiles go to LDS as
+// they lie in memory ([b][64 + pad] rows, ds_write_b128) and the MFMA fragments are ds_read_b32 along b: lane (r, g)
+// feeds row 4j + g of a 16-row block to MFMA j (rows stride 80 floats = 16 banks apart: the two half-waves of a read
+// hit 32 distinct banks).  Workgroup = 64 x 64 outputs, four waves of 32 x 32 (2 x 2 MFMA tiles), 16 rows of b per
+// stage, two LDS buffers, one barrier per stage.  Workgroups of one G column slab share an XCD (id = nt * MT + mt).
+constexpr int kWgStride = 80;       // floats per LDS row: 64 + 16
+constexpr int kWgStage = 16;        // rows of b per stage
+
+// The batch axis is cut into `splits` ranges (split-K): workgroup (tile, split) writes its partial tile to
+// part[split][M][Nf] (and partial column sums to partb[split][M]); k_wgrad_reduce adds the splits in ascending order and
+// applies s.  With 64 x 64 tiles alone a 2048 x 512 gradient is 256 workgroups of 256 serial stages each; eight splits
+// put 8 workgroups on every CU and hide the stage latency.
+__global__ void __launch_bounds__(256)
+k_wgrad_tn(const float *__restrict__ G /*[B][M]*/, const float *__restrict__ X /*[B][Nf]*/, long B, int M, int Nf,
+           long rows_per_split, float *__restrict__ gW /*part [splits][M][Nf]*/, float *__restrict__ gb /*partb [splits][M]*/) {
+    __shared__ __attribute__((aligned(16))) float lds[2][2][kWgStage * kWgStride];   // [buffer][A | B][row b][col]
+    __shared__ float colsum[16][64];
+    const int MT = (M + 63) / 64, NT = (Nf + 63) / 64;
+    const int tile = blockIdx.x % (MT * NT), split = blockIdx.x / (MT * NT);
+    const int mt = tile % MT, nt = tile / MT;
+    G += split * rows_per_split * M;
+    X += split * rows_per_split * Nf;
+    B = (B - split * rows_per_split < rows_per_split) ? B - split * rows_per_split : rows_per_split;
+    gW += (size_t)split * M * Nf;
+    gb += (size_t)split * M;
+    const int m0 = 64 * mt, n0 = 64 * nt;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int r = lane & 15, g = lane >> 4;
+    // staging: thread t moves the float4 at row (t / 16) of the stage, columns 4 * (t % 16) .. +3, of both tiles
+    const int srow = tid >> 4, scol = 4 * (tid & 15);
+    const bool acol_ok = m0 + scol < M;           // M = N*K is a multiple of 16
+    const bool xvec = (Nf & 3) == 0;              // rows of x are 16-byte aligned
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) acc[t][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+    const long nst = (B + kWgStage - 1) / kWgStage;
+    f32x4 ra, rb;
+    auto load = [&](long st) {
+        const long b = st * kWgStage + srow;
+        const long bc = b < B ? b : B - 1;
+        ra = acol_ok ? *reinterpret_cast<const f32x4 *>(G + bc * M + m0 + scol) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (xvec) {
+            rb = (n0 + scol < Nf) ? *reinterpret_cast<const f32x4 *>(X + bc * Nf + n0 + scol) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) rb[c] = (n0 + scol + c < Nf) ? X[bc * Nf + n0 + scol + c] : 0.f;
+        }
+        if (b >= B) { ra = (f32x4){0.f, 0.f, 0.f, 0.f}; rb = ra; }
+    };
+    auto store = [&](int buf) {
+        *reinterpret_cast<f32x4 *>(&lds[buf][0][srow * kWgStride + scol]) = ra;
+        *reinterpret_cast<f32x4 *>(&lds[buf][1][srow * kWgStride + scol]) = rb;
+        csum = csum + ra;                       // rows b = srow (mod 16) of this thread's four columns, b ascending
+    };
+    load(0);
+    store(0);
+    __syncthreads();
+    if (nst > 1) load(1);
+    for (long st = 0; st < nst; ++st) {
+        const int buf = (int)(st & 1);
+        const float *A = lds[buf][0], *Bt = lds[buf][1];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float a[2], b[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) a[t] = A[(4 * j + g) * kWgStride + 32 * wm + 16 * t + r];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) b[u] = Bt[(4 * j + g) * kWgStride + 32 * wn + 16 * u + r];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[u], acc[t][u], 0, 0, 0);
+        }
+        if (st + 1 < nst) store(buf ^ 1);
+        __syncthreads();
+        if (st + 2 < nst) load(st + 2);
+    }
+    const float s = 1.0f;
+    // lane holds rows m = 32 wm + 16 t + 4 g + v, column n = 32 wn + 16 u + r
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int n = n0 + 32 * wn + 16 * u + r;
+            if (n < Nf) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int m = m0 + 32 * wm + 16 * t + 4 * g + v;
+                    if (m < M) gW[(long)m * Nf + n] = s * acc[t][u][v];
+                }
+            }
+        }
+    if (nt == 0) {     // column sums of this G slab: the 16 row classes are added in order
+#pragma unroll
+        for (int c = 0; c < 4; ++c) colsum[srow][scol + c] = csum[c];
+        __syncthreads();
+        if (tid < 64) {
+            float t = colsum[0][tid];
+#pragma unroll
+            for (int q = 1; q < 16; ++q) t = t + colsum[q][tid];
+            if (m0 + tid < M) gb[m0 + tid] = t;
+        }
+    }
+}
+
+// gW[i] = s * (part[0][i] + part[1][i] + ...), gb likewise without the factor: splits ascending
+__global__ void __launch_bounds__(256)
+k_wgrad_reduce(const float *__restrict__ part, const float *__restrict__ partb, int splits, long MN, int M,
+               const float *__restrict__ scale, float *__restrict__ gW, float *__restrict__ gb) {
+    const float s = *scale;
+    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i < MN) {       // MN is a multiple of 4 (M = N*K is a multiple of 16)
+        f32x4 t = *reinterpret_cast<const f32x4 *>(part + i);
+        for (int q = 1; q < splits; ++q) t = t + *reinterpret_cast<const f32x4 *>(part + (size_t)q * MN + i);
+        *reinterpret_cast<f32x4 *>(gW + i) = t * s;
+    }
+    if (i < M) {
+        f32x4 t = *reinterpret_cast<const f32x4 *>(partb + i);
+        for (int q = 1; q < splits; ++q) t = t + *reinterpret_cast<const f32x4 *>(partb + (size_t)q * M + i);
+        *reinterpret_cast<f32x4 *>(gb + i) = t;
+    }
+}
+
+// --------------------------------------------------------------------- Adam
+// torch.optim.Adam (L2 weight decay, no amsgrad), the arithmetic of its fused implementation in fp32:
+//   g += wd * p;  m += (1 - beta1) * (g - m);  v = beta2 * v + (1 - beta2) * g * g;
+//   p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)
+// over one flat bucket (the parameters' .data and .grad are views of p and g).  lr / bc1, 1 - beta1, 1 - beta2 and
+// sqrt(bc2) are formed by the host in double precision, as torch forms them (1.0f - 0.9f is not float(0.1)).
+__global__ void __launch_bounds__(256)
+k_adam(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v, long n,
+       float step_size /* lr / bc1 */, float omb1 /* 1 - beta1 */, float beta2, float omb2 /* 1 - beta2 */, float eps, float wd,
+       float bc2_sqrt) {
+    for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long)gridDim.x * blockDim.x * 4) {
+        if (i + 3 < n) {
+            f32x4 pp = *reinterpret_cast<f32x4 *>(p + i), mm = *reinterpret_cast<f32x4 *>(m + i),
+                  vv = *reinterpret_cast<f32x4 *>(v + i);
+            const f32x4 gg0 = *reinterpret_cast<const f32x4 *>(g + i);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float gg = gg0[c] + wd * pp[c];
+                mm[c] = mm[c] + omb1 * (gg - mm[c]);
+                vv[c] = vv[c] * beta2 + (omb2 * gg) * gg;
+                const float denom = sqrtf(vv[c]) / bc2_sqrt + eps;
+                pp[c] = pp[c] - step_size * (mm[c] / denom);
+            }
+            *reinterpret_cast<f32x4 *>(p + i) = pp;
+            *reinterpret_cast<f32x4 *>(m + i) = mm;
+            *reinterpret_cast<f32x4 *>(v + i) = vv;
+        } else {
+            for (long q = i; q < n; ++q) {
+                const float gg = g[q] + wd * p[q];
+                m[q] = m[q] + omb1 * (gg - m[q]);
+                v[q] = v[q] * beta2 + (omb2 * gg) * gg;
+                p[q] = p[q] - step_size * (m[q] / (sqrtf(v[q]) / bc2_sqrt + eps));
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------- small pieces
+// head[4] = {sum num_part, sum den_part, sum chosen_n, Bf}: the sums mcq_loss_tail consumes (one workgroup; each sum
+// is 256 strided partials added in thread order, then a fixed tree)
+__global__ void __launch_bounds__(256)
+k_loss_head(const float *__restrict__ num_part, const float *__restrict__ den_part, long nparts,
+            const float *__restrict__ chosen_n, int N, float Bf, float *__restrict__ head) {
+    __shared__ float s[3][256];
+    const int t = threadIdx.x;
+    float a = 0.f, b = 0.f, c = 0.f;
+    for (long i = t; i < nparts; i += 256) { a += num_part[i]; b += den_part[i]; }
+    for (int i = t; i < N; i += 256) c += chosen_n[i];
+    s[0][t] = a; s[1][t] = b; s[2][t] = c;
+    __syncthreads();
+    for (int m = 128; m >= 1; m >>= 1) {
+        if (t < m) { s[0][t] += s[0][t + m]; s[1][t] += s[1][t + m]; s[2][t] += s[2][t + m]; }
+        __syncthreads();
+    }
+    if (t == 0) { head[0] = s[0][0]; head[1] = s[1][0]; head[2] = s[2][0]; head[3] = Bf; }
+}
+
+// The two scalar gradients from per-wave partials (fixed order: 256 strided sums, then a tree):
+//   out_c = (sum part_c) * (sa[0] * sb[0] * sc) * speed     d/d centers_scale (:78: scaled centers = exp(speed*cs) * centers)
+//   out_l = (sum part_l) * speed                            d/d logits_scale  (:278)
+__global__ void __launch_bounds__(256)
+k_grad_tail(const float *__restrict__ part_c, long n_c, const float *__restrict__ sa, const float *__restrict__ sb, float sc,
+            const float *__restrict__ part_l, long n_l, float speed, float *__restrict__ out_c, float *__restrict__ out_l) {
+    __shared__ float s[2][256];
+    const int t = threadIdx.x;
+    float a = 0.f, b = 0.f;
+    for (long i = t; i < n_c; i += 256) a += part_c[i];
+    for (long i = t; i < n_l; i += 256) b += part_l[i];
+    s[0][t] = a; s[1][t] = b;
+    __syncthreads();
+    for (int m = 128; m >= 1; m >>= 1) {
+        if (t < m) { s[0][t] += s[0][t + m]; s[1][t] += s[1][t + m]; }
+        __syncthreads();
+    }
+    if (t == 0) {
+        if (out_c) *out_c = s[0][0] * (((sa ? *sa : 1.0f) * (sb ? *sb : 1.0f) * sc) * speed);
+        if (out_l) *out_l = s[1][0] * speed;
+    }
+}
+
+// out[0] = exp(speed * centers_scale), out[1] = exp(speed * logits_scale)   (:78, :278; training flavour: on the device)
+__global__ void k_scales(const float *__restrict__ centers_scale, const float *__restrict__ logits_scale, float speed,
+                         float *__restrict__ out) {
+    if (threadIdx.x == 0) out[0] = expf(*centers_scale * speed);
+    if (threadIdx.x == 1) out[1] = expf(*logits_scale * speed);
+}
+
+}  // namespace mcq

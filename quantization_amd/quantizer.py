@@ -100,6 +100,7 @@ class Quantizer(nn.Module):
         st["_prep"] = None
         st["_ws"] = None
         st.pop("_host_stage", None)
+        st.pop("_scales_dev", None)
         return st
 
     # ------------------------------------------------------------ bookkeeping
@@ -158,16 +159,20 @@ class Quantizer(nn.Module):
         centers = self.centers.detach().to(torch.float32).contiguous()
         weight = self.to_logits.weight.detach().to(torch.float32).contiguous()
         bias = self.to_logits.bias.detach().to(torch.float32).contiguous()
-        both = torch.stack([self.centers_scale.detach(), self.logits_scale.detach()]).to(torch.float32)
         with torch.cuda.device(dev):
             st = torch.cuda.current_stream(dev).cuda_stream
             if on_device:
-                scales = (both * self.scale_speed).exp().contiguous()
+                scales = torch.empty(2, dtype=torch.float32, device=dev)     # {exp(speed*centers_scale), exp(speed*logits_scale)}
+                cs, ls = self.centers_scale.detach(), self.logits_scale.detach()
+                assert cs.dtype == torch.float32 and ls.dtype == torch.float32
+                _lib.check(L.mcq_scales_exp(cs.data_ptr(), ls.data_ptr(), self.scale_speed, scales.data_ptr(), st), "mcq_scales_exp")
+                self._scales_dev = scales
                 self._scale_flags = 2       # MCQ_ENCODE_LSCALE_FROM_PREPARED
                 self._cscale_exp = self._lscale_exp = 1.0
                 rc = L.mcq_prepare_dev(centers.data_ptr(), scales.data_ptr(), weight.data_ptr(), bias.data_ptr(), N, K,
                                        D, blob.data_ptr(), st)
             else:
+                both = torch.stack([self.centers_scale.detach(), self.logits_scale.detach()]).to(torch.float32)
                 both = both.to("cpu")       # both scalars in one device->host copy; exp on the host
                 self._scale_flags = 0
                 self._cscale_exp = _scale_exp(both[0], self.scale_speed)
@@ -502,7 +507,7 @@ class _LossState:
     __slots__ = ("xf", "idx", "err", "logits", "lse", "parts", "chosen_n", "prob_sum", "count")
 
 
-def _loss_forward_kernels(module, x, iters, blob, lscale_exp, flags) -> _LossState:
+def _loss_forward_kernels(module, x, iters, blob, lscale_exp, flags, prob_sum=None, count=None) -> _LossState:
     """mcq_logits_argmax (one GEMM gives the logits AND the initial indexes), mcq_refine_indexes,
     mcq_recon_fwd, mcq_loss_fwd on x (B, dim) fp32/fp16 on the HIP device."""
     L = _lib.lib()
@@ -524,8 +529,8 @@ def _loss_forward_kernels(module, x, iters, blob, lscale_exp, flags) -> _LossSta
     st_.parts = torch.empty((2, (B + 3) // 4), **f32)
     st_.lse = torch.empty((B, N), **f32)
     st_.chosen_n = torch.empty((N,), **f32)
-    st_.prob_sum = torch.empty((N, K), **f32)
-    st_.count = torch.empty((N, K), **f32)
+    st_.prob_sum = prob_sum if prob_sum is not None else torch.empty((N, K), **f32)
+    st_.count = count if count is not None else torch.empty((N, K), **f32)
     lws = torch.empty(L.mcq_loss_workspace_bytes(B, N, K), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         st = torch.cuda.current_stream(dev).cuda_stream
@@ -543,38 +548,67 @@ def _loss_forward_kernels(module, x, iters, blob, lscale_exp, flags) -> _LossSta
     return st_
 
 
-def _loss_backward_kernels(module, st_: _LossState, g_num, g_chosen, g_prob, centers, centers_scale, bias, logits_scale):
+def _loss_backward_kernels(module, st_: _LossState, g_num, g_chosen, g_prob, centers, centers_scale, bias, logits_scale,
+                           out=None, scales=None):
     """Gradients of  g_num * sum err^2 + g_chosen * sum chosen + <g_prob, prob_sum>  w.r.t. (centers, centers_scale,
     to_logits.weight, to_logits.bias, logits_scale); g_* are device tensors (or None).  Derivation:
-      d sum err^2 / d(scaled centers) = 2 * scatter-add of err (mcq_decode_backward);
-      logits = s (x W^T) + b with s = exp(speed * logits_scale):  dW = s G^T x,  db = sum_b G,
-      d logits_scale = speed * <G, logits - b>,  G = mcq_loss_bwd."""
+      d sum err^2 / d(scaled centers) = 2 * scatter-add of err  (mcq_decode_backward_u8_ex: rows scaled by
+        f = exp(speed*centers_scale) * 2 * g_num in its epilogue, <unscaled rows, centers> left as per-wave partials);
+      logits = s (x W^T) + b with s = exp(speed * logits_scale):  dW = s G^T x,  db = sum_b G  (mcq_weight_grad, fp32 MFMA),
+      d logits_scale = speed * <G, logits - b>  (per-wave partials of mcq_loss_bwd_ex),  G = d/d logits;
+      mcq_grad_tail reduces the two partial arrays in a fixed order.
+    `out`: optional dict name -> preallocated tensor (the trainer's flat gradient bucket); `scales`: optional device
+    float[2] {exp(speed*centers_scale), exp(speed*logits_scale)} (the trainer's prepared state holds it)."""
     L = _lib.lib()
     N, K, D = centers.shape
     B, dev = st_.xf.shape[0], st_.xf.device
     f32 = dict(dtype=torch.float32, device=dev)
+    speed = float(module.scale_speed)
+    out = out or {}
+
+    def buf(name, shape):
+        t = out.get(name)
+        if t is None:
+            t = torch.empty(shape, **f32)
+        assert t.dtype == torch.float32 and t.is_contiguous()
+        return t
+
+    if scales is None:
+        scales = torch.stack([(centers_scale.detach() * speed).exp(), (logits_scale.detach() * speed).exp()]).to(torch.float32)
+    assert scales.dtype == torch.float32 and st_.xf.dtype == torch.float32 and st_.err.dtype == torch.float32
     g_centers = g_cscale = g_weight = g_bias = g_lscale = None
-    speed = module.scale_speed
+    part_c = part_l = None
     with torch.cuda.device(dev):
         st = torch.cuda.current_stream(dev).cuda_stream
         if g_num is not None:
-            gC = torch.empty((N, K, D), **f32)
+            g_centers, g_cscale = buf("centers", (N, K, D)), buf("centers_scale", ())
+            gn = g_num.detach().to(torch.float32).reshape(1)
+            cw = centers.detach()
+            assert cw.dtype == torch.float32 and cw.is_contiguous()
             codes = st_.idx.to(torch.uint8)         # the scatter is bound by scanning the index column: 1 byte, not 8
-            _lib.check(L.mcq_decode_backward_u8(st_.err.data_ptr(), codes.data_ptr(), B, N, K, D, gC.data_ptr(), st),
-                       "mcq_decode_backward_u8")
-            f = (centers_scale.detach() * speed).exp() * (2.0 * g_num)          # scalar tensor
-            g_centers = gC * f
-            g_cscale = torch.dot(gC.reshape(-1), centers.detach().reshape(-1)) * (f * speed)
+            part_c = torch.empty(L.mcq_decode_backward_waves(N, K, D), **f32)
+            _lib.check(L.mcq_decode_backward_u8_ex(st_.err.data_ptr(), codes.data_ptr(), B, N, K, D, g_centers.data_ptr(),
+                                                   scales.data_ptr(), gn.data_ptr(), 2.0, cw.data_ptr(), part_c.data_ptr(), st),
+                       "mcq_decode_backward_u8_ex")
         if g_chosen is not None or g_prob is not None:
-            gc = (g_chosen if g_chosen is not None else torch.zeros((), **f32)).to(torch.float32).reshape(1).contiguous()
-            gp = (g_prob if g_prob is not None else torch.zeros((N, K), **f32)).to(torch.float32).contiguous()
+            g_weight, g_bias, g_lscale = buf("to_logits.weight", (N * K, D)), buf("to_logits.bias", (N * K,)), buf("logits_scale", ())
+            gc = (g_chosen if g_chosen is not None else torch.zeros((), **f32)).detach().to(torch.float32).reshape(1).contiguous()
+            gp = (g_prob if g_prob is not None else torch.zeros((N, K), **f32)).detach().to(torch.float32).contiguous()
+            bw = bias.detach()
+            assert bw.dtype == torch.float32 and bw.is_contiguous()
             G = torch.empty((B, N * K), **f32)
-            _lib.check(L.mcq_loss_bwd(st_.logits.data_ptr(), st_.idx.data_ptr(), st_.lse.data_ptr(), B, N, K, gc.data_ptr(),
-                                      gp.data_ptr(), G.data_ptr(), st), "mcq_loss_bwd")
-            s_ = (logits_scale.detach() * speed).exp()
-            g_weight = torch.mm(G.t(), st_.xf) * s_
-            g_bias = G.sum(dim=0)
-            g_lscale = (torch.dot(G.reshape(-1), st_.logits.reshape(-1)) - torch.dot(g_bias, bias.detach())) * speed
+            part_l = torch.empty(L.mcq_loss_bwd_waves(B, N, K), **f32)
+            _lib.check(L.mcq_loss_bwd_ex(st_.logits.data_ptr(), st_.idx.data_ptr(), st_.lse.data_ptr(), B, N, K, gc.data_ptr(),
+                                         gp.data_ptr(), G.data_ptr(), bw.data_ptr(), part_l.data_ptr(), st), "mcq_loss_bwd_ex")
+            wws = torch.empty(L.mcq_weight_grad_workspace_bytes(B, N * K, D), dtype=torch.uint8, device=dev)
+            _lib.check(L.mcq_weight_grad(G.data_ptr(), st_.xf.data_ptr(), B, N * K, D, scales[1:].data_ptr(), g_weight.data_ptr(),
+                                         g_bias.data_ptr(), wws.data_ptr(), wws.numel(), st), "mcq_weight_grad")
+        if part_c is not None or part_l is not None:
+            _lib.check(L.mcq_grad_tail(part_c.data_ptr() if part_c is not None else None, part_c.numel() if part_c is not None else 0,
+                                       scales.data_ptr(), gn.data_ptr() if part_c is not None else None, 2.0,
+                                       part_l.data_ptr() if part_l is not None else None, part_l.numel() if part_l is not None else 0,
+                                       speed, g_cscale.data_ptr() if g_cscale is not None else None,
+                                       g_lscale.data_ptr() if g_lscale is not None else None, st), "mcq_grad_tail")
     return g_centers, g_cscale, g_weight, g_bias, g_lscale
 
 

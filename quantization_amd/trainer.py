@@ -1,13 +1,48 @@
 """Host-side mirror of `quantization.QuantizerTrainer`
 (/root/reference/quantization/quantization.py:577-742)."""
 import logging
+import math
 import os
 import random
 import time
 
 import torch
 
+from . import _lib
 from .quantizer import Quantizer
+
+
+class _FlatAdam(torch.optim.Optimizer):
+    """The reference's optimizer (torch.optim.Adam with weight decay, quantization.py:722-727) as ONE kernel
+    (mcq_adam_step) over a flat bucket: the parameters' `.data` and `.grad` are views of `flat_p` / `flat_g`, the two
+    moments are flat too.  A torch Optimizer subclass, so the reference's StepLR drives its learning rate unchanged and
+    optimizer step hooks fire."""
+
+    def __init__(self, params, flat_p, flat_g, lr, betas, eps, weight_decay):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.flat_p, self.flat_g = flat_p, flat_g
+        self.exp_avg = torch.zeros_like(flat_p)
+        self.exp_avg_sq = torch.zeros_like(flat_p)
+        self.t = 0
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        assert closure is None
+        self.t += 1
+        g = self.param_groups[0]
+        b1, b2 = g["betas"]
+        bc1 = 1.0 - b1 ** self.t
+        bc2_sqrt = math.sqrt(1.0 - b2 ** self.t)
+        dev = self.flat_p.device
+        with torch.cuda.device(dev):
+            rc = _lib.lib().mcq_adam_step(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.exp_avg.data_ptr(),
+                                          self.exp_avg_sq.data_ptr(), self.flat_p.numel(), float(g["lr"]), float(b1), float(b2),
+                                          float(g["eps"]), float(g["weight_decay"]), float(bc1), float(bc2_sqrt),
+                                          torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(rc, "mcq_adam_step")
+
+    def zero_grad(self, set_to_none: bool = True):
+        self.flat_g.zero_()          # the gradients stay views of the bucket
 
 
 class QuantizerTrainer(object):
@@ -114,9 +149,14 @@ class QuantizerTrainer(object):
             tot_loss = reconstruction_loss + logprob_loss + logits_entropy_loss * self.entropy_scale   # quantization.py:682-683
             tot_loss.backward()
         if self._world() > 1:
-            self._all_reduce_flat([p.grad for p in self.quantizer.parameters()])
+            if self._flat is not None:      # one collective on the bucket the gradients already live in
+                dist = self._dist()
+                dist.all_reduce(self._flat[1], op=dist.ReduceOp.SUM, group=self.process_group)
+            else:
+                self._all_reduce_flat([p.grad for p in self.quantizer.parameters()])
         self.optim.step()
-        self.optim.zero_grad()
+        if not (fused and self._flat is not None):
+            self.optim.zero_grad()          # the fused step overwrites every gradient: nothing to clear
         self.scheduler.step()
         if self.cur_iter == self.phase_one_iters:                           # quantization.py:717-718
             self._begin_second_phase()
@@ -124,37 +164,43 @@ class QuantizerTrainer(object):
 
     def _fused_loss_and_grads(self, x, num_iters):
         """The step's loss AND its parameter gradients without autograd (HIP device): forward kernels ->
-        batch sums (all-reduced across ranks in data-parallel training) -> mcq_loss_tail (the four losses and
-        the upstream gradients of total = rel + logprob + entropy_scale * logits_entropy, :682-683) -> backward
-        kernels on the local shard.  Same mathematics as compute_loss + backward() (tested against it);
-        ~40 launches per step instead of ~100, which matters because the step is host-bound at batch 4096."""
-        from . import _lib
+        batch sums (mcq_loss_head; all-reduced across ranks in data-parallel training) -> mcq_loss_tail (the four
+        losses and the upstream gradients of total = rel + logprob + entropy_scale * logits_entropy, :682-683) ->
+        backward kernels on the local shard, writing straight into the flat gradient bucket.  Same mathematics as
+        compute_loss + backward() (tested against it)."""
         from .quantizer import _loss_backward_kernels, _loss_forward_kernels
         q = self.quantizer
         q._check_domain()
         N, K = q.num_codebooks, q.codebook_size
         B, dev = x.shape[0], x.device
+        L = _lib.lib()
         with torch.enable_grad():
             blob = q._prepared()                    # training flavour: scale factors stay on the device
         with torch.no_grad():
-            st_ = _loss_forward_kernels(q, x, num_iters, blob, q._lscale_exp, q._scale_flags)
-            key = (B, str(dev))
-            if getattr(self, "_bconst", (None,))[0] != key:
-                self._bconst = (key, torch.tensor([float(B)], dtype=torch.float32, device=dev))
-            head = torch.cat([st_.parts.sum(dim=1), st_.chosen_n.sum().reshape(1), self._bconst[1]])   # num, den, chosen, B
-            if self._world() > 1:
-                stats = [head, st_.prob_sum, st_.count]
-                self._all_reduce_flat(stats)
+            # head (4) | prob_sum (N*K) | count (N*K): one buffer, so the data-parallel forward exchange is one all-reduce
+            stats = torch.empty(4 + 2 * N * K, dtype=torch.float32, device=dev)
+            head, prob_sum, count = stats[:4], stats[4:4 + N * K].view(N, K), stats[4 + N * K:].view(N, K)
+            st_ = _loss_forward_kernels(q, x, num_iters, blob, q._lscale_exp, q._scale_flags, prob_sum, count)
             out = torch.empty(6 + N * K, dtype=torch.float32, device=dev)
             with torch.cuda.device(dev):
-                rc = _lib.lib().mcq_loss_tail(head.data_ptr(), st_.prob_sum.data_ptr(), st_.count.data_ptr(), N, K,
-                                              self.entropy_scale, out.data_ptr(), out[4:].data_ptr(), out[6:].data_ptr(),
-                                              torch.cuda.current_stream(dev).cuda_stream)
-            _lib.check(rc, "mcq_loss_tail")
+                st = torch.cuda.current_stream(dev).cuda_stream
+                _lib.check(L.mcq_loss_head(st_.parts[0].data_ptr(), st_.parts[1].data_ptr(), st_.parts.shape[1],
+                                           st_.chosen_n.data_ptr(), N, float(B), head.data_ptr(), st), "mcq_loss_head")
+                if self._world() > 1:
+                    dist = self._dist()
+                    dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=self.process_group)
+                _lib.check(L.mcq_loss_tail(head.data_ptr(), prob_sum.data_ptr(), count.data_ptr(), N, K, self.entropy_scale,
+                                           out.data_ptr(), out[4:].data_ptr(), out[6:].data_ptr(), st), "mcq_loss_tail")
+            names = ("centers", "centers_scale", "to_logits.weight", "to_logits.bias", "logits_scale")
+            params = (q.centers, q.centers_scale, q.to_logits.weight, q.to_logits.bias, q.logits_scale)
+            views = None
+            if self._flat is not None:
+                views = {n_: p_.grad for n_, p_ in zip(names, params)}
             grads = _loss_backward_kernels(q, st_, out[4], out[5], out[6:].view(N, K), q.centers, q.centers_scale,
-                                           q.to_logits.bias, q.logits_scale)
-            for p_, g_ in zip((q.centers, q.centers_scale, q.to_logits.weight, q.to_logits.bias, q.logits_scale), grads):
-                p_.grad = g_.reshape(p_.shape)
+                                           q.to_logits.bias, q.logits_scale, out=views, scales=getattr(q, "_scales_dev", None))
+            if views is None:
+                for p_, g_ in zip(params, grads):
+                    p_.grad = g_.reshape(p_.shape)
         return out[0], out[1], out[2], out[3]
 
     def _dp_losses(self, x, num_iters):
@@ -193,12 +239,39 @@ class QuantizerTrainer(object):
         """(rel_reconstruction, logprob, logits_entropy, index_entropy) losses of the last step, as floats."""
         return tuple(float(v) for v in self._last_losses)
 
+    def _flatten_parameters(self):
+        """Move the quantizer's parameters into one flat fp32 bucket (and their gradients into another): `.data` and
+        `.grad` become views, so the backward kernels write where Adam reads and the data-parallel all-reduce runs on
+        the bucket in place.  Offsets are multiples of 16 bytes."""
+        ps = list(self.quantizer.parameters())
+        offs, off = [], 0
+        for p in ps:
+            offs.append(off)
+            off += (p.numel() + 3) // 4 * 4
+        dev = ps[0].device
+        flat_p = torch.zeros(off, dtype=torch.float32, device=dev)
+        flat_g = torch.zeros(off, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for p, o in zip(ps, offs):
+                v = flat_p[o:o + p.numel()].view(p.shape)
+                v.copy_(p.data)
+                p.data = v
+                p.grad = flat_g[o:o + p.numel()].view(p.shape)
+        self.quantizer.invalidate_cache()
+        return flat_p, flat_g
+
     def _init_optimizer(self):
         # quantization.py:722-730
-        # the reference's Adam; on the HIP device as torch's single multi-tensor kernel (same update to 3e-8)
-        on_gpu = all(p.is_cuda for p in self.quantizer.parameters()) and os.environ.get("MCQ_TRAINER_FUSED_ADAM", "1") != "0"
-        self.optim = torch.optim.Adam(self.quantizer.parameters(), lr=self.lr, betas=(0.9, 0.98), eps=1e-9,
-                                      weight_decay=1.0e-06, **({"fused": True} if on_gpu else {}))
+        params = list(self.quantizer.parameters())
+        on_gpu = all(p.is_cuda and p.dtype == torch.float32 for p in params)
+        adam = dict(lr=self.lr, betas=(0.9, 0.98), eps=1e-9, weight_decay=1.0e-06)
+        self._flat = None
+        if on_gpu and os.environ.get("MCQ_TRAINER_FUSED_ADAM", "1") != "0":
+            # the reference's Adam as one kernel over a flat parameter / gradient bucket (same update to 3e-8)
+            self._flat = self._flatten_parameters()
+            self.optim = _FlatAdam(params, self._flat[0], self._flat[1], **adam)
+        else:
+            self.optim = torch.optim.Adam(params, **adam)
         self.scheduler = torch.optim.lr_scheduler.StepLR(
             self.optim, step_size=(self.phase_one_iters if self.cur_iter == 0 else self.phase_two_iters) / 4,
             gamma=0.5)

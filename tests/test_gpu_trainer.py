@@ -185,3 +185,71 @@ def test_decode_backward_on_uint8_codes_is_bit_identical():
         rows = (idx + torch.arange(N, device=dev) * K).reshape(-1)
         ref.index_add_(0, rows, g.double().unsqueeze(1).expand(-1, N, -1).reshape(-1, D))
         assert torch.allclose(a.double().reshape(N * K, D), ref, rtol=1e-5, atol=1e-4)
+
+
+def test_adam_kernel_matches_torch_adam():
+    """mcq_adam_step over a flat bucket against torch.optim.Adam (the reference's optimizer, quantization.py:722-727):
+    parameters within 3e-8 after 25 steps with changing learning rates, padding gaps untouched."""
+    from quantization_amd.trainer import _FlatAdam
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    shapes = [(8, 256, 24), (2048, 24), (2048,), (), ()]
+    ref_params = [torch.nn.Parameter(torch.randn(s, device=dev) * 0.05) for s in shapes]
+    offs, off = [], 0
+    for p in ref_params:
+        offs.append(off)
+        off += (p.numel() + 3) // 4 * 4
+    flat_p = torch.zeros(off, device=dev)
+    flat_g = torch.zeros(off, device=dev)
+    mine = []
+    for p, o in zip(ref_params, offs):
+        q = torch.nn.Parameter(torch.empty(0, device=dev))
+        q.data = flat_p[o:o + p.numel()].view(p.shape)
+        q.data.copy_(p.data)
+        q.grad = flat_g[o:o + p.numel()].view(p.shape)
+        mine.append(q)
+    kw = dict(lr=0.005, betas=(0.9, 0.98), eps=1e-9, weight_decay=1.0e-06)
+    ref_opt = torch.optim.Adam(ref_params, **kw)
+    my_opt = _FlatAdam(mine, flat_p, flat_g, **kw)
+    sched_r = torch.optim.lr_scheduler.StepLR(ref_opt, step_size=2.5, gamma=0.5)
+    sched_m = torch.optim.lr_scheduler.StepLR(my_opt, step_size=2.5, gamma=0.5)
+    for it in range(25):
+        for p, q in zip(ref_params, mine):
+            g = torch.randn(p.shape, device=dev) * (0.1 if it % 3 else 3.0)
+            p.grad = g.clone()
+            q.grad.copy_(g)
+        ref_opt.step()
+        my_opt.step()
+        sched_r.step()
+        sched_m.step()
+        assert ref_opt.param_groups[0]["lr"] == my_opt.param_groups[0]["lr"]
+    for p, q in zip(ref_params, mine):
+        assert float((p.detach() - q.detach()).abs().max()) <= 3e-8, float((p.detach() - q.detach()).abs().max())
+
+
+@pytest.mark.parametrize("B,N,K,D", [(4096, 8, 256, 512), (600, 4, 256, 256), (333, 8, 16, 40), (65, 2, 16, 30), (1000, 16, 16, 96)])
+def test_weight_grad_kernel_matches_matmul(B, N, K, D):
+    """mcq_weight_grad (fp32 MFMA, fused scale / column sums) against the library formulation s * G^T x, G.sum(0)."""
+    from quantization_amd import _lib
+    L = _lib.lib()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(B + D)
+    G = torch.randn(B, N * K, device=dev) * 0.01
+    x = torch.randn(B, D, device=dev)
+    s = torch.tensor([1.37], device=dev)
+    gW = torch.empty(N * K, D, device=dev)
+    gb = torch.empty(N * K, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    ws = torch.empty(L.mcq_weight_grad_workspace_bytes(B, N * K, D), dtype=torch.uint8, device=dev)
+    assert L.mcq_weight_grad(G.data_ptr(), x.data_ptr(), B, N * K, D, s.data_ptr(), gW.data_ptr(), gb.data_ptr(), ws.data_ptr(),
+                             ws.numel(), st) == 0
+    ref = (G.double().t() @ x.double()) * 1.37
+    assert float((gW.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    refb = G.double().sum(dim=0)
+    assert float((gb.double() - refb).abs().max()) <= 2e-5 * float(refb.abs().max() + 1e-6)
+    gW2 = torch.empty_like(gW)
+    gb2 = torch.empty_like(gb)
+    assert L.mcq_weight_grad(G.data_ptr(), x.data_ptr(), B, N * K, D, s.data_ptr(), gW2.data_ptr(), gb2.data_ptr(), ws.data_ptr(),
+                             ws.numel(), st) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(gW, gW2) and torch.equal(gb, gb2)        # fixed summation order
