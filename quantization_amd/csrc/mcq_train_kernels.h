@@ -196,20 +196,30 @@ k_loss_head(const float *__restrict__ num_part, const float *__restrict__ den_pa
     if (t == 0) { head[0] = s[0][0]; head[1] = s[1][0]; head[2] = s[2][0]; head[3] = Bf; }
 }
 
-// The two scalar gradients from per-wave partials (fixed order: 256 strided sums, then a tree):
+// The two scalar gradients from per-wave partials (fixed order: 1,024 strided sums, then a tree):
 //   out_c = (sum part_c) * (sa[0] * sb[0] * sc) * speed     d/d centers_scale (:78: scaled centers = exp(speed*cs) * centers)
 //   out_l = (sum part_l) * speed                            d/d logits_scale  (:278)
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 k_grad_tail(const float *__restrict__ part_c, long n_c, const float *__restrict__ sa, const float *__restrict__ sb, float sc,
             const float *__restrict__ part_l, long n_l, float speed, float *__restrict__ out_c, float *__restrict__ out_l) {
-    __shared__ float s[2][256];
+    __shared__ float s[2][1024];
     const int t = threadIdx.x;
-    float a = 0.f, b = 0.f;
-    for (long i = t; i < n_c; i += 256) a += part_c[i];
-    for (long i = t; i < n_l; i += 256) b += part_l[i];
-    s[0][t] = a; s[1][t] = b;
+    // thread t adds the elements t, t + 1024, ... in order, eight loads in flight at a time
+    auto strided_sum = [&](const float *__restrict__ p, long n) {
+        float a = 0.f;
+        for (long i0 = t; i0 < n; i0 += 8 * 1024) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const long i = i0 + (long)u * 1024; v[u] = i < n ? p[i] : 0.f; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a += v[u];
+        }
+        return a;
+    };
+    s[0][t] = strided_sum(part_c, n_c);
+    s[1][t] = strided_sum(part_l, n_l);
     __syncthreads();
-    for (int m = 128; m >= 1; m >>= 1) {
+    for (int m = 512; m >= 1; m >>= 1) {
         if (t < m) { s[0][t] += s[0][t + m]; s[1][t] += s[1][t + m]; }
         __syncthreads();
     }

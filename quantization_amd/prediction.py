@@ -31,7 +31,10 @@ def _forward_kernels(pred2d, idx2d, w1, b1, emb, w2, w2b, bias2):
     K, H = w2.shape[1], w2.shape[2]
     dev = pred2d.device
     f32 = dict(dtype=torch.float32, device=dev)
+    for t_ in (pred2d, w1, emb, w2, w2b, bias2):     # raw pointers go to fp32 kernels: no autocast / half tensors here
+        assert t_.dtype == torch.float32, "JointCodebookLoss kernels are fp32 (autocast is disabled inside the Function)"
     hp = torch.addmm(b1, pred2d, w1.t()) if b1 is not None else torch.mm(pred2d, w1.t())
+    assert hp.dtype == torch.float32 and hp.is_contiguous()
     A = torch.empty((N, B, H), **f32)
     scale = 0.5 * ((H / N) ** 0.5)                                            # prediction.py:52
     with torch.cuda.device(dev):
@@ -40,6 +43,7 @@ def _forward_kernels(pred2d, idx2d, w1, b1, emb, w2, w2b, bias2):
                    "mcq_jcl_prefix_fwd")
     Z = torch.baddbmm(bias2.unsqueeze(1), A, w2.transpose(1, 2))                # (N, B, K)   :67-77
     Z = torch.baddbmm(Z, pred2d.unsqueeze(0).expand(N, B, pred2d.shape[1]), w2b.transpose(1, 2))
+    assert Z.dtype == torch.float32 and Z.is_contiguous()
     idxT = idx2d.t().contiguous()
     lse = torch.empty((N * B,), **f32)
     chosen = torch.empty((1,), **f32)
@@ -55,6 +59,7 @@ def _forward_kernels(pred2d, idx2d, w1, b1, emb, w2, w2b, bias2):
 
 class _JointCodebookLossFn(torch.autograd.Function):
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, pred2d, idx2d, w1, b1, emb, w2, w2b, bias2, reduction, keep):
         hp, A, Z, idxT, lse, chosen, count, scale = _forward_kernels(pred2d, idx2d, w1, b1, emb, w2, w2b, bias2)
         nvalid = count.sum()
@@ -62,8 +67,14 @@ class _JointCodebookLossFn(torch.autograd.Function):
             loss = -chosen[0]
         elif reduction == "mean":
             loss = -chosen[0] / nvalid
+        elif reduction == "none":
+            # per (frame, codebook) losses in the reference's order (logprobs.reshape(-1, K): frame-major), 0 where ignored
+            N_, B_ = idxT.shape
+            tgt = idxT.clamp(min=0).unsqueeze(2)
+            rows = lse.view(N_, B_) - torch.gather(Z, 2, tgt).squeeze(2)
+            loss = torch.where(idxT >= 0, rows, torch.zeros_like(rows)).t().reshape(-1)
         else:
-            raise ValueError(f"reduction {reduction!r}: 'sum' and 'mean' are implemented")
+            raise ValueError(f"reduction {reduction!r}: expected 'sum', 'mean' or 'none'")
         ctx.reduction, ctx.scale, ctx.keep = reduction, scale, keep
         ctx.has_b1 = b1 is not None
         saved = [pred2d, idx2d, w1, b1 if b1 is not None else pred2d.new_empty(0), emb, w2, w2b, bias2, nvalid]
@@ -73,6 +84,7 @@ class _JointCodebookLossFn(torch.autograd.Function):
         return loss
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, g_out):
         saved = ctx.saved_tensors
         pred2d, idx2d, w1, b1, emb, w2, w2b, bias2, nvalid = saved[:9]
@@ -86,13 +98,16 @@ class _JointCodebookLossFn(torch.autograd.Function):
         K, H = w2.shape[1], w2.shape[2]
         dev = pred2d.device
         f32 = dict(dtype=torch.float32, device=dev)
-        gc = (-g_out if ctx.reduction == "sum" else -g_out / nvalid).to(torch.float32).reshape(1).contiguous()
         G = torch.empty((N, B, K), **f32)                                         # dL/dZ
+        gc = ((-g_out / nvalid) if ctx.reduction == "mean" else
+              (-g_out if ctx.reduction == "sum" else -torch.ones((), **f32))).to(torch.float32).reshape(1).contiguous()
         zeros = torch.zeros((1, K), **f32)
         with torch.cuda.device(dev):
             st = torch.cuda.current_stream(dev).cuda_stream
             _lib.check(L.mcq_loss_bwd(Z.data_ptr(), idxT.data_ptr(), lse.data_ptr(), N * B, 1, K, gc.data_ptr(),
                                       zeros.data_ptr(), G.data_ptr(), st), "mcq_loss_bwd")
+        if ctx.reduction == "none":      # unit-weight row gradients from the kernel, weighted by the upstream vector
+            G = G * g_out.to(torch.float32).reshape(B, N).t().unsqueeze(2)
         g_bias2 = G.sum(dim=1)
         Gt = G.transpose(1, 2)                                                      # (N, K, B)
         g_w2 = torch.bmm(Gt, A)                                                     # (N, K, H)
@@ -143,6 +158,8 @@ class JointCodebookLoss(nn.Module):
         _check_hip(predictor, "predictor")
         _check_hip(self.linear2_weight, "the module")
         assert list(predictor.shape[:-1]) == list(codebook_indexes.shape[:-1])     # prediction.py:41
+        # deviation from F.cross_entropy(ignore_index=...): EVERY negative target is ignored (the reference's callers pad
+        # with -100; any other negative index is an error there), and out-of-range codes are not diagnosed
         assert self.ignore_index < 0, "targets are ignored by sign (every negative index), as the reference's callers use it"
         pred2d = predictor.reshape(-1, predictor.shape[-1]).to(torch.float32).contiguous()
         idx2d = codebook_indexes.reshape(-1, codebook_indexes.shape[-1]).to(device=pred2d.device, dtype=torch.int64).contiguous()

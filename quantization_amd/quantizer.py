@@ -51,9 +51,16 @@ def _note_optimizer_step(optimizer, *_args, **_kwargs):
         _param_epoch[0] += 1
 
 
-from torch.optim.optimizer import register_optimizer_step_post_hook as _register_step_hook  # noqa: E402
+_hook_installed = [False]
 
-_register_step_hook(_note_optimizer_step)
+
+def _ensure_optimizer_hook():
+    """Installed on first use by a quantizer that has trainable parameters (not at import): a program that only
+    encodes / decodes with frozen quantizers never gets a process-wide optimizer hook."""
+    if not _hook_installed[0]:
+        from torch.optim.optimizer import register_optimizer_step_post_hook
+        register_optimizer_step_post_hook(_note_optimizer_step)
+        _hook_installed[0] = True
 
 
 def _is_pow2(n: int) -> bool:
@@ -138,7 +145,10 @@ class Quantizer(nn.Module):
         the training flavour is never used for an inference search (its scale factors may differ from
         the host's by an ulp); decode (`any_flavour`) takes whichever is current."""
         ps = (self.centers, self.centers_scale, self.logits_scale, self.to_logits.weight, self.to_logits.bias)
-        training = torch.is_grad_enabled() and any(p.requires_grad for p in ps)
+        trainable = any(p.requires_grad for p in ps)
+        if trainable:
+            _ensure_optimizer_hook()
+        training = torch.is_grad_enabled() and trainable
         for p in ps:
             if id(p) not in _quantizer_params or _quantizer_params[id(p)]() is not p:
                 if len(_quantizer_params) > 4096:     # drop entries of collected modules
@@ -147,6 +157,9 @@ class Quantizer(nn.Module):
                 _quantizer_params[id(p)] = weakref.ref(p)
         key = tuple((p.data_ptr(), p._version, str(p.device)) for p in ps) + (_param_epoch[0],)
         if self._prep is not None and self._prep[0] == key and (self._prep[2] == "host" or training or any_flavour):
+            cur = torch.cuda.current_stream(self._prep[1].device)
+            if cur.cuda_stream != self._prep[3]:
+                cur.wait_event(self._prep[4])      # built (asynchronously) on another stream: order this one after it
             return self._prep[1]
         on_device = training
         dev = self.centers.device
@@ -181,7 +194,11 @@ class Quantizer(nn.Module):
                                    blob.data_ptr(), st)
         _lib.check(rc, "mcq_prepare")
         # the inputs above may be temporaries: the stream orders their reuse after the kernel
-        self._prep = (key, blob, "device" if on_device else "host")
+        with torch.cuda.device(dev):
+            ev = torch.cuda.Event()
+            cur = torch.cuda.current_stream(dev)
+            ev.record(cur)
+        self._prep = (key, blob, "device" if on_device else "host", cur.cuda_stream, ev)
         return blob
 
     def _check_domain(self):
@@ -192,11 +209,18 @@ class Quantizer(nn.Module):
             "num_codebooks <= 64 for codebook_size 16, <= 32 otherwise (bytes_per_frame <= 32, quantization.py:614)")
 
     def _workspace(self, B: int, dev) -> Tensor:
+        """Scratch of the search, one buffer per (device, stream): encodes issued on different streams never share it."""
         L = _lib.lib()
         need = L.mcq_encode_workspace_bytes(B, self.num_codebooks, self.codebook_size, self.dim)
-        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
-        return self._ws
+        if not isinstance(self._ws, dict):
+            self._ws = {}
+        key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < need:
+            if len(self._ws) >= 8:
+                self._ws.clear()
+            ws = self._ws[key] = torch.empty(need, dtype=torch.uint8, device=dev)
+        return ws
 
     def _search(self, x2d: Tensor, iters: int, as_bytes: bool) -> Tensor:
         """x2d (B, dim) on the HIP device -> uint8 codes or int64 indexes via mcq_encode."""
@@ -364,6 +388,10 @@ class Quantizer(nn.Module):
         out = torch.empty((B, D), dtype=torch.float32, device=flat.device)
         if B == 0:
             return out
+        if os.environ.get("MCQ_CHECK_CODES") == "1" and flat.numel():
+            # debugging aid (synchronises): the kernels mask digits with K - 1 where the reference's gather would
+            # raise on an out-of-range index (quantization.py:142)
+            assert int(flat.min()) >= 0 and int(flat.max()) < K ** (N // per_row), "codes outside [0, codebook_size)"
         blob = self._prepared(any_flavour=True)
         with torch.cuda.device(flat.device):
             st = torch.cuda.current_stream(flat.device).cuda_stream
@@ -470,6 +498,7 @@ class _DecodeFn(torch.autograd.Function):
     d(out) into the chosen rows (what torch.gather/sum differentiate to, quantization.py:142-147)."""
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, module, flat, centers, centers_scale):
         out = module._decode_kernel(flat)
         idx = module._maybe_separate_indexes(flat.to(torch.int64))
@@ -478,6 +507,7 @@ class _DecodeFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, grad_out):
         idx, centers, centers_scale = ctx.saved_tensors
         m = ctx.module
@@ -617,6 +647,7 @@ class _LossSumsFn(torch.autograd.Function):
     the hand-derived backward of _loss_backward_kernels."""
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, module, x, iters, blob, lscale_exp, flags, centers, centers_scale, weight, bias, logits_scale):
         st_ = _loss_forward_kernels(module, x, iters, blob, lscale_exp, flags)
         sums = st_.parts.sum(dim=1)
@@ -628,6 +659,7 @@ class _LossSumsFn(torch.autograd.Function):
         return num, den, chosen, st_.prob_sum, st_.count, st_.idx
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, g_num, g_den, g_chosen, g_prob, g_count, g_idx):
         centers, centers_scale, bias, logits_scale = ctx.saved_tensors
         grads = _loss_backward_kernels(ctx.module, ctx.st, g_num, g_chosen, g_prob, centers, centers_scale, bias,

@@ -105,3 +105,72 @@ def test_ragged_sizes_against_the_torch_op_sequence(B, P, N, H, K):
     assert float((ga - gb).abs().max()) <= 1e-4 * float(gb.abs().max() + 1e-9)
     for k in pa:
         assert float((pa[k] - pb[k]).abs().max()) <= 1e-4 * float(pb[k].abs().max() + 1e-9), k
+
+
+def _torch_rows(m, pred, idx):
+    """the reference's op sequence (prediction.py:38-82) with reduction='none', in torch"""
+    import torch.nn.functional as F
+    N, K, H = m.num_codebooks, m.codebook_size, m.hidden_channels
+    p2 = pred.reshape(-1, pred.shape[-1])
+    i2 = idx.reshape(-1, N).to(torch.int64)
+    first = i2[:, :-1].clamp(min=0) + torch.arange(0, (N - 1) * K, K, device=i2.device)
+    emb = F.embedding(first, m.codebook_embedding.weight) * (0.5 * ((H / N) ** 0.5))
+    hp = F.linear(p2, m.linear1.weight, m.linear1.bias)
+    a = torch.relu(torch.cumsum(torch.cat((hp.unsqueeze(1), emb), dim=1), dim=1))
+    z = torch.matmul(a.transpose(0, 1), m.linear2_weight.transpose(1, 2)).transpose(0, 1)
+    z = z + torch.matmul(p2, m.linear2b_weight.transpose(1, 2)).transpose(0, 1) + m.linear2_bias
+    return F.cross_entropy(z.reshape(-1, K), i2.reshape(-1), ignore_index=-100, reduction="none")
+
+
+@pytest.mark.gpu
+def test_reduction_none_and_autocast():
+    """reduction='none' gives the per-(frame, codebook) losses in the reference's order with the right gradient; under
+    torch.autocast the fp32 kernels still see fp32 tensors (same loss and gradients as without it)."""
+    fx = np.load(FIXTURES[0])
+    m = _module(fx, False).cuda()
+    pred = torch.from_numpy(fx["predictor"]).cuda()
+    idx = torch.from_numpy(fx["indexes"]).cuda()
+    m.reduction = "none"
+    p1 = pred.clone().requires_grad_(True)
+    rows = m(p1, idx)
+    ref_rows = _torch_rows(m, pred, idx)
+    assert rows.shape == ref_rows.shape
+    assert torch.allclose(rows, ref_rows, rtol=1e-4, atol=1e-4)
+    w = torch.rand_like(rows)
+    (rows * w).sum().backward()
+    g1 = {k: p.grad.clone() for k, p in m.named_parameters()}
+    m.zero_grad()
+    p2 = pred.clone().requires_grad_(True)
+    (_torch_rows(m, p2, idx) * w).sum().backward()
+    assert torch.allclose(p1.grad, p2.grad, rtol=1e-3, atol=1e-4 * float(p2.grad.abs().max()))
+    for k, p in m.named_parameters():
+        assert torch.allclose(g1[k], p.grad, rtol=1e-3, atol=2e-4 * float(p.grad.abs().max())), k
+    # autocast
+    m.reduction = "sum"
+    m.zero_grad()
+    p3 = pred.clone().requires_grad_(True)
+    plain = m(p3, idx)
+    plain.backward()
+    gp = {k: p.grad.clone() for k, p in m.named_parameters()}
+    m.zero_grad()
+    p4 = pred.clone().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.float16):
+        ac = m(p4, idx)
+    ac.backward()
+    assert ac.dtype == torch.float32 and torch.equal(ac.detach(), plain.detach()) and torch.equal(p3.grad, p4.grad)
+    assert all(torch.equal(gp[k], p.grad) for k, p in m.named_parameters())
+    # the quantizer's own loss under autocast
+    from quantization_amd import Quantizer
+    torch.manual_seed(0)
+    q = Quantizer(64, 256, 4).cuda()
+    x = torch.randn(300, 64, device="cuda")
+    la = q.compute_loss(x, 1)
+    sum(la[:3]).backward()
+    ga = {k: p.grad.clone() for k, p in q.named_parameters()}
+    q.zero_grad()
+    with torch.autocast("cuda", dtype=torch.float16):
+        lb = q.compute_loss(x, 1)
+        tot = sum(lb[:3])
+    tot.backward()
+    assert all(torch.equal(a.detach(), b.detach()) for a, b in zip(la, lb))
+    assert all(torch.equal(ga[k], p.grad) for k, p in q.named_parameters())
