@@ -699,29 +699,6 @@ int mcq_decode(const void *codes, int code_bytes, int codes_per_row, long B, con
         hipError_t e4 = hipGetLastError();
         return e4 == hipSuccess ? 0 : (int)e4;
     }
-    // hybrid kernel (half the rows from LDS, half from L2): big batches of unpacked codes, rows that cut into 128-byte slices
-    const char *hyb_env = getenv("MCQ_DECODE_HYBRID_MIN");   // test / tuning hook, read per call
-    const long hyb_min_b = hyb_env ? atol(hyb_env) : 32768;
-    if (sliced_ok && rep == 1 && B >= hyb_min_b && K >= 32 && N >= 2 && (Dp % 32) == 0 && B < lds_min_b) {
-        int NL = (int)((144 * 1024) / ((size_t)K * 128));
-        NL = NL > N / 2 ? N / 2 : NL;
-        NL = NL < 1 ? 1 : NL;
-        if (N - NL <= 12) {
-            const int ns = Dp / 32, per_xcd = (ns + 7) / 8;
-            int groups = 256 / (8 * per_xcd);
-            groups = groups < 1 ? 1 : groups;
-            const unsigned g = (unsigned)(8 * per_xcd * groups);
-            const size_t lds = (size_t)NL * K * 128;
-            if (code_bytes == 1)
-                hipLaunchKernelGGL((k_decode_hybrid<uint8_t>), dim3(g), dim3(1024), lds, st, static_cast<const uint8_t *>(codes), B,
-                                   P.C, N, K, D, Dp, NL, groups, out);
-            else
-                hipLaunchKernelGGL((k_decode_hybrid<int64_t>), dim3(g), dim3(1024), lds, st, static_cast<const int64_t *>(codes), B,
-                                   P.C, N, K, D, Dp, NL, groups, out);
-            hipError_t e5 = hipGetLastError();
-            return e5 == hipSuccess ? 0 : (int)e5;
-        }
-    }
     if (sliced_ok && rep == 1 && B >= 4096 && K >= 32) {   // (16-entry codebooks: the per-vector kernels measured faster)
         int lpv = 4;
         while (lpv * 32 < Dp) lpv *= 2;          // 8 slices x lpv lanes x 4 floats cover Dp

@@ -1823,60 +1823,6 @@ k_decode_lds(const CodeT *__restrict__ codes, long B, const float *__restrict__ 
     }
 }
 
-// Hybrid decode for big batches: BOTH gather paths of a CU work at once.  The feature axis is cut into slices of
-// 32 floats (128 B of every row); a persistent workgroup keeps its slice of the first NL codebooks' rows in LDS
-// (NL * K * 128 B <= 144 KB: 4 codebooks of 256 entries) and gathers the rows of the other N - NL codebooks from its
-// XCD's L2 (each XCD serves two slices: 128 B pieces of 2 * (N - NL) * K rows).  The sliced kernel is bound by the
-// L2 -> L1 fabric (16 KB gathered per 2 KB written at 8 codebooks) and the LDS-resident one by LDS bank conflicts
-// on 64-byte rows and 64-byte output pieces; splitting the rows between the two halves the load of each and the
-// output is written in 128-byte pieces.  Eight lanes per (vector, slice); sums in codebook order as everywhere.
-template <typename CodeT>
-__global__ void __launch_bounds__(1024)
-k_decode_hybrid(const CodeT *__restrict__ codes, long B, const float *__restrict__ C, int N, int K, int D, int Dp, int NL,
-                int groups /* workgroups per slice */, float *__restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    f32x4 *rows = reinterpret_cast<f32x4 *>(smem);            // [NL*K][8]
-    const int ns = Dp / 32;                                    // slices (Dp % 32 == 0 checked by the host)
-    const int xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
-    const int per_xcd = (ns + 7) / 8;
-    const int slice = xcd + 8 * (within % per_xcd);            // slices congruent to the XCD id stay on it
-    const int grp = within / per_xcd;
-    if (slice >= ns) return;
-    const int tid = threadIdx.x;
-    const int nrows = NL * K;
-    for (int u = tid; u < nrows * 8; u += blockDim.x)
-        rows[u] = *reinterpret_cast<const f32x4 *>(C + (long)(u >> 3) * Dp + slice * 32 + 4 * (u & 7));
-    __syncthreads();
-    const long per = (B + groups - 1) / groups;
-    const long b_lo = grp * per, b_hi = (b_lo + per < B) ? b_lo + per : B;
-    const int q = tid & 7;
-    const int off = slice * 32 + 4 * q;
-    const bool vec_store = ((D & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0) && off + 3 < D;
-    const float *Cq = C + off;
-    for (long b = b_lo + (tid >> 3); b < b_hi; b += blockDim.x >> 3) {
-        const CodeT *cb = codes + b * N;
-        f32x4 g[12];
-#pragma unroll
-        for (int j = 0; j < 12; ++j) {                          // the L2 gathers first: they have the long latency
-            const int n = NL + j;
-            if (n < N) g[j] = *reinterpret_cast<const f32x4 *>(Cq + ((long)n * K + ((int)cb[n] & (K - 1))) * Dp);
-        }
-        f32x4 t = rows[((int)cb[0] & (K - 1)) * 8 + q];
-        for (int n = 1; n < NL; ++n) t = t + rows[(n * K + ((int)cb[n] & (K - 1))) * 8 + q];
-#pragma unroll
-        for (int j = 0; j < 12; ++j)
-            if (NL + j < N) t = t + g[j];
-        float *ob = out + b * D + off;
-        if (vec_store) {
-            __builtin_nontemporal_store(t, reinterpret_cast<f32x4 *>(ob));
-        } else {
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-                if (off + c < D) ob[c] = t[c];
-        }
-    }
-}
-
 // Fast path for unpacked uint8 codes and the common small shapes: all NN x J row pieces of a
 // vector are requested before the first add (16 gathers in flight per lane at dim 512 / 8 codebooks).
 template <int NN, int J>

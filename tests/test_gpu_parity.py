@@ -408,14 +408,6 @@ def test_decode_of_big_batches_takes_the_xcd_sliced_kernel_and_stays_bit_exact(D
     finally:
         del os.environ["MCQ_DECODE_LDS_MIN"]
     assert torch.equal(lds8, got8) and torch.equal(lds64, got8)
-    # the hybrid kernel of big batches (half the rows from LDS, half from L2; threshold lowered through its test hook)
-    os.environ["MCQ_DECODE_HYBRID_MIN"] = "4096"
-    try:
-        hy8 = q.decode(torch.from_numpy(codes.astype(np.uint8)).cuda())
-        hy64 = q.decode(torch.from_numpy(codes).cuda())
-    finally:
-        del os.environ["MCQ_DECODE_HYBRID_MIN"]
-    assert torch.equal(hy8, got8) and torch.equal(hy64, got8)
 
 
 def test_derived_state_follows_fused_optimizer_steps():
