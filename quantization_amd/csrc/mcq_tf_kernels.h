@@ -237,32 +237,62 @@ __device__ __forceinline__ void tf_table1(const float *__restrict__ G, const uin
         mq[2] = (uint32_t)__builtin_amdgcn_readlane((int)m, 32);
         mq[3] = (uint32_t)__builtin_amdgcn_readlane((int)m, 48);
         wave_lds_fence();
+        // All four tables move together: their border reads are one batch of loads, their core reads another, so a
+        // wave waits for two L2 round trips instead of eight (the kernel is bound by that latency chain, not by bytes).
+        int na_[4], nc_[4];
+        uint32_t rown_[4], colm_[4];
+        float bv[4];
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int tb = 0; tb < 4; ++tb) {
+            const int a = tb >> 1, cc = tb & 1;
+            const int n = 2 * X + a, mcb = 2 * Y + cc;
+            na_[tb] = __popc(mq[a]);
+            nc_[tb] = __popc(mq[2 + cc]);
+            rown_[tb] = (uint32_t)(n * K);
+            colm_[tb] = (uint32_t)(mcb * K);
+            // border: lanes [0, na) G[s_i][o_m], [na, na + nc) G[o_n][s_j], the others G[o_n][o_m]
+            const bool isu = lane < na_[tb], isv = lane >= na_[tb] && lane < na_[tb] + nc_[tb];
+            const uint32_t br = rown_[tb] + (uint32_t)(isu ? cent[a * 16 + lane] : id[n]);
+            const uint32_t bc = colm_[tb] + (uint32_t)(isv ? cent[(2 + cc) * 16 + (lane - na_[tb])] : id[mcb]);
+            bv[tb] = G[br * (uint32_t)NK + bc];
+        }
+        float g[4][4];
+        int rr[4][4];      // ra * 16 + rc of this lane's entry, -1 if none
 #pragma unroll
-            for (int cc = 0; cc < 2; ++cc) {
-                const int n = 2 * X + a, mcb = 2 * Y + cc;
-                const int na = __popc(mq[a]), nc = __popc(mq[2 + cc]);
-                const uint32_t rown = (uint32_t)(n * K), colm = (uint32_t)(mcb * K);
-                float *lt = leaf + (a * 2 + cc) * LS;
-                // border: lanes [0, na) G[s_i][o_m], [na, na + nc) G[o_n][s_j], the others G[o_n][o_m]
-                const bool isu = lane < na, isv = lane >= na && lane < na + nc;
-                const uint32_t br = rown + (uint32_t)(isu ? cent[a * 16 + lane] : id[n]);
-                const uint32_t bc = colm + (uint32_t)(isv ? cent[(2 + cc) * 16 + (lane - na)] : id[mcb]);
-                const float bv = G[br * (uint32_t)NK + bc];
-                if (lane <= na + nc) lt[MH + lane] = bv;
-                wave_lds_fence();
-                const float wv = lt[MH + na + nc];
-                const float rnc = 1.0f / (float)nc;
-                for (int q = lane; q < na * nc; q += 64) {
-                    int ra = (int)((float)q * rnc);               // q / nc for q < 256 (corrected below)
-                    ra -= (ra * nc > q);
-                    ra += ((ra + 1) * nc <= q);
-                    const int rc = q - ra * nc;
-                    const float g = G[(rown + (uint32_t)cent[a * 16 + ra]) * (uint32_t)NK + colm + (uint32_t)cent[(2 + cc) * 16 + rc]];
-                    lt[ra * 16 + rc] = ((g - lt[MH + ra]) - lt[MH + na + rc]) + wv;
+        for (int tb = 0; tb < 4; ++tb) {
+            const int a = tb >> 1, cc = tb & 1;
+            const int na = na_[tb], nc = nc_[tb];
+            const float rnc = 1.0f / (float)nc;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int q = lane + 64 * it;
+                rr[tb][it] = -1;
+                g[tb][it] = 0.f;
+                if (64 * it < na * nc) {          // wave-uniform
+                    const int qc = q < na * nc ? q : 0;
+                    int ra = (int)((float)qc * rnc);               // qc / nc for qc < 256 (corrected below)
+                    ra -= (ra * nc > qc);
+                    ra += ((ra + 1) * nc <= qc);
+                    const int rc = qc - ra * nc;
+                    g[tb][it] = G[(rown_[tb] + (uint32_t)cent[a * 16 + ra]) * (uint32_t)NK + colm_[tb] + (uint32_t)cent[(2 + cc) * 16 + rc]];
+                    rr[tb][it] = q < na * nc ? ra * 16 + rc : -1;
                 }
             }
+        }
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb)
+            if (lane <= na_[tb] + nc_[tb]) leaf[tb * LS + MH + lane] = bv[tb];
+        wave_lds_fence();
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb) {
+            float *lt = leaf + tb * LS;
+            const float wv = lt[MH + na_[tb] + nc_[tb]];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int e = rr[tb][it];
+                if (e >= 0) lt[e] = ((g[tb][it] - lt[MH + (e >> 4)]) - lt[MH + na_[tb] + (e & 15)]) + wv;
+            }
+        }
         wave_lds_fence();
         const int i = lane >> 2, j0 = 4 * (lane & 3);
         const int ri0 = crank[i], ri1 = crank[16 + i];
