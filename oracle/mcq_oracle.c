@@ -43,7 +43,11 @@
  *   XC[b][r] = dot16(C[r], x[b])        one GEMM per encode call (x zero padded, unscaled)
  *   stage 0:  X[b,n,k] = (G[(m0,i_m0)][(n,k)] + G[(m1,i_m1)][(n,k)] + ...) - XC[b][(n,k)],
  *             m ascending over the codebooks m != n (x_rem = sum_{m != n} old_m - x), then
- *             S = (R + Q) + 2 X as before; R and E are still computed from x_err directly.
+ *             S = (R + Q) + 2 X as before.
+ *   E, R:     x_err = sum_m o_m - x (o_m the current rows), so with xx = sumsq64(x):
+ *             E = (sum_{m,m'} G[o_m][o_m'] - 2 sum_m XC[b][o_m]) + xx      (both sums added as one wave adds them),
+ *             R[n] = (E - 2 ((G[o_0][o_n] + ... + G[o_{N-1}][o_n]) - XC[b][o_n])) + G[o_n][o_n];
+ *             they enter every score of a pass as additive constants only.
  *   leaf tables (codebooks n < m, shortlist positions i, j; o_n = current entry of n):
  *             D[n][m][i][j] = ((G[s_n,i][s_m,j] - G[s_n,i][o_m]) - G[o_n][s_m,j]) + G[o_n][o_m]
  *             = delta_n[i] . delta_m[j]  with delta = c - old  (:436-439)
@@ -361,8 +365,8 @@ static void refine_one(const mcq_oracle *o, const float *x, uint8_t *idx, scratc
 
 
 /* ---------------------------------------------------------------- table form */
-/* G[r][c] = dot16(C[r], C[c]) for rows in different codebooks (the blocks on the diagonal are never
- * read and stay zero).  fmaf(a, b, acc) is symmetric in a, b, so G[c][r] == G[r][c] bit for bit. */
+/* G[r][c] = dot16(C[r], C[c]) for all pairs of rows.  fmaf(a, b, acc) is symmetric in a, b, so
+ * G[c][r] == G[r][c] bit for bit. */
 static void build_gram(mcq_oracle *o) {
     const int N = o->N, K = o->K, Dp = o->Dp;
     const size_t nk = (size_t)N * K;
@@ -371,7 +375,7 @@ static void build_gram(mcq_oracle *o) {
     for (long r = 0; r < (long)nk; r++) {
         const float *cr = o->C + (size_t)r * Dp;
         const int nr = (int)(r / K);
-        for (int m = nr + 1; m < N; m++) {
+        for (int m = nr; m < N; m++) {      /* blocks on and above the diagonal; the rest is mirrored */
             float *acc = G + (size_t)r * nk + (size_t)m * K;
             for (int i = 0; i < Dp; i++) {
                 const float xv = cr[o->order16[i]];
@@ -382,11 +386,27 @@ static void build_gram(mcq_oracle *o) {
     }
     for (size_t r = 0; r < nk; r++)
         for (size_t c = 0; c < (r / K) * K; c++) G[r * nk + c] = G[c * nk + r];
-    o->G = G;
+    o->G = G;      /* (inside a diagonal block both triangles were computed: fmaf(a, b, .) == fmaf(b, a, .)) */
 }
 
 static void ensure_gram(const mcq_oracle *o) {
     if (o->table_form && !o->G) build_gram((mcq_oracle *)o);
+}
+
+/* sum of n (<= 256) terms the way one wave adds them: lane l takes the terms l, l + 64, ... in order (absent
+ * terms are +0), then the xor butterfly 32, 16, ..., 1 -- the reduction of sumsq64 */
+static float wave_sum(const float *t, int n) {
+    float p[64], q[64];
+    for (int l = 0; l < 64; l++) {
+        float a = 0.0f;
+        for (int j = l; j < n; j += 64) a = a + t[j];
+        p[l] = a;
+    }
+    for (int m = 32; m >= 1; m >>= 1) {
+        for (int l = 0; l < 64; l++) q[l] = p[l] + p[l ^ m];
+        memcpy(p, q, sizeof(p));
+    }
+    return p[0];
 }
 
 /* XC[r] = dot16(C[r], x) for all N*K rows (x unscaled, zero padded) */
@@ -454,22 +474,38 @@ static void refine_one_table(const mcq_oracle *o, const float *x, const float *x
                              mcq_trace *tr) {
     const int N = o->N, K = o->K, D = o->D, Dp = o->Dp;
     const size_t nk = (size_t)N * K;
-    for (int n = 0; n < N; n++)
-        memcpy(s->old + (size_t)n * Dp, o->C + ((size_t)n * K + idx[n]) * Dp, sizeof(float) * Dp);
-    for (int d = 0; d < Dp; d++) {
-        float t = s->old[d];
-        for (int n = 1; n < N; n++) t = t + s->old[(size_t)n * Dp + d];
-        s->xerr[d] = t - ((d < D) ? x[d] : 0.0f);
+    /* E = |x_err|^2 and R[n] = |x_err - old_n|^2 (:401-409) from the tables: with o_m the current rows,
+     *   x_err = sum_m o_m - x   =>   E = sum_{m,m'} G[o_m][o_m'] - 2 sum_m XC[o_m] + |x|^2,
+     *   x_err . o_n = sum_m G[o_m][o_n] - XC[o_n]   =>   R[n] = (E - 2 (x_err . o_n)) + G[o_n][o_n].
+     * They only enter the scores as additive constants of the pass.  xx = sumsq64(x) (zero padded). */
+    float gterm[256], xterm[16], xx;
+    {
+        float *xp = s->xrem;                       /* scratch: the padded x */
+        for (int d = 0; d < Dp; d++) xp[d] = (d < D) ? x[d] : 0.0f;
+        xx = sumsq64(xp, Dp);
     }
-    const float E = sumsq64(s->xerr, Dp);
-    if (tr && tr->xerr) memcpy(tr->xerr, s->xerr, sizeof(float) * Dp);
+    for (int m = 0; m < N; m++) {
+        xterm[m] = xc[(size_t)m * K + idx[m]];
+        for (int m2 = 0; m2 < N; m2++)
+            gterm[m * N + m2] = o->G[((size_t)m * K + idx[m]) * nk + (size_t)m2 * K + idx[m2]];
+    }
+    const float gsum = wave_sum(gterm, N * N), xsum = wave_sum(xterm, N);
+    const float E = (gsum - 2.0f * xsum) + xx;
+    if (tr && tr->xerr) {                          /* trace only: the residual itself */
+        for (int d = 0; d < Dp; d++) {
+            float t = o->C[((size_t)0 * K + idx[0]) * Dp + d];
+            for (int n = 1; n < N; n++) t = t + o->C[((size_t)n * K + idx[n]) * Dp + d];
+            tr->xerr[d] = t - ((d < D) ? x[d] : 0.0f);
+        }
+    }
     if (tr && tr->E) tr->E[0] = E;
 
     /* stage 0 (:403-418) with X from the tables */
     for (int n = 0; n < N; n++) {
-        const float *old = s->old + (size_t)n * Dp;
-        for (int d = 0; d < Dp; d++) s->xrem[d] = s->xerr[d] - old[d];
-        const float R = sumsq64(s->xrem, Dp);
+        float col = gterm[0 * N + n];
+        for (int m = 1; m < N; m++) col = col + gterm[m * N + n];
+        const float xo = col - xterm[n];
+        const float R = (E - 2.0f * xo) + gterm[n * N + n];
         if (tr && tr->R) tr->R[n] = R;
         float *acc = s->S + (size_t)n * K;
         const float *Q = o->Q + (size_t)n * K;

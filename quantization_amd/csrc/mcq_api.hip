@@ -61,7 +61,7 @@ struct Workspace {
     int *map[2], *cnt;
     float *xerr, *E, *R, *S0;
     // table form: x.C products, the lists of every level, the level-1 tables of cousin groups
-    float *XC, *tabs;
+    float *XC, *tabs, *xx;
     TfLists tf;
     uint8_t *tup[3];   // three-way rotation: a DEDUP pair stage also reads the lists of two stages back
     uint8_t *pos;      // (a, b) of every candidate kept by the stage before a DEDUP stage
@@ -81,7 +81,8 @@ size_t workspace_per_vector(int N, int K, int Dp) {
     if (table_form(N)) {
         // idx x4, maps, xerr, E, R, XC, lists (entries / positions / scores: <= 16 + 4*16 B per codebook and level), tabs
         const int kc1 = k_cutoff(K, 2);
-        return 4 * (size_t)N + 8 + 4 * (size_t)Dp + 4 + 4 * (size_t)N + 4 * (size_t)N * K + kTfLevels * (size_t)N * (16 + 2 * 16 + 4 * 16) +
+        (void)Dp;
+        return 4 * (size_t)N + 8 + 8 + 4 * (size_t)N + 4 * (size_t)N * K + kTfLevels * (size_t)N * (16 + 2 * 16 + 4 * 16) +
                (size_t)tf_ntab(N) * kc1 * kc1 * 4;
     }
     const size_t s0 = fused_select(N, K) ? 0 : 4 * (size_t)N * K;
@@ -102,11 +103,12 @@ Workspace carve(void *ws, long Bc, int N, int K, int Dp) {
     w.final_idx = reinterpret_cast<uint8_t *>(take((size_t)Bc * N));
     for (int i = 0; i < 2; ++i) w.map[i] = reinterpret_cast<int *>(take((size_t)Bc * 4));
     w.cnt = reinterpret_cast<int *>(take(64 * 4));
-    w.xerr = reinterpret_cast<float *>(take((size_t)Bc * Dp * 4));
+    w.xerr = table_form(N) ? nullptr : reinterpret_cast<float *>(take((size_t)Bc * Dp * 4));
     w.E = reinterpret_cast<float *>(take((size_t)Bc * 4));
     w.R = reinterpret_cast<float *>(take((size_t)Bc * N * 4));
     if (table_form(N)) {
         w.S0 = nullptr;
+        w.xx = reinterpret_cast<float *>(take((size_t)Bc * 4));
         w.XC = reinterpret_cast<float *>(take((size_t)Bc * N * K * 4));
         for (int v = 0; v < kTfLevels; ++v) {
             const int kc = k_cutoff(K, 1 << v);
@@ -125,7 +127,7 @@ Workspace carve(void *ws, long Bc, int N, int K, int Dp) {
         w.S[0] = w.S[1] = nullptr;
         return w;
     }
-    w.XC = w.tabs = nullptr;
+    w.XC = w.tabs = w.xx = nullptr;
     w.S0 = fused_select(N, K) ? nullptr : reinterpret_cast<float *>(take((size_t)Bc * N * K * 4));
     for (int i = 0; i < 3; ++i) w.tup[i] = reinterpret_cast<uint8_t *>(take((size_t)Bc * N * 64));
     w.pos = reinterpret_cast<uint8_t *>(take((size_t)Bc * N * 16));
@@ -383,6 +385,20 @@ int launch_tf_stage0_k(int N, const float *G, const float *XC, const uint8_t *id
     return 0;
 }
 
+int launch_tf_er(int N, const float *G, const float *XC, const uint8_t *idx, const float *xx, long B, int K, float *E, float *R,
+                 const int *nact, const int *map, hipStream_t st) {
+    const dim3 grid((unsigned)((B + 3) / 4)), block(256);
+    switch (N) {
+        case 2: hipLaunchKernelGGL((k_tf_er<2>), grid, block, 0, st, G, XC, idx, xx, B, K, E, R, nact, map); break;
+        case 4: hipLaunchKernelGGL((k_tf_er<4>), grid, block, 0, st, G, XC, idx, xx, B, K, E, R, nact, map); break;
+        case 8: hipLaunchKernelGGL((k_tf_er<8>), grid, block, 0, st, G, XC, idx, xx, B, K, E, R, nact, map); break;
+        case 16: hipLaunchKernelGGL((k_tf_er<16>), grid, block, 0, st, G, XC, idx, xx, B, K, E, R, nact, map); break;
+        default: return MCQ_EUNSUPPORTED;
+    }
+    MCQ_TF_CHECK();
+    return 0;
+}
+
 int launch_tf_stage0(int K, int N, const float *G, const float *XC, const uint8_t *idx, const float *R, const float *Q,
                      long B, int keep, uint8_t *ent, float *S, const int *nact, const int *map, hipStream_t st) {
     switch (K) {
@@ -499,7 +515,10 @@ int run_encode(const float *x, long B, const void *prepared, float lscale, int N
             rc = launch_gemm<MODE_XC>(K, P.C, xc, nullptr, 1.0f, nullptr, nullptr, nullptr, Bc, N, D, Dp, nullptr, w.XC, st,
                                       0, nullptr, nullptr, xh);
             if (rc) return rc;
-            if (prof) prof->end(CAT_PRUNE0);
+            if (prof) { prof->end(CAT_PRUNE0); prof->begin(); }
+            hipLaunchKernelGGL(k_tf_xx, dim3((unsigned)((Bc + 3) / 4)), dim3(256), 0, st, xc, Bc, D, Dp, w.xx, xh);
+            MCQ_LAUNCH_CHECK();
+            if (prof) prof->end(CAT_RESIDUAL);
         }
         // without skipping: indexes are refined in place in w.idx, nothing is packed
         uint8_t *idx_cur = w.idx, *idx_new = skip ? w.idxB : w.idx, *idx_pk = w.idxC;
@@ -511,10 +530,15 @@ int run_encode(const float *x, long B, const void *prepared, float lscale, int N
         }
         for (int it = 0; it < iters; ++it) {
             if (prof) prof->begin();
-            rc = launch_residual(xc, idx_cur, P.C, Bc, N, K, D, Dp, w.xerr, w.E, w.R, st, nact, map_cur, xh);
-            if (rc) return rc;
-            if (prof) { prof->end(CAT_RESIDUAL); prof->begin(); }
+            if (!tf) {
+                rc = launch_residual(xc, idx_cur, P.C, Bc, N, K, D, Dp, w.xerr, w.E, w.R, st, nact, map_cur, xh);
+                if (rc) return rc;
+                if (prof) { prof->end(CAT_RESIDUAL); prof->begin(); }
+            }
             if (tf) {
+                rc = launch_tf_er(N, P.G, w.XC, idx_cur, w.xx, Bc, K, w.E, w.R, nact, map_cur, st);
+                if (rc) return rc;
+                if (prof) { prof->end(10); prof->begin(); }
                 rc = launch_tf_stage0(K, N, P.G, w.XC, idx_cur, w.R, P.Q, Bc, w.tf.kc[0], w.tf.ent, w.tf.S[0], nact, map_cur, st);
                 if (rc) return rc;
                 if (prof) prof->end(CAT_STAGE0);

@@ -32,6 +32,85 @@ __device__ __forceinline__ float shfl_f(float v, int src) {
     return __int_as_float(__builtin_amdgcn_ds_bpermute(src << 2, __float_as_int(v)));
 }
 
+// ------------------------------------------------------------------- |x|^2
+// xx[b] = sumsq64(x[b]) (zero padded), once per encode call: the constant of E in table form.  One wave per vector.
+__global__ void __launch_bounds__(256)
+k_tf_xx(const float *__restrict__ x, long B, int D, int Dp, float *__restrict__ xx, int xh /* x is fp16 */) {
+    const long b = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int lane = lane_id();
+    const float *xb = x + b * D;
+    const _Float16 *xbh = reinterpret_cast<const _Float16 *>(x) + b * D;
+    const bool vec_ok = ((D & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & (xh ? 7 : 15)) == 0);
+    float pe = 0.f;
+    for (int q = lane; q < Dp / 4; q += 64) {
+        f32x4 xv;
+        if (vec_ok && 4 * q + 3 < D) {
+            xv = xh ? load_h4(xbh + 4 * q) : *reinterpret_cast<const f32x4 *>(xb + 4 * q);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int kc = (4 * q + c < D) ? 4 * q + c : 0;
+                const float val = xh ? (float)xbh[kc] : xb[kc];
+                xv[c] = (4 * q + c < D) ? val : 0.f;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) pe = fmaf(xv[c], xv[c], pe);
+    }
+    pe = wave_sum_butterfly(pe);
+    if (lane == 0) xx[b] = pe;
+}
+
+// --------------------------------------------------------------------- E, R
+// One wave per vector: E = |x_err|^2 and R[n] = |x_err - old_n|^2 (:401-409) from N*N Gram entries, N entries of XC
+// and |x|^2 (oracle "TABLE FORM", E, R).  Its reads go all over G, which is why it is not part of k_tf_stage0 (whose
+// XCD-local L2 footprint they would break: tried, stage 0 went from 0.31 to 0.62 ms); 260 bytes per vector here.
+template <int N>
+__global__ void __launch_bounds__(256)
+k_tf_er(const float *__restrict__ G, const float *__restrict__ XC, const uint8_t *__restrict__ idx,
+        const float *__restrict__ xx, long B, int K, float *__restrict__ E_out, float *__restrict__ R_out,
+        const int *__restrict__ nact, const int *__restrict__ map) {
+    constexpr int NT = (N * N + 63) / 64;          // Gram terms per lane
+    if (nact) B = *nact;
+    const long b = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int lane = lane_id();
+    const int NK = N * K;
+    const uint8_t *id = idx + b * N;
+    const long bx = map ? (long)map[b] : b;          // row of the per-call arrays (XC, xx)
+    // term t = m * N + m2 (lane t % 64, slot t / 64) is G[o_m][o_m2]
+    float gt[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int t = lane + 64 * j;
+        const int tc = t < N * N ? t : 0;
+        const float g = G[(size_t)((tc / N) * K + id[tc / N]) * NK + (tc % N) * K + id[tc % N]];
+        gt[j] = t < N * N ? g : 0.f;
+    }
+    const int lm = lane < N ? lane : 0;
+    const float xt = lane < N ? XC[(size_t)bx * NK + lm * K + id[lm]] : 0.f;        // XC[o_m] in lane m
+    const float xxb = xx[bx];
+    float gp = gt[0];
+#pragma unroll
+    for (int j = 1; j < NT; ++j) gp = gp + gt[j];
+    const float gsum = wave_sum_butterfly(gp), xsum = wave_sum_butterfly(xt);
+    const float E = (gsum - 2.0f * xsum) + xxb;
+    // lane n < N: R[n] from column n of the N x N block, m ascending
+    const int n = lane < N ? lane : 0;
+    float col = 0.f, gnn = 0.f;
+#pragma unroll
+    for (int m = 0; m < N; ++m) {
+        const float v = shfl_f(gt[(m * N) / 64], (m * N + n) & 63);   // term m * N + n: its slot is a compile-time function of m
+        col = (m == 0) ? v : col + v;
+        if (m == n) gnn = v;
+    }
+    const float xo = col - xt;
+    const float Rv = (E - 2.0f * xo) + gnn;
+    if (lane < N) R_out[b * N + lane] = Rv;
+    if (lane == 0) E_out[b] = E;
+}
+
 // ------------------------------------------------------------------ stage 0
 // One wave per (vector, codebook n): the K scores of :418 from N - 1 row segments of G, the vector's XC segment and
 // Q, then the first sort-and-truncate (:470-503).  Workgroup id mod N = n: an XCD's L2 holds G[:, segment n] only.
