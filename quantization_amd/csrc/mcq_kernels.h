@@ -111,7 +111,7 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 load_h4(const void *p) {
     return __builtin_convertvector(*reinterpret_cast<const f16x4 *>(p), f32x4);
 }
-constexpr int kSelectLdsU64 = 128;  // per-wave LDS scratch of wave_select_fast, in u64
+constexpr int kSelectLdsU64 = 208;  // per-wave LDS scratch of wave_select_fast, in u64 (136 survivors + 64 results)
 
 __device__ __forceinline__ uint32_t ord32(float v) {
     const uint32_t b = __float_as_uint(v);
@@ -196,6 +196,61 @@ __device__ __forceinline__ void wave_select_fast(const float (&v)[VPL], const in
         out_p = M - 1;
         if (lane < cnt) {
             const u64 o = ldsB[lane];
+            out_p = (int)(uint32_t)o;
+            out_v = unord32((uint32_t)(o >> 32));
+        }
+        wave_lds_fence();
+        return;
+    }
+    if (VPL > 1 && cnt * VPL <= 128 && cnt <= 64) {
+        // Two-level variant with up to two survivors per lane (32 of 256 with four keys per lane): T0 as above bounds
+        // the answer, at most cnt lanes hold keys <= T0, so at most cnt * VPL <= 128 keys survive; lane l ranks the
+        // survivors l and l + 64 against all of them.
+        u64 lmin = key[0];
+#pragma unroll
+        for (int i = 1; i < VPL; ++i) lmin = key[i] < lmin ? key[i] : lmin;
+        u64 cm = __ballot(lmin != kKeyMax);
+        u64 T0 = kKeyMax;
+        while (cm != 0) {
+            const int pl = __ffsll((long long)cm) - 1;
+            const u64 kp = readlane_u64(lmin, pl);
+            const u64 ltm = __ballot(lmin < kp);
+            const int rr = __popcll(ltm);
+            if (rr == target) { T0 = kp; break; }
+            cm &= (rr > target) ? ltm : ~(ltm | (1ull << pl));
+        }
+        u64 *ldsS = lds, *ldsO = lds + 144;        // survivors [0, 136), results [144, 208)
+        int base = 0;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const bool sel = key[i] <= T0;
+            const u64 m = __ballot(sel);
+            const int dst = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+            if (sel && dst < 128) ldsS[dst] = key[i];
+            base += __popcll(m);
+        }
+        const int c0 = base < 128 ? base : 128;
+        if (lane < 8) ldsS[c0 + lane] = kKeyMax;                       // sentinel tail
+        wave_lds_fence();
+        const u64 ka = (lane < c0) ? ldsS[lane] : kKeyMax;
+        const u64 kb = (lane + 64 < c0) ? ldsS[lane + 64] : kKeyMax;
+        int ra = 0, rb = 0;
+        const int c8 = (c0 + 7) & ~7;
+        for (int j = 0; j < c8; j += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const u64 o = ldsS[j + u];
+                ra += (o < ka) ? 1 : 0;
+                rb += (o < kb) ? 1 : 0;
+            }
+        }
+        if (lane < c0 && ra < cnt) ldsO[ra] = ka;
+        if (lane + 64 < c0 && rb < cnt) ldsO[rb] = kb;
+        wave_lds_fence();
+        out_v = INFINITY;
+        out_p = M - 1;
+        if (lane < cnt) {
+            const u64 o = ldsO[lane];
             out_p = (int)(uint32_t)o;
             out_v = unord32((uint32_t)(o >> 32));
         }
