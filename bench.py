@@ -57,38 +57,27 @@ def reference_flops_per_vector(D, N, K, iters):
 
 def kernel_work(B, D, N, K):
     """Per launch of each kernel category of mcq_profile_encode (in its order): (name, launches per encode as
-    'once' | 'pass', algorithmic FLOPs, algorithmic bytes).  Table form (2 <= N <= 16): the two GEMMs are the only
-    MFMA work; the table kernels read 4-byte Gram entries (bytes = entries read x 4 + lists and tables written)."""
+    'once' | 'pass', algorithmic FLOPs, algorithmic bytes).  The two GEMMs are the only MFMA work; the table kernels
+    read 4-byte Gram entries (bytes = entries read x 4 + lists and tables written)."""
     gemm = 2.0 * D * N * K * B
-    kc = [k_cutoff(K, 1 << v) for v in range(4)]
-    if 2 <= N <= 16:
-        leaf = (kc[0] * kc[0] + 2 * kc[0] + 1) * 4.0           # one leaf table's Gram reads
-        cats = [("logits_gemm_argmax", "once", gemm, 0.0),
-                ("x_sumsq", "once", 0.0, B * D * 4.0),
-                ("stage0_tables", "pass", 0.0, B * N * ((N + 1) * K * 4.0 + kc[0] * 5.0)),
-                ("xc_gemm", "once", gemm, 0.0),
-                ("combine_level0", "pass", 0.0, B * (N / 2) * (leaf + kc[1] * 6.0))]
-        if N >= 4:
-            cats.append(("combine_level1", "pass", 0.0, B * (N / 4) * (4 * leaf + kc[2] * 6.0)))
-        if N >= 8:
-            cats.append(("tables_level1", "pass", 0.0, B * 4 * (N / 8) * (4 * leaf + kc[1] * kc[1] * 4.0)))
-            cats.append(("combine_level2", "pass", 0.0, B * (N / 8) * (4 * kc[1] * kc[1] * 4.0 + kc[3] * 6.0)))
-        if N >= 16:
-            cats.append(("tables_level1_quads", "pass", 0.0, B * 16 * (4 * leaf + kc[1] * kc[1] * 4.0)))
-            cats.append(("combine_level3", "pass", 0.0, B * 16 * kc[1] * kc[1] * 4.0))
-        while len(cats) < 10:
-            cats.append((f"unused_{len(cats)}", "pass", 0.0, 0.0))
-        cats.append(("residual_energies", "pass", 0.0, B * (N * N + 2 * N + 2) * 4.0))     # category 10: E, R from the tables
-        return cats
-    cats = [("logits_gemm_argmax", "once", gemm, 0.0), ("residual", "pass", 0.0, B * (N + 2) * D * 4.0),
-            ("stage0_gemm", "pass", gemm, 0.0), ("prune0", "pass", 0.0, 0.0)]
-    G, L, KI = N, 1, (1 if N == 1 else k_cutoff(K, 1))
-    while G > 1:
-        Gout = G // 2
-        cats.append((f"pair_L{L}_K{KI}", "pass", Gout * KI * KI * 2.0 * D * B, 0.0))
-        KI = 1 if Gout == 1 else k_cutoff(K, 2 * L)
-        G, L = Gout, 2 * L
-    return cats
+    kc = [k_cutoff(K, 1 << v) for v in range(6)]
+    leaf = (kc[0] * kc[0] + 2 * kc[0] + 1) * 4.0           # one leaf table's Gram reads
+    cats = [("logits_gemm_argmax", "once", gemm, 0.0),
+            ("x_sumsq", "once", 0.0, B * D * 4.0),
+            ("stage0_tables", "pass", 0.0, B * N * ((N + 1) * K * 4.0 + kc[0] * 5.0)),
+            ("xc_gemm", "once", gemm, 0.0),
+            ("combine_level0", "pass", 0.0, B * (N / 2) * (leaf + kc[1] * 6.0)),
+            ("combine_level1", "pass", 0.0, B * (N / 4) * (4 * leaf + kc[2] * 6.0)),
+            ("tables_level1", "pass", 0.0, B * 4 * (N / 8) * (4 * leaf + kc[1] * kc[1] * 4.0)),
+            ("combine_level2", "pass", 0.0, B * (N / 8) * (4 * kc[1] * kc[1] * 4.0 + kc[3] * 6.0)),
+            ("tables_upper_levels", "pass", 0.0, B * max(N // 16, 0) * 16 * (4 * leaf + kc[1] * kc[1] * 4.0)),
+            ("combine_upper_levels", "pass", 0.0, B * max(N // 16, 0) * 16 * kc[1] * kc[1] * 4.0),
+            ("residual_energies", "pass", 0.0, B * (N * N + 2 * N + 2) * 4.0)]       # E, R from the tables
+    present = 5 if N >= 2 else 4
+    present = 6 if N >= 4 else present
+    present = 8 if N >= 8 else present
+    present = 10 if N >= 16 else present
+    return [c if (i < present or i == 10) else ("unused_%d" % i, "pass", 0.0, 0.0) for i, c in enumerate(cats)]
 
 
 def load_quantizer(state, D, K, N, dev):
@@ -346,7 +335,7 @@ def main():
                             "priced against the HBM peak as the contract asks"}
 
     fpv = reference_flops_per_vector(D, N, K, iters)
-    exec_fpv = 2 * 2.0 * D * N * K if 2 <= N <= 16 else fpv     # table form: the logits and x.C GEMMs only
+    exec_fpv = 2 * 2.0 * D * N * K          # the logits and x.C GEMMs only
     value = world * B * args.steps / dt
     out = {
         "metric": "vectors encoded/sec at dim=512, 8 codebooks; uint8 codes bit-exact vs ref",

@@ -26,9 +26,9 @@
  *    (quantization/quantization.py:506) and needs K <= 256 for byte output (:271).
  *
  * Numerics: bit-identical to oracle/mcq_oracle.c (see its header for the spec:
- * v_mfma_f32_16x16x4_f32 k-order fmaf chains, wave64 butterfly reductions; for
- * 2 <= N <= 16 the TABLE FORM: the search's inner products are read from the Gram
- * matrix of the centers kept in `prepared` and from one x.C GEMM per call).
+ * v_mfma_f32_16x16x4_f32 k-order fmaf chains, wave64 butterfly reductions; the
+ * refinement passes read their inner products from the Gram matrix of the centers
+ * kept in `prepared` and from one x.C GEMM per call: the TABLE FORM).
  */
 #ifndef MCQ_H
 #define MCQ_H
@@ -55,8 +55,8 @@ int mcq_padded_dim(int D);
  * on every call there) and the parameter reads of Quantizer._logits (:277-279).
  * `prepared` receives: scaled centers C[N][K][Dp] = cscale_exp * centers, their
  * sum of squares Q[N][K] (:411), to_logits.weight padded to Dp and the bias, and -- when
- * weight is given and 2 <= N <= 16 -- the Gram matrix G[N*K][N*K] of the scaled centers
- * (16 MB at 8 x 256; what the table form of the search reads).
+ * weight is given -- the Gram matrix G[N*K][N*K] of the scaled centers (16 MB at 8 x 256;
+ * what the refinement passes read).
  * cscale_exp / lscale_exp = exp(10*centers_scale) / exp(10*logits_scale), formed
  * by the caller in fp32 exactly as the reference does (:78, :278).
  * weight/bias may be NULL when only decode is needed.                          */

@@ -29,25 +29,21 @@
  *   sumsq64 = 64 partial fmaf chains, partial l over the float4 groups q with
  *             (q mod 64) == l in increasing q, then the xor butterfly
  *             p[l] += p[l^m] for m = 32,16,8,4,2,1 (a wave64 reduction).
- *   every other operation is a single IEEE fp32 add/sub/mul, in the order the
- *   reference writes it:  S = (R + Q) + 2X   (:418),
- *   S' = ((Se + So) - E) + 2*dot   (:533-535),  delta = c - old  (:436-439),
- *   delta' = delta_e + delta_o (:538-541), x_err = (old_0 + old_1 + ...) - x.
  *   selections are by (value, position) ascending, lowest position on ties.
  *
- * TABLE FORM (2 <= N <= 16; the direct form above stays for N == 1 and N >= 32).
- * The search's inner products are linear in codebook rows, so they are read from
- * tables instead of being recomputed per vector and pass (gate run:
- * tools/exp_gram/results_r02.txt -- same codes as the direct form on every fixture):
+ * TABLE FORM of the refinement pass.  The reference recomputes, per vector and pass, inner products that are
+ * linear in codebook rows (:403-416, :533-535); here they are READ from two tables (SURVEY.md section 7 "hard
+ * parts"; gate runs against every reference fixture: tools/exp_gram/results_r02.txt and
+ * DESIGN.md section 2 -- the codes equal those of a direct restatement, which round 1 shipped, on all 58,880 cases):
  *   G[r][c]  = dot16(C[r], C[c])        Gram matrix of all N*K scaled centers (per state)
  *   XC[b][r] = dot16(C[r], x[b])        one GEMM per encode call (x zero padded, unscaled)
- *   stage 0:  X[b,n,k] = (G[(m0,i_m0)][(n,k)] + G[(m1,i_m1)][(n,k)] + ...) - XC[b][(n,k)],
- *             m ascending over the codebooks m != n (x_rem = sum_{m != n} old_m - x), then
- *             S = (R + Q) + 2 X as before.
- *   E, R:     x_err = sum_m o_m - x (o_m the current rows), so with xx = sumsq64(x):
+ *   E, R:     x_err = sum_m o_m - x (o_m the current rows; :338-340), so with xx = sumsq64(x):
  *             E = (sum_{m,m'} G[o_m][o_m'] - 2 sum_m XC[b][o_m]) + xx      (both sums added as one wave adds them),
- *             R[n] = (E - 2 ((G[o_0][o_n] + ... + G[o_{N-1}][o_n]) - XC[b][o_n])) + G[o_n][o_n];
+ *             R[n] = (E - 2 ((G[o_0][o_n] + ... + G[o_{N-1}][o_n]) - XC[b][o_n])) + G[o_n][o_n]    (:401-409);
  *             they enter every score of a pass as additive constants only.
+ *   stage 0:  x_rem = sum_{m != n} o_m - x (:403), so
+ *             X[b,n,k] = (G[(m0,i_m0)][(n,k)] + G[(m1,i_m1)][(n,k)] + ...) - XC[b][(n,k)], m ascending over m != n
+ *             (N == 1: X = 0 - XC), then S = (R + Q) + 2 X   (:418).
  *   leaf tables (codebooks n < m, shortlist positions i, j; o_n = current entry of n):
  *             D[n][m][i][j] = ((G[s_n,i][s_m,j] - G[s_n,i][o_m]) - G[o_n][s_m,j]) + G[o_n][o_m]
  *             = delta_n[i] . delta_m[j]  with delta = c - old  (:436-439)
@@ -55,8 +51,8 @@
  *             candidates of its halves X0, X1, likewise j of Y; :538-541 distributes over the dot):
  *             T_l[X][Y][i][j] = ((T_h[X0][Y0][i0][j0] + T_h[X0][Y1][i0][j1]) + T_h[X1][Y0][i1][j0])
  *                               + T_h[X1][Y1][i1][j1],   h = l/2,  T_1 = D
- *   combine of the siblings X = 2g, Y = 2g+1:  S' = ((S_X[i] + S_Y[j]) - E) + 2 T_l[X][Y][i][j].
- * Every operation is a single IEEE fp32 add/sub in the order written.
+ *   combine of the siblings X = 2g, Y = 2g+1:  S' = ((S_X[i] + S_Y[j]) - E) + 2 T_l[X][Y][i][j]   (:533-535).
+ * Every operation is a single IEEE fp32 add/sub/mul in the order written.
  */
 #include <math.h>
 #include <stdint.h>
@@ -75,7 +71,6 @@ typedef struct {
     float *bias;   /* [N*K]                                               */
     float lscale;  /* exp(10*logits_scale), computed by the caller        */
     int *order16;  /* [Dp]                                                */
-    int table_form; /* 2 <= N <= 16: inner products from the Gram matrix  */
     float *G;      /* [N*K][N*K]   dot16(C[r], C[c]); built on first use  */
 } mcq_oracle;
 
@@ -102,7 +97,6 @@ mcq_oracle *mcq_oracle_create(const float *centers, float cscale_exp, const floa
     mcq_oracle *o = (mcq_oracle *)calloc(1, sizeof(mcq_oracle));
     int Dp = round_up16(D);
     o->N = N; o->K = K; o->D = D; o->Dp = Dp; o->lscale = lscale_exp;
-    o->table_form = (N >= 2 && N <= 16);
     o->order16 = (int *)malloc(sizeof(int) * Dp);
     for (int i = 0; i < Dp; i++) {
         int blk = i / 16, w = i % 16;
@@ -185,54 +179,25 @@ typedef struct {
 } mcq_trace;
 
 typedef struct {
-    float *old;    /* [N][Dp] */
-    float *xerr;   /* [Dp] */
-    float *xrem;   /* [Dp] */
-    float *S;      /* [N*K] or combine scores, max size */
-    float *S2;
-    float *dA;     /* delta buffers [groups][Dp][Kc] (transposed, chain order) */
-    float *dB;
-    uint8_t *tA;   /* tuples [groups][Kc][L] */
-    uint8_t *tB;
-    float *sA;     /* candidate scores [groups][Kc] */
-    float *sB;
+    float *xpad;   /* [Dp]  the zero-padded frame */
+    float *S;      /* stage-0 scores [N*K] or the scores of one combine, max size */
     int *pos;
-    size_t maxS;
 } scratch;
 
 static size_t max_sz(size_t a, size_t b) { return a > b ? a : b; }
 
 static void scratch_alloc(scratch *s, int N, int K, int Dp) {
-    /* largest candidate count per group after any prune, and largest combine */
-    size_t max_group_c = 0, maxS = (size_t)N * K;
-    int Ng = N, L = 1;
-    int kc = (N == 1) ? 1 : k_cutoff(K, L);
-    max_group_c = (size_t)Ng * kc;
-    while (Ng > 1) {
-        maxS = max_sz(maxS, (size_t)(Ng / 2) * kc * kc);
-        Ng /= 2; L *= 2;
-        kc = (Ng == 1) ? 1 : k_cutoff(K, L);
-        max_group_c = max_sz(max_group_c, (size_t)Ng * kc);
+    size_t maxS = (size_t)N * K;
+    for (int v = 0; (1 << v) < N; v++) {
+        const size_t kc = (size_t)k_cutoff(K, 1 << v);
+        maxS = max_sz(maxS, (size_t)(N >> (v + 1)) * kc * kc);
     }
-    s->maxS = maxS;
-    s->old = (float *)malloc(sizeof(float) * N * Dp);
-    s->xerr = (float *)malloc(sizeof(float) * Dp);
-    s->xrem = (float *)malloc(sizeof(float) * Dp);
+    s->xpad = (float *)malloc(sizeof(float) * Dp);
     s->S = (float *)malloc(sizeof(float) * maxS);
-    s->S2 = (float *)malloc(sizeof(float) * maxS);
-    s->dA = (float *)malloc(sizeof(float) * max_group_c * Dp);
-    s->dB = (float *)malloc(sizeof(float) * max_group_c * Dp);
-    s->tA = (uint8_t *)malloc(max_group_c * N);
-    s->tB = (uint8_t *)malloc(max_group_c * N);
-    s->sA = (float *)malloc(sizeof(float) * max_group_c);
-    s->sB = (float *)malloc(sizeof(float) * max_group_c);
-    s->pos = (int *)malloc(sizeof(int) * max_group_c);
+    s->pos = (int *)malloc(sizeof(int) * 256);
 }
 
-static void scratch_free(scratch *s) {
-    free(s->old); free(s->xerr); free(s->xrem); free(s->S); free(s->S2); free(s->dA); free(s->dB);
-    free(s->tA); free(s->tB); free(s->sA); free(s->sB); free(s->pos);
-}
+static void scratch_free(scratch *s) { free(s->xpad); free(s->S); free(s->pos); }
 
 /* A.1: initial indexes from the logits (:297-301) */
 static void init_indexes(const mcq_oracle *o, const float *x, uint8_t *idx, float *acc /*[N*K]*/,
@@ -255,114 +220,6 @@ static void init_indexes(const mcq_oracle *o, const float *x, uint8_t *idx, floa
         idx[n] = (uint8_t)best;
     }
 }
-
-/* A.2: one _refine_indexes pass for one vector (:308-547); idx updated in place */
-static void refine_one(const mcq_oracle *o, const float *x, uint8_t *idx, scratch *s, mcq_trace *tr) {
-    const int N = o->N, K = o->K, D = o->D, Dp = o->Dp;
-    /* old centers, x_err, E  (:338-340, :401) */
-    for (int n = 0; n < N; n++)
-        memcpy(s->old + (size_t)n * Dp, o->C + ((size_t)n * K + idx[n]) * Dp, sizeof(float) * Dp);
-    for (int d = 0; d < Dp; d++) {
-        float t = s->old[d];
-        for (int n = 1; n < N; n++) t = t + s->old[(size_t)n * Dp + d];
-        s->xerr[d] = t - ((d < D) ? x[d] : 0.0f);
-    }
-    const float E = sumsq64(s->xerr, Dp);
-    if (tr && tr->xerr) memcpy(tr->xerr, s->xerr, sizeof(float) * Dp);
-    if (tr && tr->E) tr->E[0] = E;
-
-    /* stage 0 scores S[n][k] = (R + Q) + 2 X   (:403-418) */
-    for (int n = 0; n < N; n++) {
-        const float *old = s->old + (size_t)n * Dp;
-        for (int d = 0; d < Dp; d++) s->xrem[d] = s->xerr[d] - old[d];
-        const float R = sumsq64(s->xrem, Dp);
-        if (tr && tr->R) tr->R[n] = R;
-        float *acc = s->S + (size_t)n * K;
-        for (int k = 0; k < K; k++) acc[k] = 0.0f;
-        for (int i = 0; i < Dp; i++) {
-            float xv = s->xrem[o->order16[i]];
-            const float *row = o->CT + ((size_t)n * Dp + i) * K;
-            for (int k = 0; k < K; k++) acc[k] = fmaf(row[k], xv, acc[k]);
-        }
-        const float *Q = o->Q + (size_t)n * K;
-        for (int k = 0; k < K; k++) acc[k] = (R + Q[k]) + 2.0f * acc[k];
-    }
-    if (tr && tr->S0) memcpy(tr->S0, s->S, sizeof(float) * N * K);
-
-    int Ng = N, Kg = K, L = 1;
-    int tr_sel = 0, tr_comb = 0;
-    /* first prune: K -> Kc (or 1 if N == 1); deltas = c - old (:436-439, :470-503) */
-    int kc = (Ng == 1) ? 1 : k_cutoff(K, L);
-    float *dcur = s->dA, *dnext = s->dB;
-    uint8_t *tcur = s->tA, *tnext = s->tB;
-    float *scur = s->sA, *snext = s->sB;
-    for (int n = 0; n < N; n++) {
-        select_smallest(s->S + (size_t)n * K, K, kc, s->pos, scur + (size_t)n * kc);
-        const float *old = s->old + (size_t)n * Dp;
-        float *dg = dcur + (size_t)n * kc * Dp;
-        for (int j = 0; j < kc; j++) {
-            int k = s->pos[j];
-            tcur[((size_t)n * kc + j)] = (uint8_t)k;
-            const float *c = o->C + ((size_t)n * K + k) * Dp;
-            for (int i = 0; i < Dp; i++) {
-                int d = o->order16[i];
-                dg[(size_t)i * kc + j] = c[d] - old[d];
-            }
-            if (tr && tr->sel_pos) { tr->sel_pos[tr_sel] = k; tr->sel_val[tr_sel] = scur[(size_t)n * kc + j]; tr_sel++; }
-        }
-    }
-    Kg = kc;
-    while (Ng > 1) {
-        /* combine pairs of groups (:504-547) */
-        int newN = Ng / 2, M = Kg * Kg, newL = 2 * L;
-        for (int g = 0; g < newN; g++) {
-            const float *de = dcur + (size_t)(2 * g) * Kg * Dp;
-            const float *dod = dcur + (size_t)(2 * g + 1) * Kg * Dp;
-            float *acc = s->S + (size_t)g * M;
-            for (int p = 0; p < M; p++) acc[p] = 0.0f;
-            for (int i = 0; i < Dp; i++) {
-                const float *ea = de + (size_t)i * Kg, *ob = dod + (size_t)i * Kg;
-                for (int a = 0; a < Kg; a++) {
-                    float av = ea[a];
-                    float *row = acc + (size_t)a * Kg;
-                    for (int b = 0; b < Kg; b++) row[b] = fmaf(av, ob[b], row[b]);
-                }
-            }
-            const float *se = scur + (size_t)(2 * g) * Kg, *so = scur + (size_t)(2 * g + 1) * Kg;
-            for (int a = 0; a < Kg; a++)
-                for (int b = 0; b < Kg; b++) {
-                    float *v = acc + (size_t)a * Kg + b;
-                    *v = ((se[a] + so[b]) - E) + 2.0f * (*v);  /* (:533-535) */
-                }
-            if (tr && tr->comb) { memcpy(tr->comb + tr_comb, acc, sizeof(float) * M); tr_comb += M; }
-        }
-        /* prune to the next cutoff (or to 1 when one group is left) (:470-503) */
-        int newK = (newN == 1) ? 1 : k_cutoff(K, newL);
-        for (int g = 0; g < newN; g++) {
-            select_smallest(s->S + (size_t)g * M, M, newK, s->pos, snext + (size_t)g * newK);
-            const float *de = dcur + (size_t)(2 * g) * Kg * Dp;
-            const float *dod = dcur + (size_t)(2 * g + 1) * Kg * Dp;
-            float *dn = dnext + (size_t)g * newK * Dp;
-            for (int j = 0; j < newK; j++) {
-                int a = s->pos[j] / Kg, b = s->pos[j] % Kg;
-                uint8_t *tn = tnext + ((size_t)g * newK + j) * newL;
-                memcpy(tn, tcur + ((size_t)(2 * g) * Kg + a) * L, L);
-                memcpy(tn + L, tcur + ((size_t)(2 * g + 1) * Kg + b) * L, L);
-                if (newN > 1)
-                    for (int i = 0; i < Dp; i++)  /* (:538-541) */
-                        dn[(size_t)i * newK + j] = de[(size_t)i * Kg + a] + dod[(size_t)i * Kg + b];
-                if (tr && tr->sel_pos) { tr->sel_pos[tr_sel] = s->pos[j]; tr->sel_val[tr_sel] = snext[(size_t)g * newK + j]; tr_sel++; }
-            }
-        }
-        float *tf = dcur; dcur = dnext; dnext = tf;
-        uint8_t *tt = tcur; tcur = tnext; tnext = tt;
-        float *ts = scur; scur = snext; snext = ts;
-        Ng = newN; Kg = newK; L = newL;
-    }
-    /* Ng == 1, Kg == 1: the tuple is the new index vector (:468-469) */
-    memcpy(idx, tcur, N);
-}
-
 
 /* ---------------------------------------------------------------- table form */
 /* G[r][c] = dot16(C[r], C[c]) for all pairs of rows.  fmaf(a, b, acc) is symmetric in a, b, so
@@ -390,7 +247,7 @@ static void build_gram(mcq_oracle *o) {
 }
 
 static void ensure_gram(const mcq_oracle *o) {
-    if (o->table_form && !o->G) build_gram((mcq_oracle *)o);
+    if (!o->G) build_gram((mcq_oracle *)o);
 }
 
 /* sum of n (<= 256) terms the way one wave adds them: lane l takes the terms l, l + 64, ... in order (absent
@@ -423,7 +280,7 @@ static void compute_xc(const mcq_oracle *o, const float *x, float *xc) {
         }
 }
 
-#define MCQ_MAX_LEVELS 5   /* candidates of 1, 2, 4, 8, 16 codebooks (N <= 16) */
+#define MCQ_MAX_LEVELS 7   /* candidates of 1, 2, 4, ..., 64 codebooks */
 typedef struct {
     int kc[MCQ_MAX_LEVELS];                 /* list length per level                             */
     uint8_t *ent1;                          /* [N][kc[0]] codebook entries of the level-0 lists  */
@@ -469,7 +326,7 @@ static void tf_table(const mcq_oracle *o, const uint8_t *idx, const tf_lists *L,
     free(t);
 }
 
-/* one _refine_indexes pass for one vector in table form; xc = compute_xc(x); idx updated in place */
+/* one _refine_indexes pass for one vector (:308-547); xc = compute_xc(x); idx updated in place */
 static void refine_one_table(const mcq_oracle *o, const float *x, const float *xc, uint8_t *idx, scratch *s,
                              mcq_trace *tr) {
     const int N = o->N, K = o->K, D = o->D, Dp = o->Dp;
@@ -478,9 +335,9 @@ static void refine_one_table(const mcq_oracle *o, const float *x, const float *x
      *   x_err = sum_m o_m - x   =>   E = sum_{m,m'} G[o_m][o_m'] - 2 sum_m XC[o_m] + |x|^2,
      *   x_err . o_n = sum_m G[o_m][o_n] - XC[o_n]   =>   R[n] = (E - 2 (x_err . o_n)) + G[o_n][o_n].
      * They only enter the scores as additive constants of the pass.  xx = sumsq64(x) (zero padded). */
-    float gterm[256], xterm[16], xx;
+    float gterm[64 * 64], xterm[64], xx;
     {
-        float *xp = s->xrem;                       /* scratch: the padded x */
+        float *xp = s->xpad;
         for (int d = 0; d < Dp; d++) xp[d] = (d < D) ? x[d] : 0.0f;
         xx = sumsq64(xp, Dp);
     }
@@ -524,6 +381,13 @@ static void refine_one_table(const mcq_oracle *o, const float *x, const float *x
     }
     if (tr && tr->S0) memcpy(tr->S0, s->S, sizeof(float) * N * K);
 
+    if (N == 1) {                                   /* one codebook: the best entry is the result (:468-469) */
+        float v1;
+        select_smallest(s->S, K, 1, s->pos, &v1);
+        if (tr && tr->sel_pos) { tr->sel_pos[0] = s->pos[0]; tr->sel_val[0] = v1; }
+        idx[0] = (uint8_t)s->pos[0];
+        return;
+    }
     int nlev = 0;
     while ((1 << nlev) < N) nlev++;                 /* levels 0 .. nlev-1 hold lists; level nlev is the result */
     tf_lists L;
@@ -592,10 +456,8 @@ static void refine_one_table(const mcq_oracle *o, const float *x, const float *x
     for (int v = 0; v < nlev; v++) { free(L.S[v]); free(L.pos[v]); }
 }
 
-/* one pass in whichever form the state uses; xc may be NULL for the direct form */
 static void refine_any(const mcq_oracle *o, const float *x, const float *xc, uint8_t *idx, scratch *s, mcq_trace *tr) {
-    if (o->table_form) refine_one_table(o, x, xc, idx, s, tr);
-    else refine_one(o, x, idx, s, tr);
+    refine_one_table(o, x, xc, idx, s, tr);
 }
 
 /* _compute_indexes for a batch (:281-305).  idx: uint8 [B][N]. */
@@ -620,7 +482,7 @@ int mcq_oracle_compute_indexes(const mcq_oracle *o, const float *x, long B, int 
         for (long b = 0; b < B; b++) {
             uint8_t *id = idx + (size_t)b * N;
             init_indexes(o, x + (size_t)b * D, id, acc, sx);
-            if (o->table_form && iters > 0) compute_xc(o, x + (size_t)b * D, xc);
+            if (iters > 0) compute_xc(o, x + (size_t)b * D, xc);
             for (int it = 0; it < iters; it++) refine_any(o, x + (size_t)b * D, xc, id, &s, NULL);
         }
         free(acc); free(sx); free(xc); scratch_free(&s);
@@ -644,7 +506,7 @@ int mcq_oracle_refine(const mcq_oracle *o, const float *x, long B, int iters, ui
         float *xc = (float *)malloc(sizeof(float) * N * K);
 #pragma omp for schedule(dynamic, 8)
         for (long b = 0; b < B; b++) {
-            if (o->table_form && iters > 0) compute_xc(o, x + (size_t)b * D, xc);
+            if (iters > 0) compute_xc(o, x + (size_t)b * D, xc);
             for (int it = 0; it < iters; it++) refine_any(o, x + (size_t)b * D, xc, idx + (size_t)b * N, &s, NULL);
         }
         free(xc); scratch_free(&s);
@@ -659,7 +521,7 @@ int mcq_oracle_refine_trace(const mcq_oracle *o, const float *x, uint8_t *idx, f
     mcq_trace tr = {xerr, E, R, S0, sel_pos, sel_val, comb};
     float *xc = (float *)malloc(sizeof(float) * o->N * o->K);
     ensure_gram(o);
-    if (o->table_form) compute_xc(o, x, xc);
+    compute_xc(o, x, xc);
     refine_any(o, x, xc, idx, &s, &tr);
     free(xc);
     scratch_free(&s);

@@ -32,9 +32,6 @@ struct PreparedLayout {
     size_t offC, offQ, offW, offBias, offScales, offG, total;
 };
 
-// table form of the refinement (mcq_tf_kernels.h; oracle/mcq_oracle.c "TABLE FORM"): 2 <= N <= 16
-inline bool table_form(int N) { return N >= 2 && N <= 16; }
-
 PreparedLayout prepared_layout(int N, int K, int D) {
     const size_t nk = (size_t)N * K, Dp = round_up16(D);
     PreparedLayout l;
@@ -43,8 +40,8 @@ PreparedLayout prepared_layout(int N, int K, int D) {
     l.offW = align256(l.offQ + nk * 4);
     l.offBias = align256(l.offW + nk * Dp * 4);
     l.offScales = align256(l.offBias + nk * 4);   // float[2] {cscale_exp, lscale_exp} (mcq_prepare_dev)
-    l.offG = align256(l.offScales + 8);           // Gram matrix G[nk][nk] of the scaled centers (table form only)
-    l.total = align256(l.offG + (table_form(N) ? nk * nk * 4 : 0));
+    l.offG = align256(l.offScales + 8);           // Gram matrix G[nk][nk] of the scaled centers
+    l.total = align256(l.offG + nk * nk * 4);
     return l;
 }
 
@@ -59,40 +56,45 @@ Prepared prepared_view(const void *p, int N, int K, int D) {
 struct Workspace {
     uint8_t *idx, *idxB, *idxC, *final_idx;   // B, C, final: fixed-point skipping only
     int *map[2], *cnt;
-    float *xerr, *E, *R, *S0;
-    // table form: x.C products, the lists of every level, the level-1 tables of cousin groups
-    float *XC, *tabs, *xx;
-    TfLists tf;
-    uint8_t *tup[3];   // three-way rotation: a DEDUP pair stage also reads the lists of two stages back
-    uint8_t *pos;      // (a, b) of every candidate kept by the stage before a DEDUP stage
-    float *S[2];
+    float *E, *R, *xx, *XC;                   // per vector: |x_err|^2, |x_err - old_n|^2, |x|^2, x.C products
+    float *tabs[2];                           // group tables of two consecutive levels (ping-pong)
+    TfLists tf;                               // candidate lists of every level
 };
 
-// the first selection is fused into the stage-0 GEMM (no S0 buffer) for K >= 32 and N >= 2, unless a
-// tuning hook selects the 4-wave GEMM
-bool fused_select(int N, int K) {
-    static const bool off = getenv("MCQ_GEMM4") != nullptr || getenv("MCQ_NO_FUSED_SELECT") != nullptr;
-    return !off && K >= 32 && N >= 2;
-}
+int tf_levels(int N) { int v = 0; while ((1 << v) < N) ++v; return v; }   // lists exist at levels 0 .. tf_levels(N) - 1
 
-int tf_ntab(int N) { return N >= 16 ? 16 : (N >= 8 ? 4 : 0); }
-
-size_t workspace_per_vector(int N, int K, int Dp) {
-    if (table_form(N)) {
-        // idx x4, maps, xerr, E, R, XC, lists (entries / positions / scores: <= 16 + 4*16 B per codebook and level), tabs
-        const int kc1 = k_cutoff(K, 2);
-        (void)Dp;
-        return 4 * (size_t)N + 8 + 8 + 4 * (size_t)N + 4 * (size_t)N * K + kTfLevels * (size_t)N * (16 + 2 * 16 + 4 * 16) +
-               (size_t)tf_ntab(N) * kc1 * kc1 * 4;
+// floats of the largest set of group tables any combine needs at one level (per vector)
+size_t tf_tab_floats(int N, int K) {
+    const int nlev = tf_levels(N);
+    size_t best = 0;
+    for (int v = 2; v < nlev; ++v) {
+        const size_t groups = (size_t)N >> (v + 1);
+        for (int u = 1; u < v; ++u) {
+            const size_t per = (size_t)1 << (v - u), kc = k_cutoff(K, 1 << u);
+            const size_t f = groups * per * per * kc * kc;
+            best = f > best ? f : best;
+        }
     }
-    const size_t s0 = fused_select(N, K) ? 0 : 4 * (size_t)N * K;
-    return 4 * (size_t)N + 8 + 4 * (size_t)Dp + 4 + 4 * (size_t)N + s0 + 3 * 64 * (size_t)N + 16 * (size_t)N +
-           2 * 4 * 16 * (size_t)N;
+    return best;
 }
-constexpr size_t kWorkspaceSlack = 40 * 256;
-constexpr long kDefaultChunk = 65536;
 
-Workspace carve(void *ws, long Bc, int N, int K, int Dp) {
+size_t workspace_per_vector(int N, int K) {
+    // idx x4, maps, E, xx, R, XC, lists (entries / positions / scores: <= 16 + 2*16 + 4*16 bytes per codebook and level), tabs x2
+    return 4 * (size_t)N + 8 + 8 + 4 * (size_t)N + 4 * (size_t)N * K + (size_t)tf_levels(N) * N * (16 + 2 * 16 + 4 * 16) + 64 +
+           2 * 4 * tf_tab_floats(N, K);
+}
+constexpr size_t kWorkspaceSlack = 48 * 256;
+
+// default chunk: 65,536 vectors, fewer when a vector's share of the workspace is large (N >= 32), so that the workspace
+// mcq_encode_workspace_bytes asks for stays near 2 GB
+long default_chunk(int N, int K) {
+    long c = (long)(((size_t)2 << 30) / workspace_per_vector(N, K));
+    c = c > 65536 ? 65536 : c;
+    c = c < 1024 ? 1024 : c;
+    return c & ~63L;
+}
+
+Workspace carve(void *ws, long Bc, int N, int K) {
     char *p = static_cast<char *>(ws);
     size_t off = 0;
     auto take = [&](size_t bytes) { char *q = p + off; off = align256(off + bytes); return q; };
@@ -103,35 +105,24 @@ Workspace carve(void *ws, long Bc, int N, int K, int Dp) {
     w.final_idx = reinterpret_cast<uint8_t *>(take((size_t)Bc * N));
     for (int i = 0; i < 2; ++i) w.map[i] = reinterpret_cast<int *>(take((size_t)Bc * 4));
     w.cnt = reinterpret_cast<int *>(take(64 * 4));
-    w.xerr = table_form(N) ? nullptr : reinterpret_cast<float *>(take((size_t)Bc * Dp * 4));
     w.E = reinterpret_cast<float *>(take((size_t)Bc * 4));
     w.R = reinterpret_cast<float *>(take((size_t)Bc * N * 4));
-    if (table_form(N)) {
-        w.S0 = nullptr;
-        w.xx = reinterpret_cast<float *>(take((size_t)Bc * 4));
-        w.XC = reinterpret_cast<float *>(take((size_t)Bc * N * K * 4));
-        for (int v = 0; v < kTfLevels; ++v) {
-            const int kc = k_cutoff(K, 1 << v);
-            w.tf.kc[v] = kc;
-            w.tf.pos[v] = nullptr;
-            w.tf.S[v] = nullptr;
-            if ((N >> v) < 2) continue;                    // no list of that level
-            if (v == 0) w.tf.ent = reinterpret_cast<uint8_t *>(take((size_t)Bc * N * kc));
-            else w.tf.pos[v] = reinterpret_cast<uint8_t *>(take((size_t)Bc * (N >> v) * kc * 2));
-            w.tf.S[v] = reinterpret_cast<float *>(take((size_t)Bc * (N >> v) * kc * 4));
-        }
-        const int kc1 = k_cutoff(K, 2);
-        w.tabs = tf_ntab(N) ? reinterpret_cast<float *>(take((size_t)Bc * tf_ntab(N) * kc1 * kc1 * 4)) : nullptr;
-        for (int i = 0; i < 3; ++i) w.tup[i] = nullptr;
-        w.pos = nullptr;
-        w.S[0] = w.S[1] = nullptr;
-        return w;
+    w.xx = reinterpret_cast<float *>(take((size_t)Bc * 4));
+    w.XC = reinterpret_cast<float *>(take((size_t)Bc * N * K * 4));
+    const int nlev = tf_levels(N);
+    w.tf.ent = nullptr;
+    for (int v = 0; v < kTfLevels; ++v) {
+        w.tf.kc[v] = k_cutoff(K, 1 << v);
+        w.tf.pos[v] = nullptr;
+        w.tf.S[v] = nullptr;
+        if (v >= nlev) continue;                       // no list of that level
+        const int kc = w.tf.kc[v];
+        if (v == 0) w.tf.ent = reinterpret_cast<uint8_t *>(take((size_t)Bc * N * kc));
+        else w.tf.pos[v] = reinterpret_cast<uint8_t *>(take((size_t)Bc * (N >> v) * kc * 2));
+        w.tf.S[v] = reinterpret_cast<float *>(take((size_t)Bc * (N >> v) * kc * 4));
     }
-    w.XC = w.tabs = w.xx = nullptr;
-    w.S0 = fused_select(N, K) ? nullptr : reinterpret_cast<float *>(take((size_t)Bc * N * K * 4));
-    for (int i = 0; i < 3; ++i) w.tup[i] = reinterpret_cast<uint8_t *>(take((size_t)Bc * N * 64));
-    w.pos = reinterpret_cast<uint8_t *>(take((size_t)Bc * N * 16));
-    for (int i = 0; i < 2; ++i) w.S[i] = reinterpret_cast<float *>(take((size_t)Bc * N * 16 * 4));
+    const size_t tf = tf_tab_floats(N, K);
+    for (int i = 0; i < 2; ++i) w.tabs[i] = tf ? reinterpret_cast<float *>(take((size_t)Bc * tf * 4)) : nullptr;
     return w;
 }
 
@@ -170,34 +161,28 @@ thread_local int g_last_launches = 0;
         ++g_last_launches;                               \
     } while (0)
 
+// the two GEMMs of an encode (logits + argmax, x.C) and the Gram matrix of a state
 template <int MODE>
-int launch_gemm(int K, const float *Bm, const float *xin, const uint8_t *idx_in, float lscale, const float *bias,
-                const float *R, const float *Q, long B, int N, int D, int Dp, uint8_t *idx_out, float *out,
-                hipStream_t st, int keep = 0, const int *nact = nullptr, const float *lscale_ptr = nullptr,
-                int xh = 0) {
+int launch_gemm(int K, const float *Bm, const float *xin, float lscale, const float *bias, long B, int N, int D, int Dp,
+                uint8_t *idx_out, float *out, hipStream_t st, const float *lscale_ptr = nullptr, int xh = 0) {
     // default: k_gemm8s with 8 waves (64 vectors); tuning hooks: MCQ_GEMM_16W=1 -> 16 waves (128
     // vectors), MCQ_GEMM4=1 -> the 4-wave 32-float-stage kernel k_gemm (always used for K == 16)
     static const bool four_wave = getenv("MCQ_GEMM4") != nullptr;
     static const bool big_block = getenv("MCQ_GEMM_16W") != nullptr;
     const unsigned grid64 = (unsigned)(((B + 63) / 64) * N), grid128 = (unsigned)(((B + 127) / 128) * N);
-#define MCQ_GEMM_ARGS Bm, xin, idx_in, lscale, bias, R, Q, B, N, D, Dp, idx_out, out, keep, nact, lscale_ptr, xh
-    // the fused-selection epilogue needs 32 score rows of K + 4 floats plus the select scratch of every wave
-    auto lds8 = [&](int K_, int vec, int waves) {
-        size_t a = (size_t)2 * (K_ * 4 + vec * 4) * 16;
-        size_t b = (MODE == MODE_STAGE0_SEL) ? (size_t)32 * (K_ + 4) * 4 + (size_t)waves * kSelectLdsU64 * 8 : 0;
-        return a > b ? a : b;
-    };
+#define MCQ_GEMM_ARGS Bm, xin, lscale, bias, B, N, D, Dp, idx_out, out, lscale_ptr, xh
+    auto lds8 = [&](int K_, int vec) { return (size_t)2 * (K_ * 4 + vec * 4) * 16; };
 #define MCQ_GEMM_CASE(TT)                                                                                       \
     case 16 * TT:                                                                                               \
-        if (MODE != MODE_STAGE0_SEL && (four_wave || TT == 1))                                                  \
-            hipLaunchKernelGGL((k_gemm<TT, (MODE == MODE_STAGE0_SEL ? MODE_STAGE0 : MODE)>), dim3(grid64), dim3(256), \
-                               ((size_t)16 * TT * 8 + 64 * 8) * 16, st, MCQ_GEMM_ARGS);                         \
+        if (four_wave || TT == 1)                                                                               \
+            hipLaunchKernelGGL((k_gemm<TT, MODE>), dim3(grid64), dim3(256), ((size_t)16 * TT * 8 + 64 * 8) * 16, st, \
+                               MCQ_GEMM_ARGS);                                                                  \
         else if (big_block)                                                                                     \
-            hipLaunchKernelGGL((k_gemm8s<(TT > 1 ? TT : 2), MODE, 8>), dim3(grid128), dim3(1024),                \
-                               lds8(16 * TT, 128, 16), st, MCQ_GEMM_ARGS);                    \
+            hipLaunchKernelGGL((k_gemm8s<(TT > 1 ? TT : 2), MODE, 8>), dim3(grid128), dim3(1024), lds8(16 * TT, 128), st, \
+                               MCQ_GEMM_ARGS);                                                                  \
         else                                                                                                    \
-            hipLaunchKernelGGL((k_gemm8s<(TT > 1 ? TT : 2), MODE, 4>), dim3(grid64), dim3(512),                  \
-                               lds8(16 * TT, 64, 8), st, MCQ_GEMM_ARGS);                     \
+            hipLaunchKernelGGL((k_gemm8s<(TT > 1 ? TT : 2), MODE, 4>), dim3(grid64), dim3(512), lds8(16 * TT, 64), st, \
+                               MCQ_GEMM_ARGS);                                                                  \
         break;
     switch (K) {
         MCQ_GEMM_CASE(1)
@@ -213,219 +198,94 @@ int launch_gemm(int K, const float *Bm, const float *xin, const uint8_t *idx_in,
     return 0;
 }
 
-int launch_prune0(int K, const float *S0, long BN, int keep, uint8_t *tup, float *S, uint8_t *idx_final,
-                  hipStream_t st, const int *nact, int N) {
-    const unsigned grid = (unsigned)((BN + 3) / 4);
-    switch (K) {
-        case 16: hipLaunchKernelGGL((k_prune0<16>), dim3(grid), dim3(256), 4 * kSelectLdsU64 * 8, st, S0, BN, keep, tup, S, idx_final, nact, N); break;
-        case 32: hipLaunchKernelGGL((k_prune0<32>), dim3(grid), dim3(256), 4 * kSelectLdsU64 * 8, st, S0, BN, keep, tup, S, idx_final, nact, N); break;
-        case 64: hipLaunchKernelGGL((k_prune0<64>), dim3(grid), dim3(256), 4 * kSelectLdsU64 * 8, st, S0, BN, keep, tup, S, idx_final, nact, N); break;
-        case 128: hipLaunchKernelGGL((k_prune0<128>), dim3(grid), dim3(256), 4 * kSelectLdsU64 * 8, st, S0, BN, keep, tup, S, idx_final, nact, N); break;
-        case 256: hipLaunchKernelGGL((k_prune0<256>), dim3(grid), dim3(256), 4 * kSelectLdsU64 * 8, st, S0, BN, keep, tup, S, idx_final, nact, N); break;
-        default: return MCQ_EUNSUPPORTED;
-    }
-    MCQ_LAUNCH_CHECK();
-    return 0;
-}
-
-template <int L, int KI>
-int launch_pair_t(const float *C, const uint8_t *idx, const float *E, const uint8_t *tup_in, const float *S_in,
-                  long B, int N, int K, int Dp, int Gout, int keep, uint8_t *tup_out, float *S_out,
-                  uint8_t *idx_final, const int *nact, hipStream_t st, uint8_t *pos_out, const uint8_t *pos_in,
-                  const uint8_t *tup_prev) {
-    // each wave stages its 2L old rows in a private LDS window: whole rows while that stays <= 32 KB
-    // per wave (measured best), otherwise `win` floats at a time in windows of <= 16 KB
-    const size_t scratch = (size_t)kSelectLdsU64 * 8;
-    int win = Dp;
-    if ((size_t)2 * L * Dp * 4 > 32768 - scratch) {
-        const int limit = (int)(16384 / (8 * L));
-        const int lim64 = (limit / 64) * 64 > 64 ? (limit / 64) * 64 : 64;
-        const int nwin = (Dp + lim64 - 1) / lim64;
-        win = (((Dp + nwin - 1) / nwin) + 63) / 64 * 64;
-    }
-    if (const char *e = getenv("MCQ_PAIR_WIN")) { const int v = atoi(e); if (v >= 64 && L >= 4) win = v < Dp ? v : Dp; }   // tuning hook
-    // operands reach MFMA lane order through an LDS tile (ds_write_b128 + ds_read_b128) for single-leaf
-    // candidates, by ds_bpermute otherwise (measured: L=1 5 % faster, L=4 10 % slower with the tile);
-    // MCQ_PAIR_XL=0/1 forces one way (tuning hook)
-    static const int xl_env = getenv("MCQ_PAIR_XL") ? atoi(getenv("MCQ_PAIR_XL")) : -1;
-    const bool xl = xl_env >= 0 ? xl_env != 0 : (L == 1);
-    constexpr int TI = (KI + 15) / 16;
-    // DEDUP (32 x 32 four-leaf stage, when the previous stage left its (a, b) positions): MCQ_PAIR_DEDUP=0 disables it
-    static const bool dedup_ok = !(getenv("MCQ_PAIR_DEDUP") && atoi(getenv("MCQ_PAIR_DEDUP")) == 0);
-    const bool dedup = dedup_ok && L == 4 && KI == 32 && pos_in != nullptr && tup_prev != nullptr;
-    const size_t per_wave = (size_t)2 * L * win * 4 + scratch + ((xl || dedup) ? (size_t)2 * TI * 1024 : 0);
-    // one wave per workgroup: the waves share nothing (private LDS, no barrier), and single-wave
-    // workgroups measured fastest (finer-grained dispatch, LDS released per wave)
-    int wpb = 1;
-    if (const char *e = getenv("MCQ_PAIR_WPB")) {   // tuning hook
-        const int v = atoi(e);
-        if (v >= 1 && v <= 4 && per_wave * v <= 65536) wpb = v;
-    }
-    const unsigned grid = (unsigned)(((B + wpb - 1) / wpb) * Gout);
-#ifdef MCQ_ABLATE   // timing experiments with WRONG results: only in the separate library tools/pair_ablate.sh builds
-    static const int abl = getenv("MCQ_PAIR_ABL") ? atoi(getenv("MCQ_PAIR_ABL")) : 0;   // timing experiments (wrong results)
-#define MCQ_PAIR_ABL_CASE(A)                                                                                          \
-    if constexpr ((L == 1 && KI == 16) || (L == 2 && KI == 16) || (L == 4 && KI == 32)) /* headline ladder only */      \
-    if (abl == A) {                                                                                                   \
-        hipLaunchKernelGGL((k_pair<L, KI, false, A>), dim3(grid), dim3(64 * wpb), per_wave * wpb, st, C, idx, E, tup_in,  \
-                           S_in, B, N, K, Dp, Gout, keep, win, tup_out, S_out, idx_final, nact, nullptr, nullptr, nullptr); \
-        return 0;                                                                                                     \
-    }
-    MCQ_PAIR_ABL_CASE(1) MCQ_PAIR_ABL_CASE(2) MCQ_PAIR_ABL_CASE(3) MCQ_PAIR_ABL_CASE(4) MCQ_PAIR_ABL_CASE(5) MCQ_PAIR_ABL_CASE(6) MCQ_PAIR_ABL_CASE(7)
-#undef MCQ_PAIR_ABL_CASE
-#endif
-    if constexpr (L == 4 && KI == 32) {
-        if (dedup) {
-            hipLaunchKernelGGL((k_pair<L, KI, false, 0, true>), dim3(grid), dim3(64 * wpb), per_wave * wpb, st, C, idx, E, tup_in,
-                               S_in, B, N, K, Dp, Gout, keep, win, tup_out, S_out, idx_final, nact, pos_out, pos_in, tup_prev);
-            MCQ_LAUNCH_CHECK();
-            return 0;
-        }
-    }
-    if (xl)
-        hipLaunchKernelGGL((k_pair<L, KI, true>), dim3(grid), dim3(64 * wpb), per_wave * wpb, st, C, idx, E, tup_in, S_in, B,
-                           N, K, Dp, Gout, keep, win, tup_out, S_out, idx_final, nact, pos_out, nullptr, nullptr);
-    else
-        hipLaunchKernelGGL((k_pair<L, KI, false>), dim3(grid), dim3(64 * wpb), per_wave * wpb, st, C, idx, E, tup_in, S_in,
-                           B, N, K, Dp, Gout, keep, win, tup_out, S_out, idx_final, nact, pos_out, nullptr, nullptr);
-    MCQ_LAUNCH_CHECK();
-    return 0;
-}
-
-int launch_pair(int L, int KI, const float *C, const uint8_t *idx, const float *E, const uint8_t *tup_in,
-                const float *S_in, long B, int N, int K, int Dp, int Gout, int keep, uint8_t *tup_out, float *S_out,
-                uint8_t *idx_final, const int *nact, hipStream_t st, uint8_t *pos_out = nullptr,
-                const uint8_t *pos_in = nullptr, const uint8_t *tup_prev = nullptr) {
-#define MCQ_PAIR_CASE(LL, KK)                                                                                     \
-    if (L == LL && KI == KK)                                                                                      \
-        return launch_pair_t<LL, KK>(C, idx, E, tup_in, S_in, B, N, K, Dp, Gout, keep, tup_out, S_out, idx_final, nact, \
-                                     st, pos_out, pos_in, tup_prev);
-    // 8-candidate lists (16-entry codebooks): two output groups per wave (MCQ_PAIR8=0: the generic kernel; tuning hook)
-    static const bool pair8 = !(getenv("MCQ_PAIR8") && atoi(getenv("MCQ_PAIR8")) == 0);
-    if (pair8 && KI == 8 && (L == 1 || L == 2)) {
-        const unsigned grid = (unsigned)(B * ((Gout + 1) / 2));
-        if (L == 1)
-            hipLaunchKernelGGL((k_pair8<1>), dim3(grid), dim3(64), kSelectLdsU64 * 8, st, C, idx, E, tup_in, S_in, B, N, K, Dp,
-                               Gout, keep, tup_out, S_out, idx_final, nact);
-        else
-            hipLaunchKernelGGL((k_pair8<2>), dim3(grid), dim3(64), kSelectLdsU64 * 8, st, C, idx, E, tup_in, S_in, B, N, K, Dp,
-                               Gout, keep, tup_out, S_out, idx_final, nact);
-        MCQ_LAUNCH_CHECK();
-        return 0;
-    }
-    // K >= 32 ladders: 16,16,32,32,64 ; K == 16 ladders: 8,8,16,16,32,32
-    MCQ_PAIR_CASE(1, 16)
-    MCQ_PAIR_CASE(2, 16)
-    MCQ_PAIR_CASE(4, 32)
-    MCQ_PAIR_CASE(8, 32)
-    MCQ_PAIR_CASE(16, 64)
-    MCQ_PAIR_CASE(1, 8)
-    MCQ_PAIR_CASE(2, 8)
-    MCQ_PAIR_CASE(4, 16)
-    MCQ_PAIR_CASE(8, 16)
-    MCQ_PAIR_CASE(16, 32)
-    MCQ_PAIR_CASE(32, 32)
-#undef MCQ_PAIR_CASE
-    return MCQ_EUNSUPPORTED;
-}
-
-int launch_residual(const float *x, const uint8_t *idx, const float *C, long B, int N, int K, int D, int Dp,
-                    float *xerr, float *E, float *R, hipStream_t st, const int *nact, const int *map, int xh = 0) {
-    const dim3 grid((unsigned)((B + 3) / 4)), block(256);
-    const int J = (Dp / 4 + 63) / 64;
-#define MCQ_RES_CASE(NN, JJ)                                                                                   \
-    if (N == NN && J == JJ) {                                                                                  \
-        hipLaunchKernelGGL((k_residual_reg<NN, JJ>), grid, block, 0, st, x, idx, C, B, K, D, Dp, xerr, E, R, nact, \
-                           map, xh);                                                                          \
-        MCQ_LAUNCH_CHECK();                                                                                    \
-        return 0;                                                                                              \
-    }
-    MCQ_RES_CASE(8, 2)
-    MCQ_RES_CASE(8, 1)
-    MCQ_RES_CASE(4, 1)
-    MCQ_RES_CASE(4, 2)
-    MCQ_RES_CASE(4, 4)
-    MCQ_RES_CASE(16, 1)
-    MCQ_RES_CASE(16, 2)
-    MCQ_RES_CASE(2, 1)
-    MCQ_RES_CASE(2, 2)
-#undef MCQ_RES_CASE
-    // long rows (J > 2 float4 columns per lane) with many codebooks: chunked register variant
-    if (J > 2 && N == 16) {
-        hipLaunchKernelGGL((k_residual_regc<16, 2>), grid, block, 0, st, x, idx, C, B, K, D, Dp, xerr, E, R, nact, map, xh);
-        MCQ_LAUNCH_CHECK();
-        return 0;
-    }
-    if (J > 2 && N == 8) {
-        hipLaunchKernelGGL((k_residual_regc<8, 2>), grid, block, 0, st, x, idx, C, B, K, D, Dp, xerr, E, R, nact, map, xh);
-        MCQ_LAUNCH_CHECK();
-        return 0;
-    }
-    hipLaunchKernelGGL(k_residual, grid, block, 0, st, x, idx, C, B, N, K, D, Dp, xerr, E, R, nact, map, xh);
-    MCQ_LAUNCH_CHECK();
-    return 0;
-}
-
-
-// ---------------------------------------------------------------- table form
-#define MCQ_TF_CHECK() MCQ_LAUNCH_CHECK()
-
+// ---------------------------------------------------------------- the refinement pass
 template <int K>
 int launch_tf_stage0_k(int N, const float *G, const float *XC, const uint8_t *idx, const float *R, const float *Q, long B,
-                       int keep, uint8_t *ent, float *S, const int *nact, const int *map, hipStream_t st) {
+                       int keep, uint8_t *ent, float *S, uint8_t *fin, const int *nact, const int *map, hipStream_t st) {
     const dim3 grid((unsigned)(((B + 3) / 4) * N)), block(256);
+#define MCQ_S0_CASE(NN) \
+    case NN: hipLaunchKernelGGL((k_tf_stage0<K, NN>), grid, block, 0, st, G, XC, idx, R, Q, B, keep, ent, S, fin, nact, map); break;
     switch (N) {
-        case 2: hipLaunchKernelGGL((k_tf_stage0<K, 2>), grid, block, 0, st, G, XC, idx, R, Q, B, keep, ent, S, nact, map); break;
-        case 4: hipLaunchKernelGGL((k_tf_stage0<K, 4>), grid, block, 0, st, G, XC, idx, R, Q, B, keep, ent, S, nact, map); break;
-        case 8: hipLaunchKernelGGL((k_tf_stage0<K, 8>), grid, block, 0, st, G, XC, idx, R, Q, B, keep, ent, S, nact, map); break;
-        case 16: hipLaunchKernelGGL((k_tf_stage0<K, 16>), grid, block, 0, st, G, XC, idx, R, Q, B, keep, ent, S, nact, map); break;
+        MCQ_S0_CASE(1) MCQ_S0_CASE(2) MCQ_S0_CASE(4) MCQ_S0_CASE(8) MCQ_S0_CASE(16) MCQ_S0_CASE(32)
+        case 64:
+            if constexpr (K == 16) {
+                hipLaunchKernelGGL((k_tf_stage0<K, 64>), grid, block, 0, st, G, XC, idx, R, Q, B, keep, ent, S, fin, nact, map);
+                break;
+            }
+            return MCQ_EUNSUPPORTED;
         default: return MCQ_EUNSUPPORTED;
     }
-    MCQ_TF_CHECK();
+#undef MCQ_S0_CASE
+    MCQ_LAUNCH_CHECK();
     return 0;
+}
+
+int launch_tf_stage0(int K, int N, const float *G, const float *XC, const uint8_t *idx, const float *R, const float *Q,
+                     long B, int keep, uint8_t *ent, float *S, uint8_t *fin, const int *nact, const int *map, hipStream_t st) {
+    switch (K) {
+        case 16: return launch_tf_stage0_k<16>(N, G, XC, idx, R, Q, B, keep, ent, S, fin, nact, map, st);
+        case 32: return launch_tf_stage0_k<32>(N, G, XC, idx, R, Q, B, keep, ent, S, fin, nact, map, st);
+        case 64: return launch_tf_stage0_k<64>(N, G, XC, idx, R, Q, B, keep, ent, S, fin, nact, map, st);
+        case 128: return launch_tf_stage0_k<128>(N, G, XC, idx, R, Q, B, keep, ent, S, fin, nact, map, st);
+        case 256: return launch_tf_stage0_k<256>(N, G, XC, idx, R, Q, B, keep, ent, S, fin, nact, map, st);
+        default: return MCQ_EUNSUPPORTED;
+    }
 }
 
 int launch_tf_er(int N, const float *G, const float *XC, const uint8_t *idx, const float *xx, long B, int K, float *E, float *R,
                  const int *nact, const int *map, hipStream_t st) {
     const dim3 grid((unsigned)((B + 3) / 4)), block(256);
+#define MCQ_ER_CASE(NN) case NN: hipLaunchKernelGGL((k_tf_er<NN>), grid, block, 0, st, G, XC, idx, xx, B, K, E, R, nact, map); break;
     switch (N) {
-        case 2: hipLaunchKernelGGL((k_tf_er<2>), grid, block, 0, st, G, XC, idx, xx, B, K, E, R, nact, map); break;
-        case 4: hipLaunchKernelGGL((k_tf_er<4>), grid, block, 0, st, G, XC, idx, xx, B, K, E, R, nact, map); break;
-        case 8: hipLaunchKernelGGL((k_tf_er<8>), grid, block, 0, st, G, XC, idx, xx, B, K, E, R, nact, map); break;
-        case 16: hipLaunchKernelGGL((k_tf_er<16>), grid, block, 0, st, G, XC, idx, xx, B, K, E, R, nact, map); break;
+        MCQ_ER_CASE(1) MCQ_ER_CASE(2) MCQ_ER_CASE(4) MCQ_ER_CASE(8) MCQ_ER_CASE(16) MCQ_ER_CASE(32) MCQ_ER_CASE(64)
         default: return MCQ_EUNSUPPORTED;
     }
-    MCQ_TF_CHECK();
+#undef MCQ_ER_CASE
+    MCQ_LAUNCH_CHECK();
     return 0;
 }
 
-int launch_tf_stage0(int K, int N, const float *G, const float *XC, const uint8_t *idx, const float *R, const float *Q,
-                     long B, int keep, uint8_t *ent, float *S, const int *nact, const int *map, hipStream_t st) {
-    switch (K) {
-        case 16: return launch_tf_stage0_k<16>(N, G, XC, idx, R, Q, B, keep, ent, S, nact, map, st);
-        case 32: return launch_tf_stage0_k<32>(N, G, XC, idx, R, Q, B, keep, ent, S, nact, map, st);
-        case 64: return launch_tf_stage0_k<64>(N, G, XC, idx, R, Q, B, keep, ent, S, nact, map, st);
-        case 128: return launch_tf_stage0_k<128>(N, G, XC, idx, R, Q, B, keep, ent, S, nact, map, st);
-        case 256: return launch_tf_stage0_k<256>(N, G, XC, idx, R, Q, B, keep, ent, S, nact, map, st);
-        default: return MCQ_EUNSUPPORTED;
-    }
+// group tables of level u >= 2 from those of level u - 1 (list lengths kh -> kc)
+int launch_tf_up(int kh, int kc, const TfLists &L, long B, int N, int u, int ntab, int per, const float *in, float *out,
+                 const int *nact, hipStream_t st) {
+    const dim3 grid((unsigned)(B * ntab)), block(64);
+#define MCQ_UP_CASE(A, C) \
+    if (kh == A && kc == C) { hipLaunchKernelGGL((k_tf_up<A, C>), grid, block, 0, st, L, B, N, u, ntab, per, in, out, nact); MCQ_LAUNCH_CHECK(); return 0; }
+    MCQ_UP_CASE(16, 32) MCQ_UP_CASE(32, 32) MCQ_UP_CASE(8, 16) MCQ_UP_CASE(16, 16) MCQ_UP_CASE(16, 32)
+#undef MCQ_UP_CASE
+    return MCQ_EUNSUPPORTED;
 }
 
-// the combines of one refinement pass in table form; lists of K >= 32 hold 16, 16, 32, 32 candidates, of K == 16: 8, 8, 16, 16
+// combine of the siblings of level v >= 2 (list lengths kh at level v - 1, kc at level v)
+int launch_tf_comb(int kh, int kc, const float *E, const TfLists &L, long B, int N, int v, int keep, const float *tabs,
+                   uint8_t *fin, const int *nact, hipStream_t st) {
+    const dim3 grid((unsigned)(B * (N >> (v + 1)))), block(64);
+#define MCQ_COMB_CASE(A, C) \
+    if (kh == A && kc == C) { hipLaunchKernelGGL((k_tf_comb<A, C>), grid, block, 0, st, E, L, B, N, v, keep, tabs, fin, nact); MCQ_LAUNCH_CHECK(); return 0; }
+    MCQ_COMB_CASE(16, 32) MCQ_COMB_CASE(32, 32) MCQ_COMB_CASE(32, 64) MCQ_COMB_CASE(8, 16) MCQ_COMB_CASE(16, 16) MCQ_COMB_CASE(16, 32)
+#undef MCQ_COMB_CASE
+    return MCQ_EUNSUPPORTED;
+}
+
+// profiling categories (mcq_profile_encode): once per call 0, 1, 3; per pass the rest
+enum { CAT_LOGITS = 0, CAT_XX = 1, CAT_STAGE0 = 2, CAT_XC = 3, CAT_LEVEL0 = 4, CAT_LEVEL1 = 5, CAT_TABLES = 6, CAT_COMBINE = 7,
+       CAT_ER = 10 };
+
+// the combines of one refinement pass; lists of K >= 32 hold 16, 16, 32, 32, 64 candidates, of K == 16: 8, 8, 16, 16, 32, 32
 int run_tf_combines(const float *G, const uint8_t *idx_cur, uint8_t *idx_new, const Workspace &w, long B, int N, int K,
                     const int *nact, hipStream_t st, Prof *prof) {
     const bool small = (K == 16);
     const TfLists &L = w.tf;
-    // level 0: single codebooks
-    {
+    const int nlev = tf_levels(N);
+    {   // level 0: single codebooks
         const int keep = (N == 2) ? 1 : L.kc[1];
         uint8_t *fin = (N == 2) ? idx_new : nullptr;
         const dim3 grid((unsigned)(B * (N / 2)));
         if (prof) prof->begin();
         if (small) hipLaunchKernelGGL((k_tf_pair0<8>), grid, dim3(64), 0, st, G, idx_cur, w.E, L, B, N, K, keep, fin, nact);
         else hipLaunchKernelGGL((k_tf_pair0<16>), grid, dim3(64), 0, st, G, idx_cur, w.E, L, B, N, K, keep, fin, nact);
-        MCQ_TF_CHECK();
-        if (prof) prof->end(4);
+        MCQ_LAUNCH_CHECK();
+        if (prof) prof->end(CAT_LEVEL0);
     }
     if (N >= 4) {   // level 1: pairs of codebooks
         const int keep = (N == 4) ? 1 : L.kc[2];
@@ -434,40 +294,41 @@ int run_tf_combines(const float *G, const uint8_t *idx_cur, uint8_t *idx_new, co
         if (prof) prof->begin();
         if (small) hipLaunchKernelGGL((k_tf_pair1<8, 8>), grid, dim3(64), 0, st, G, idx_cur, w.E, L, B, N, K, keep, fin, nact);
         else hipLaunchKernelGGL((k_tf_pair1<16, 16>), grid, dim3(64), 0, st, G, idx_cur, w.E, L, B, N, K, keep, fin, nact);
-        MCQ_TF_CHECK();
-        if (prof) prof->end(5);
+        MCQ_LAUNCH_CHECK();
+        if (prof) prof->end(CAT_LEVEL1);
     }
-    if (N >= 8) {   // level 2: the level-1 tables of the cousins, then the groups of four
-        const int ntab = 4 * (N / 8);
-        const int keep = (N == 8) ? 1 : L.kc[3];
-        uint8_t *fin = (N == 8) ? idx_new : nullptr;
+    for (int v = 2; v < nlev; ++v) {   // level v: level-1 tables of the cousins below, raised level by level, then the combine
+        const int groups = N >> (v + 1);
+        const bool last = (v == nlev - 1);
+        const int keep = last ? 1 : L.kc[v + 1];
+        uint8_t *fin = last ? idx_new : nullptr;
+        const int per1 = 1 << (v - 1), ntab1 = groups * per1 * per1;
         if (prof) prof->begin();
-        if (small) hipLaunchKernelGGL((k_tf_table1<8, 8>), dim3((unsigned)(B * ntab)), dim3(64), 0, st, G, idx_cur, L, B, N, K, ntab, 0, w.tabs, nact);
-        else hipLaunchKernelGGL((k_tf_table1<16, 16>), dim3((unsigned)(B * ntab)), dim3(64), 0, st, G, idx_cur, L, B, N, K, ntab, 0, w.tabs, nact);
-        MCQ_TF_CHECK();
-        if (prof) { prof->end(6); prof->begin(); }
-        const dim3 grid((unsigned)(B * (N / 8)));
-        if (small) hipLaunchKernelGGL((k_tf_comb2<8, 16>), grid, dim3(64), 0, st, idx_cur, w.E, L, B, N, keep, ntab, w.tabs, fin, nact);
-        else hipLaunchKernelGGL((k_tf_comb2<16, 32>), grid, dim3(64), 0, st, idx_cur, w.E, L, B, N, keep, ntab, w.tabs, fin, nact);
-        MCQ_TF_CHECK();
-        if (prof) prof->end(7);
-    }
-    if (N >= 16) {  // level 3: sixteen level-1 tables, then the two groups of eight
-        if (prof) prof->begin();
-        if (small) hipLaunchKernelGGL((k_tf_table1<8, 8>), dim3((unsigned)(B * 16)), dim3(64), 0, st, G, idx_cur, L, B, N, K, 16, 1, w.tabs, nact);
-        else hipLaunchKernelGGL((k_tf_table1<16, 16>), dim3((unsigned)(B * 16)), dim3(64), 0, st, G, idx_cur, L, B, N, K, 16, 1, w.tabs, nact);
-        MCQ_TF_CHECK();
-        if (prof) { prof->end(8); prof->begin(); }
-        if (small) hipLaunchKernelGGL((k_tf_comb3<8, 16, 16>), dim3((unsigned)B), dim3(64), 0, st, idx_cur, w.E, L, B, N, w.tabs, idx_new, nact);
-        else hipLaunchKernelGGL((k_tf_comb3<16, 32, 32>), dim3((unsigned)B), dim3(64), 0, st, idx_cur, w.E, L, B, N, w.tabs, idx_new, nact);
-        MCQ_TF_CHECK();
-        if (prof) prof->end(9);
+        if (small) hipLaunchKernelGGL((k_tf_table1<8, 8>), dim3((unsigned)(B * ntab1)), dim3(64), 0, st, G, idx_cur, L, B, N, K, ntab1, per1, w.tabs[0], nact);
+        else hipLaunchKernelGGL((k_tf_table1<16, 16>), dim3((unsigned)(B * ntab1)), dim3(64), 0, st, G, idx_cur, L, B, N, K, ntab1, per1, w.tabs[0], nact);
+        MCQ_LAUNCH_CHECK();
+        if (N == 16 && v == 3) {       // two groups of eight: levels 2 and 3 in one kernel, tables in LDS
+            if (prof) { prof->end(CAT_TABLES + 2); prof->begin(); }
+            if (small) hipLaunchKernelGGL((k_tf_comb3<8, 16, 16>), dim3((unsigned)B), dim3(64), 0, st, idx_cur, w.E, L, B, N, w.tabs[0], idx_new, nact);
+            else hipLaunchKernelGGL((k_tf_comb3<16, 32, 32>), dim3((unsigned)B), dim3(64), 0, st, idx_cur, w.E, L, B, N, w.tabs[0], idx_new, nact);
+            MCQ_LAUNCH_CHECK();
+            if (prof) prof->end(CAT_COMBINE + 2);
+            continue;
+        }
+        int cur = 0;
+        for (int u = 2; u < v; ++u) {
+            const int per = 1 << (v - u), ntab = groups * per * per;
+            const int rc = launch_tf_up(L.kc[u - 1], L.kc[u], L, B, N, u, ntab, per, w.tabs[cur], w.tabs[cur ^ 1], nact, st);
+            if (rc) return rc;
+            cur ^= 1;
+        }
+        if (prof) { prof->end(v == 2 ? CAT_TABLES : CAT_TABLES + 2); prof->begin(); }
+        const int rc = launch_tf_comb(L.kc[v - 1], L.kc[v], w.E, L, B, N, v, keep, w.tabs[cur], fin, nact, st);
+        if (rc) return rc;
+        if (prof) prof->end(v == 2 ? CAT_COMBINE : CAT_COMBINE + 2);
     }
     return 0;
 }
-
-// categories for profiling
-enum { CAT_LOGITS = 0, CAT_RESIDUAL = 1, CAT_STAGE0 = 2, CAT_PRUNE0 = 3, CAT_PAIR0 = 4 };
 
 int run_encode(const float *x, long B, const void *prepared, float lscale, int N, int K, int D, int iters,
                uint8_t *out_u8, int64_t *out_i64, void *workspace, size_t workspace_bytes, hipStream_t st,
@@ -478,7 +339,7 @@ int run_encode(const float *x, long B, const void *prepared, float lscale, int N
     if (B == 0) return 0;
     if (!x || !prepared || !workspace) return MCQ_EINVAL;
     const int Dp = round_up16(D);
-    const size_t per = workspace_per_vector(N, K, Dp);
+    const size_t per = workspace_per_vector(N, K);
     if (workspace_bytes < kWorkspaceSlack + per) return MCQ_EWORKSPACE;
     long chunk = (long)((workspace_bytes - kWorkspaceSlack) / per);
     if (chunk > B) chunk = B;
@@ -486,14 +347,13 @@ int run_encode(const float *x, long B, const void *prepared, float lscale, int N
     if (chunk < B) chunk &= ~63L;
     const Prepared P = prepared_view(prepared, N, K, D);
     const int pack = (out_u8 != nullptr && K == 16 && N >= 2) ? 2 : 1;
-    const int first_keep = (N == 1) ? 1 : k_cutoff(K, 1);
     // fixed-point skipping (opt-in): vectors whose indexes a pass leaves unchanged drop out of the later
     // passes (k_compact); results are identical, the cost becomes data dependent
     const bool skip = (flags & MCQ_ENCODE_SKIP_FIXED_POINTS) != 0 && iters >= 2;
 
     for (long lo = 0; lo < B; lo += chunk) {
         const long Bc = (B - lo < chunk) ? (B - lo) : chunk;
-        const Workspace w = carve(workspace, Bc, N, K, Dp);
+        const Workspace w = carve(workspace, Bc, N, K);
         const int xh = (flags & MCQ_ENCODE_X_FP16) ? 1 : 0;   // rows of 2-byte elements
         const float *xc = xh ? reinterpret_cast<const float *>(reinterpret_cast<const uint16_t *>(x) + lo * D) : x + lo * D;
         int rc;
@@ -503,22 +363,19 @@ int run_encode(const float *x, long B, const void *prepared, float lscale, int N
             MCQ_LAUNCH_CHECK();
         } else {
             if (prof) prof->begin();
-            rc = launch_gemm<MODE_LOGITS>(K, P.W, xc, nullptr, lscale, P.bias, nullptr, nullptr, Bc, N, D, Dp, w.idx,
-                                          nullptr, st, 0, nullptr,
+            rc = launch_gemm<MODE_LOGITS>(K, P.W, xc, lscale, P.bias, Bc, N, D, Dp, w.idx, nullptr, st,
                                           (flags & MCQ_ENCODE_LSCALE_FROM_PREPARED) ? P.scales + 1 : nullptr, xh);
             if (rc) return rc;
             if (prof) prof->end(CAT_LOGITS);
         }
-        const bool tf = table_form(N);
-        if (tf && iters > 0) {   // x.C products of the chunk, once (the table form's only per-vector GEMM besides the logits)
+        if (iters > 0) {   // what the passes read per vector: the x.C products and |x|^2, once per call
             if (prof) prof->begin();
-            rc = launch_gemm<MODE_XC>(K, P.C, xc, nullptr, 1.0f, nullptr, nullptr, nullptr, Bc, N, D, Dp, nullptr, w.XC, st,
-                                      0, nullptr, nullptr, xh);
+            rc = launch_gemm<MODE_XC>(K, P.C, xc, 1.0f, nullptr, Bc, N, D, Dp, nullptr, w.XC, st, nullptr, xh);
             if (rc) return rc;
-            if (prof) { prof->end(CAT_PRUNE0); prof->begin(); }
+            if (prof) { prof->end(CAT_XC); prof->begin(); }
             hipLaunchKernelGGL(k_tf_xx, dim3((unsigned)((Bc + 3) / 4)), dim3(256), 0, st, xc, Bc, D, Dp, w.xx, xh);
             MCQ_LAUNCH_CHECK();
-            if (prof) prof->end(CAT_RESIDUAL);
+            if (prof) prof->end(CAT_XX);
         }
         // without skipping: indexes are refined in place in w.idx, nothing is packed
         uint8_t *idx_cur = w.idx, *idx_new = skip ? w.idxB : w.idx, *idx_pk = w.idxC;
@@ -530,53 +387,16 @@ int run_encode(const float *x, long B, const void *prepared, float lscale, int N
         }
         for (int it = 0; it < iters; ++it) {
             if (prof) prof->begin();
-            if (!tf) {
-                rc = launch_residual(xc, idx_cur, P.C, Bc, N, K, D, Dp, w.xerr, w.E, w.R, st, nact, map_cur, xh);
-                if (rc) return rc;
-                if (prof) { prof->end(CAT_RESIDUAL); prof->begin(); }
-            }
-            if (tf) {
-                rc = launch_tf_er(N, P.G, w.XC, idx_cur, w.xx, Bc, K, w.E, w.R, nact, map_cur, st);
-                if (rc) return rc;
-                if (prof) { prof->end(10); prof->begin(); }
-                rc = launch_tf_stage0(K, N, P.G, w.XC, idx_cur, w.R, P.Q, Bc, w.tf.kc[0], w.tf.ent, w.tf.S[0], nact, map_cur, st);
-                if (rc) return rc;
-                if (prof) prof->end(CAT_STAGE0);
+            rc = launch_tf_er(N, P.G, w.XC, idx_cur, w.xx, Bc, K, w.E, w.R, nact, map_cur, st);
+            if (rc) return rc;
+            if (prof) { prof->end(CAT_ER); prof->begin(); }
+            rc = launch_tf_stage0(K, N, P.G, w.XC, idx_cur, w.R, P.Q, Bc, (N == 1) ? 1 : w.tf.kc[0], w.tf.ent, w.tf.S[0],
+                                  (N == 1) ? idx_new : nullptr, nact, map_cur, st);
+            if (rc) return rc;
+            if (prof) prof->end(CAT_STAGE0);
+            if (N >= 2) {
                 rc = run_tf_combines(P.G, idx_cur, idx_new, w, Bc, N, K, nact, st, prof);
                 if (rc) return rc;
-            } else if (fused_select(N, K)) {
-                // stage-0 scores never reach HBM: the first sort-and-truncate runs in the GEMM epilogue
-                rc = launch_gemm<MODE_STAGE0_SEL>(K, P.C, w.xerr, idx_cur, 0.f, nullptr, w.R, P.Q, Bc, N, D, Dp,
-                                                  w.tup[0], w.S[0], st, first_keep, nact);
-                if (rc) return rc;
-                if (prof) { prof->end(CAT_STAGE0); prof->begin(); prof->end(CAT_PRUNE0); }
-            } else {
-                rc = launch_gemm<MODE_STAGE0>(K, P.C, w.xerr, idx_cur, 0.f, nullptr, w.R, P.Q, Bc, N, D, Dp, nullptr,
-                                              w.S0, st, 0, nact);
-                if (rc) return rc;
-                if (prof) { prof->end(CAT_STAGE0); prof->begin(); }
-                rc = launch_prune0(K, w.S0, Bc * N, first_keep, w.tup[0], w.S[0], (N == 1) ? idx_new : nullptr, st,
-                                   nact, N);
-                if (rc) return rc;
-                if (prof) prof->end(CAT_PRUNE0);
-            }
-            int G = tf ? 1 : N, L = 1, KI = first_keep, cur = 0, stage = 0;
-            while (G > 1) {
-                const int Gout = G / 2;
-                const int keep = (Gout == 1) ? 1 : k_cutoff(K, 2 * L);
-                if (prof) prof->begin();
-                // tuple lists rotate through three buffers (the lists of two stages back stay readable); scores ping-pong.
-                // A two-leaf 16-candidate stage that keeps 32 records which pairs it kept for the DEDUP stage after it.
-                const int tcur = stage % 3, tnext = (stage + 1) % 3, tprev = (stage + 2) % 3;
-                const bool next_dedup = (L == 2 && KI == 16 && keep == 32 && Gout > 1);
-                const bool this_dedup = (L == 4 && KI == 32 && stage >= 2);
-                rc = launch_pair(L, KI, P.C, idx_cur, w.E, w.tup[tcur], w.S[cur], Bc, N, K, Dp, Gout, keep,
-                                 w.tup[tnext], w.S[cur ^ 1], (Gout == 1) ? idx_new : nullptr, nact, st,
-                                 next_dedup ? w.pos : nullptr, this_dedup ? w.pos : nullptr,
-                                 this_dedup ? w.tup[tprev] : nullptr);
-                if (rc) return rc;
-                if (prof) prof->end(CAT_PAIR0 + stage);
-                G = Gout; L *= 2; KI = keep; cur ^= 1; ++stage;
             }
             if (skip) {
                 const int last = (it + 1 == iters) ? 1 : 0;
@@ -640,11 +460,10 @@ static int prepare_impl(const float *centers, float cscale_exp, const float *sca
         e = hipMemcpyAsync(b + l.offScales, scales_dev, 8, hipMemcpyDeviceToDevice, st);
         if (e != hipSuccess) return (int)e;
     }
-    if (weight && table_form(N)) {
+    if (weight) {
         // Gram matrix of the scaled centers: the same GEMM kernel with the padded rows themselves as the "vectors"
         const float *C = reinterpret_cast<const float *>(b + l.offC);
-        const int rc = launch_gemm<MODE_XC>(K, C, C, nullptr, 1.0f, nullptr, nullptr, nullptr, rows, N, Dp, Dp, nullptr,
-                                            reinterpret_cast<float *>(b + l.offG), st);
+        const int rc = launch_gemm<MODE_XC>(K, C, C, 1.0f, nullptr, rows, N, Dp, Dp, nullptr, reinterpret_cast<float *>(b + l.offG), st);
         if (rc) return rc;
     }
     return 0;
@@ -662,9 +481,9 @@ int mcq_prepare_dev(const float *centers, const float *scales_exp, const float *
 }
 
 size_t mcq_encode_workspace_bytes(long B, int N, int K, int D) {
-    if (B <= 0 || N <= 0 || K <= 0 || D <= 0) return kWorkspaceSlack;
-    const long chunk = B < kDefaultChunk ? B : kDefaultChunk;
-    return kWorkspaceSlack + workspace_per_vector(N, K, round_up16(D)) * (size_t)chunk;
+    if (B <= 0 || N <= 0 || K <= 0 || D <= 0 || !domain_ok(N, K, D)) return kWorkspaceSlack;
+    const long dc = default_chunk(N, K), chunk = B < dc ? B : dc;
+    return kWorkspaceSlack + workspace_per_vector(N, K) * (size_t)chunk;
 }
 
 int mcq_encode(const float *x, long B, const void *prepared, float lscale_exp, int N, int K, int D, int refine_iters,
@@ -842,8 +661,8 @@ int mcq_logits(const float *x, long B, const void *prepared, float lscale_exp, i
     if (B == 0) return 0;
     if (!x || !prepared || !out || B < 0) return MCQ_EINVAL;
     const Prepared P = prepared_view(prepared, N, K, D);
-    return launch_gemm<MODE_LOGITS_OUT>(K, P.W, x, nullptr, lscale_exp, P.bias, nullptr, nullptr, B, N, D,
-                                        round_up16(D), nullptr, out, static_cast<hipStream_t>(stream));
+    return launch_gemm<MODE_LOGITS_OUT>(K, P.W, x, lscale_exp, P.bias, B, N, D, round_up16(D), nullptr, out,
+                                        static_cast<hipStream_t>(stream));
 }
 
 // ------------------------------------------------------------------ trainer pieces
@@ -858,8 +677,7 @@ int mcq_logits_argmax(const float *x, long B, const void *prepared, float lscale
     hipStream_t st = static_cast<hipStream_t>(stream);
     const Prepared P = prepared_view(prepared, N, K, D);
     uint8_t *idx8 = static_cast<uint8_t *>(workspace);
-    int rc = launch_gemm<MODE_LOGITS_OUT>(K, P.W, x, nullptr, lscale_exp, P.bias, nullptr, nullptr, B, N, D, round_up16(D),
-                                          idx8, logits_out, st, 0, nullptr,
+    int rc = launch_gemm<MODE_LOGITS_OUT>(K, P.W, x, lscale_exp, P.bias, B, N, D, round_up16(D), idx8, logits_out, st,
                                           (flags & MCQ_ENCODE_LSCALE_FROM_PREPARED) ? P.scales + 1 : nullptr,
                                           (flags & MCQ_ENCODE_X_FP16) ? 1 : 0);
     if (rc) return rc;

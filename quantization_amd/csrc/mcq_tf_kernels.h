@@ -19,7 +19,7 @@
 
 namespace mcq {
 
-constexpr int kTfLevels = 4;   // lists of candidates over 1, 2, 4, 8 codebooks (N <= 16)
+constexpr int kTfLevels = 6;   // lists of candidates over 1, 2, 4, 8, 16, 32 codebooks (N <= 64)
 
 struct TfLists {
     uint8_t *ent;               // [B][N][kc[0]]            level-0 lists: codebook entries
@@ -118,10 +118,11 @@ template <int K, int N>
 __global__ void __launch_bounds__(256)
 k_tf_stage0(const float *__restrict__ G, const float *__restrict__ XC, const uint8_t *__restrict__ idx,
             const float *__restrict__ R, const float *__restrict__ Q, long B, int keep,
-            uint8_t *__restrict__ ent_out, float *__restrict__ S_out, const int *__restrict__ nact,
-            const int *__restrict__ map) {
+            uint8_t *__restrict__ ent_out, float *__restrict__ S_out, uint8_t *__restrict__ idx_final /* N == 1 */,
+            const int *__restrict__ nact, const int *__restrict__ map) {
     constexpr int VPL = (K >= 64) ? K / 64 : 1;
     constexpr int NK = N * K;
+    constexpr int CH = (N - 1 < 8) ? (N > 1 ? N - 1 : 1) : 8;    // row segments in flight
     __shared__ u64 sel[4][kSelectLdsU64];
     if (nact) B = *nact;
     const int n = blockIdx.x & (N - 1);
@@ -131,19 +132,32 @@ k_tf_stage0(const float *__restrict__ G, const float *__restrict__ XC, const uin
     const bool act = VPL * lane < K;
     const int k0 = act ? VPL * lane : 0;
     const uint8_t *id = idx + b * N;
-    float gv[N - 1][VPL];
+    float t[VPL];
 #pragma unroll
-    for (int j = 0; j < N - 1; ++j) {
-        const int m = j < n ? j : j + 1;                    // m ascending over the codebooks other than n
-        const float *p = G + ((size_t)(m * K + id[m]) * NK + n * K + k0);
-        if constexpr (VPL == 4) {
-            const f32x4 t4 = *reinterpret_cast<const f32x4 *>(p);
+    for (int i = 0; i < VPL; ++i) t[i] = 0.f;               // N == 1: no other codebook, X = 0 - XC
 #pragma unroll
-            for (int i = 0; i < 4; ++i) gv[j][i] = t4[i];
-        } else {
+    for (int j0 = 0; j0 < N - 1; j0 += CH) {
+        float gv[CH][VPL];
 #pragma unroll
-            for (int i = 0; i < VPL; ++i) gv[j][i] = p[i];
+        for (int u = 0; u < CH; ++u) {
+            const int j = j0 + u < N - 1 ? j0 + u : N - 2;
+            const int m = j < n ? j : j + 1;                    // m ascending over the codebooks other than n
+            const float *p = G + ((size_t)(m * K + id[m]) * NK + n * K + k0);
+            if constexpr (VPL == 4) {
+                const f32x4 t4 = *reinterpret_cast<const f32x4 *>(p);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) gv[u][i] = t4[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < VPL; ++i) gv[u][i] = p[i];
+            }
         }
+#pragma unroll
+        for (int u = 0; u < CH; ++u)
+            if (j0 + u < N - 1) {
+#pragma unroll
+                for (int i = 0; i < VPL; ++i) t[i] = (j0 + u == 0) ? gv[u][i] : t[i] + gv[u][i];
+            }
     }
     const float *xc = XC + ((size_t)(map ? (long)map[b] : b) * NK + n * K + k0);
     const float *q = Q + n * K + k0;
@@ -152,16 +166,17 @@ k_tf_stage0(const float *__restrict__ G, const float *__restrict__ XC, const uin
     int sp[VPL];
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
-        float t = gv[0][i];
-#pragma unroll
-        for (int j = 1; j < N - 1; ++j) t = t + gv[j][i];
-        const float X = t - xc[i];
+        const float X = t[i] - xc[i];
         sv[i] = act ? (Rv + q[i]) + 2.0f * X : INFINITY;
         sp[i] = act ? k0 + i : kBigPos;
     }
     float ov;
     int op;
     wave_select_fast<VPL>(sv, sp, keep, K, sel[threadIdx.x >> 6], ov, op);
+    if (N == 1) {                                             // the best entry is the result (:468-469)
+        if (lane == 0) idx_final[b] = (uint8_t)op;
+        return;
+    }
     if (lane < keep) {
         ent_out[(b * N + n) * keep + lane] = (uint8_t)op;
         S_out[(b * N + n) * keep + lane] = ov;
@@ -441,14 +456,13 @@ k_tf_pair1(const float *__restrict__ G, const uint8_t *__restrict__ idx, const f
     tf_finish<VPL>(sv, sp, keep, KC, scratch, L, 2, b, N, g, idx_final);
 }
 
-// T_1 of COUSIN pairs (needed by the combines of levels 2 and 3) -> tabs[b][t][KC*KC].  One wave per (b, t);
-// workgroup id mod ntab = t, so an XCD reads the leaf blocks of its own tables only.
-//   quads == 0: the cousins under the level-2 siblings P = 2h, Q = 2h + 1:  t = 4h + 2a + c -> X = 4h + a, Y = 4h + 2 + c
-//   quads == 1: (N = 16, level-3 siblings) all X in 0..3 against Y in 4..7:  t = 4X + (Y - 4)
+// T_1 of COUSIN pairs under the siblings of a higher level -> tabs[b][t][KC*KC].  One wave per (b, t); workgroup id
+// mod ntab = t, so an XCD reads the leaf blocks of its own tables only.  Under sibling pair g each side has `per`
+// level-1 groups: t = (g * per + a) * per + c  ->  X = 2 g per + a,  Y = (2 g + 1) per + c.
 template <int KCH, int KC>
 __global__ void __launch_bounds__(64)
 k_tf_table1(const float *__restrict__ G, const uint8_t *__restrict__ idx, TfLists L, long B, int N, int K, int ntab,
-            int quads, float *__restrict__ tabs, const int *__restrict__ nact) {
+            int per, float *__restrict__ tabs, const int *__restrict__ nact) {
     constexpr int VPL = KC * KC / 64;
     __shared__ __attribute__((aligned(16))) float leaf[tf_leaf_lds_floats(KCH)];
     if (nact) B = *nact;
@@ -456,9 +470,9 @@ k_tf_table1(const float *__restrict__ G, const uint8_t *__restrict__ idx, TfList
     const long b = (long)(blockIdx.x >> __builtin_ctz((unsigned)ntab));
     if (b >= B) return;
     const int lane = lane_id();
-    int X, Y;
-    if (quads) { X = t >> 2; Y = 4 + (t & 3); }
-    else { X = 4 * (t >> 2) + ((t >> 1) & 1); Y = 4 * (t >> 2) + 2 + (t & 1); }
+    const int psh = __builtin_ctz((unsigned)per);
+    const int c = t & (per - 1), a = (t >> psh) & (per - 1), g = t >> (2 * psh);
+    const int X = 2 * g * per + a, Y = (2 * g + 1) * per + c;
     float tv[VPL];
     tf_table1<KCH, KC>(G, idx, L, b, N, K, X, Y, leaf, tv);
     float *dst = tabs + ((size_t)(b * ntab + t) * (KC * KC) + VPL * lane);
@@ -499,42 +513,96 @@ __device__ __forceinline__ void tf_up(const float *t00, const float *t01, const 
     }
 }
 
-// ------------------------------------------------------- combine of level 2
-// Siblings P = 2h, Q = 2h + 1 (groups of four codebooks, lists of KC2): the four level-1 tables of their halves
-// come from tabs.  One wave per (b, h).
-template <int KC1, int KC2>
+// ------------------------------------------------- tables of levels >= 2
+// T_u of the cousin pair (X, Y) of level-u groups from the four level-(u-1) tables of their halves (tabs_in, rows of
+// 2 * per tables) -> tabs_out.  Same indexing as k_tf_table1: t = (g * per + a) * per + c.  One wave per (b, t).
+template <int KH, int KC>
 __global__ void __launch_bounds__(64)
-k_tf_comb2(const uint8_t *__restrict__ idx, const float *__restrict__ E, TfLists L, long B, int N, int keep, int ntab,
-           const float *__restrict__ tabs, uint8_t *__restrict__ idx_final, const int *__restrict__ nact) {
-    constexpr int VPL = KC2 * KC2 / 64, M1 = KC1 * KC1;
-    __shared__ u64 scratch[kSelectLdsU64];
-    __shared__ __attribute__((aligned(16))) float t1[4 * M1];
+k_tf_up(TfLists L, long B, int N, int u, int ntab, int per, const float *__restrict__ tabs_in, float *__restrict__ tabs_out,
+        const int *__restrict__ nact) {
+    constexpr int VPL = KC * KC / 64, MH = KH * KH;
+    __shared__ __attribute__((aligned(16))) float th[4 * MH];
     if (nact) B = *nact;
-    const int Gout = N >> 3;
+    const int t = (int)(blockIdx.x & (unsigned)(ntab - 1));
+    const long b = (long)(blockIdx.x >> __builtin_ctz((unsigned)ntab));
+    if (b >= B) return;
+    const int lane = lane_id();
+    const int psh = __builtin_ctz((unsigned)per);
+    const int c = t & (per - 1), a = (t >> psh) & (per - 1), g = t >> (2 * psh);
+    const int X = 2 * g * per + a, Y = (2 * g + 1) * per + c;
+    const int Gu = N >> u;
+    // children: tables (2a + i, 2c + j) of sibling pair g at the level below (2 * per tables per row)
+    const size_t cbase = (size_t)b * (4 * ntab) + (size_t)g * (4 * per * per);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            tf_load_tables<MH>(tabs_in + (cbase + (size_t)(2 * a + i) * (2 * per) + (2 * c + j)) * MH, th + (2 * i + j) * MH, 1);
+    wave_lds_fence();
+    float tv[VPL];
+    tf_up<KH, KC>(th, th + MH, th + 2 * MH, th + 3 * MH, L.pos[u] + ((b * Gu + X) * KC) * 2, L.pos[u] + ((b * Gu + Y) * KC) * 2, tv);
+    float *dst = tabs_out + ((size_t)(b * ntab + t) * (KC * KC) + VPL * lane);
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) dst[v] = tv[v];
+}
+
+// ------------------------------------------------ combine of a level >= 2
+// Siblings P = 2h, Q = 2h + 1 of level v (lists of KC): the four level-(v-1) tables of their halves come from tabs
+// ([b][h][2][2][KH*KH]).  One wave per (b, h).  KC == 64 (4,096 pairs: only ever the last combine) streams the scores
+// through a running arg-min instead of holding them.
+template <int KH, int KC>
+__global__ void __launch_bounds__(64)
+k_tf_comb(const float *__restrict__ E, TfLists L, long B, int N, int v, int keep, const float *__restrict__ tabs,
+          uint8_t *__restrict__ idx_final, const int *__restrict__ nact) {
+    constexpr int MH = KH * KH;
+    constexpr int VPL = (KC * KC / 64 <= 16) ? KC * KC / 64 : 16;
+    constexpr int CHUNKS = KC * KC / (64 * VPL);
+    __shared__ u64 scratch[kSelectLdsU64];
+    __shared__ __attribute__((aligned(16))) float th[4 * MH];
+    if (nact) B = *nact;
+    const int Gout = N >> (v + 1);
     const int h = (int)(blockIdx.x & (unsigned)(Gout - 1));
     const long b = (long)(blockIdx.x >> __builtin_ctz((unsigned)Gout));
     if (b >= B) return;
     const int lane = lane_id();
-    const int P = 2 * h, Q = P + 1, G2 = N >> 2;
-    tf_load_tables<M1>(tabs + (size_t)(b * ntab + 4 * h) * M1, t1, 4);
-    const int i = (VPL * lane) / KC2, j0 = (VPL * lane) % KC2;
+    const int P = 2 * h, Q = P + 1, Gv = N >> v;
+    tf_load_tables<MH>(tabs + ((size_t)b * Gout + h) * 4 * MH, th, 4);
     const float Eb = E[b];
-    const float se = L.S[2][(b * G2 + P) * KC2 + i];
-    float so[VPL];
-#pragma unroll
-    for (int v = 0; v < VPL; ++v) so[v] = L.S[2][(b * G2 + Q) * KC2 + j0 + v];
+    const uint8_t *px = L.pos[v] + ((b * Gv + P) * KC) * 2, *py = L.pos[v] + ((b * Gv + Q) * KC) * 2;
+    const float *Sx = L.S[v] + (b * Gv + P) * KC, *Sy = L.S[v] + (b * Gv + Q) * KC;
     wave_lds_fence();
-    float t[VPL];
-    tf_up<KC1, KC2>(t1, t1 + M1, t1 + 2 * M1, t1 + 3 * M1, L.pos[2] + ((b * G2 + P) * KC2) * 2,
-                    L.pos[2] + ((b * G2 + Q) * KC2) * 2, t);
-    float sv[VPL];
-    int sp[VPL];
+    if constexpr (CHUNKS == 1) {
+        const int i = (VPL * lane) / KC, j0 = (VPL * lane) % KC;
+        const float se = Sx[i];
+        float t[VPL];
+        tf_up<KH, KC>(th, th + MH, th + 2 * MH, th + 3 * MH, px, py, t);
+        float sv[VPL];
+        int sp[VPL];
 #pragma unroll
-    for (int v = 0; v < VPL; ++v) {
-        sv[v] = ((se + so[v]) - Eb) + 2.0f * t[v];
-        sp[v] = VPL * lane + v;
+        for (int u = 0; u < VPL; ++u) {
+            sv[u] = ((se + Sy[j0 + u]) - Eb) + 2.0f * t[u];
+            sp[u] = VPL * lane + u;
+        }
+        tf_finish<VPL>(sv, sp, keep, KC, scratch, L, v + 1, b, N, h, idx_final);
+    } else {
+        float bv = INFINITY;
+        int bp = kBigPos;
+        for (int c = 0; c < CHUNKS; ++c) {
+            const int p0 = 64 * VPL * c + VPL * lane;             // positions p0 .. p0 + VPL - 1 share the row i
+            const int i = p0 / KC, j0 = p0 % KC;
+            const int i0 = px[2 * i], i1 = px[2 * i + 1];
+            const float se = Sx[i];
+#pragma unroll
+            for (int u = 0; u < VPL; ++u) {
+                const int jj0 = py[2 * (j0 + u)], jj1 = py[2 * (j0 + u) + 1];
+                const float t = ((th[i0 * KH + jj0] + th[MH + i0 * KH + jj1]) + th[2 * MH + i1 * KH + jj0]) + th[3 * MH + i1 * KH + jj1];
+                lexmin(bv, bp, ((se + Sy[j0 + u]) - Eb) + 2.0f * t, p0 + u);
+            }
+        }
+        wave_lexmin(bv, bp);
+        if (bp > KC * KC - 1) bp = KC * KC - 1;                  // only reachable with NaN keys
+        tf_emit(L, b, N, v + 1, bp, idx_final);                   // keep == 1, last combine
     }
-    tf_finish<VPL>(sv, sp, keep, KC2, scratch, L, 3, b, N, h, idx_final);
 }
 
 // ------------------------------------------------------- combine of level 3
