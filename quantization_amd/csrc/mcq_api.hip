@@ -523,10 +523,10 @@ int mcq_decode(const void *codes, int code_bytes, int codes_per_row, long B, con
     const int J = (Dp / 4 + 63) / 64;
     // XCD-sliced kernel (unpacked codes, batches big enough to fill the chip; MCQ_DECODE_SLICED=0 disables: tuning hook)
     static const bool sliced_ok = !(getenv("MCQ_DECODE_SLICED") && atoi(getenv("MCQ_DECODE_SLICED")) == 0);
-    // LDS-resident kernel: very large batches whose codebook slice (N*K*64 B) fits the LDS
-    // (N >= 8: with fewer rows per vector the L2 gathers of the sliced kernel measured faster; 20 % gain at 8 x 256)
+    // LDS-resident kernel: batches of >= 16,384 vectors whose codebook slice (N*K*64 B) fits the LDS
+    // (N >= 8: with fewer rows per vector the L2 gathers of the sliced kernel measured faster; 36.9 vs 52.2 us at 8 x 256, 65,536 vectors)
     const char *lds_env = getenv("MCQ_DECODE_LDS_MIN");   // test / tuning hook, read per call
-    const long lds_min_b = lds_env ? atol(lds_env) : 262144;
+    const long lds_min_b = lds_env ? atol(lds_env) : 16384;
     if (sliced_ok && rep == 1 && B >= lds_min_b && (size_t)N * K * 64 <= 144 * 1024 && K >= 32 && N >= 8) {
         const int ns = Dp / 16, per_xcd = (ns + 7) / 8;
         int groups = 256 / (8 * per_xcd);            // one workgroup per CU
