@@ -97,3 +97,21 @@ def test_product_quantizer_matches_definition():
                 assert torch.equal(p.to_logits.weight[256 * c + ko],
                                    q.to_logits.weight[16 * 2 * c + k1] + q.to_logits.weight[16 * (2 * c + 1) + k2])
                 assert p.to_logits.bias[256 * c + ko] == q.to_logits.bias[16 * 2 * c + k1] + q.to_logits.bias[16 * (2 * c + 1) + k2]
+
+
+def test_workspace_and_prepared_sizes_over_the_domain():
+    """mcq_encode_workspace_bytes / mcq_prepared_bytes for every (K, N) of the domain: positive, monotone in B up to the
+    default chunk, below 4 GB at the largest shapes, and 'slack only' outside the domain."""
+    from quantization_amd import _lib as m
+    L = m.lib()
+    for K in (16, 32, 64, 128, 256):
+        for N in (1, 2, 4, 8, 16, 32, 64):
+            ok = N <= (64 if K == 16 else 32)
+            big = L.mcq_encode_workspace_bytes(10 ** 7, N, K, 512)
+            small = L.mcq_encode_workspace_bytes(100, N, K, 512)
+            if not ok:
+                assert big == small
+                continue
+            assert 0 < small < big <= 4 * 2 ** 30, (K, N, small, big)
+            nk = N * K
+            assert L.mcq_prepared_bytes(N, K, 512) >= 4 * (2 * nk * 512 + nk * nk)

@@ -305,6 +305,25 @@ def test_large_and_unusual_shapes_vs_oracle(D, K, N, B, it):
     assert np.array_equal(q.decode(torch.from_numpy(got).cuda()).cpu().numpy(), o.decode(want))
 
 
+@pytest.mark.parametrize("D,K,N,B", [(64, 256, 32, 20000), (48, 16, 64, 30000), (96, 64, 32, 3000), (40, 32, 16, 9000)])
+def test_many_codebooks_in_chunks(D, K, N, B):
+    """N >= 32 goes through the generic group-table levels (k_tf_up / k_tf_comb, streaming arg-min for 64 x 64) and its
+    per-vector workspace is large, so the default chunk is below 65,536 vectors: sampled rows vs the oracle, equality
+    with separate calls, decode bit-exact."""
+    sd = gen.synthetic_state(800 + N + K, D, K, N)
+    q = load_quantizer(sd, D, K, N)
+    o = oracle_of(sd)
+    x = gen.make_gaussian(33 + D, B, D)
+    xd = torch.from_numpy(x).cuda()
+    got = q.encode(xd, 2, as_bytes=False)
+    rows = np.random.RandomState(1).choice(B, 160, replace=False)
+    want = o.compute_indexes(x[rows], 2)
+    assert np.array_equal(got.cpu().numpy()[rows], want)
+    assert torch.equal(got[:1500], q.encode(xd[:1500], 2, as_bytes=False))
+    assert torch.equal(got[B - 777:], q.encode(xd[B - 777:], 2, as_bytes=False))
+    assert np.array_equal(q.decode(got[rows]).cpu().numpy(), o.decode(want.astype(np.uint8)))
+
+
 def test_non_finite_inputs_terminate_with_codes_in_range():
     """NaN / Inf rows give unspecified codes but never a hang, a fault or an
     out-of-range index, and do not disturb their neighbours."""
