@@ -57,27 +57,31 @@ def reference_flops_per_vector(D, N, K, iters):
 
 def kernel_work(B, D, N, K):
     """Per launch of each kernel category of mcq_profile_encode (in its order): (name, launches per encode as
-    'once' | 'pass', algorithmic FLOPs, algorithmic bytes).  The two GEMMs are the only MFMA work; the table kernels
-    read 4-byte Gram entries (bytes = entries read x 4 + lists and tables written)."""
+    'once' | 'pass', algorithmic FLOPs, algorithmic HBM bytes, table bytes).  The two GEMMs are the only MFMA work.  A
+    table kernel's HBM bytes are what it must exchange with memory (per-vector inputs, lists and tables written);
+    its table bytes are the 4-byte Gram entries / Gram row segments it reads, which an XCD's L2 serves (the Gram matrix is
+    resident state: 16 MB at 8 x 256)."""
     gemm = 2.0 * D * N * K * B
     kc = [k_cutoff(K, 1 << v) for v in range(6)]
-    leaf = (kc[0] * kc[0] + 2 * kc[0] + 1) * 4.0           # one leaf table's Gram reads
-    cats = [("logits_gemm_argmax", "once", gemm, 0.0),
-            ("x_sumsq", "once", 0.0, B * D * 4.0),
-            ("stage0_tables", "pass", 0.0, B * N * ((N + 1) * K * 4.0 + kc[0] * 5.0)),
-            ("xc_gemm", "once", gemm, 0.0),
-            ("combine_level0", "pass", 0.0, B * (N / 2) * (leaf + kc[1] * 6.0)),
-            ("combine_level1", "pass", 0.0, B * (N / 4) * (4 * leaf + kc[2] * 6.0)),
-            ("tables_level1", "pass", 0.0, B * 4 * (N / 8) * (4 * leaf + kc[1] * kc[1] * 4.0)),
-            ("combine_level2", "pass", 0.0, B * (N / 8) * (4 * kc[1] * kc[1] * 4.0 + kc[3] * 6.0)),
-            ("tables_upper_levels", "pass", 0.0, B * max(N // 16, 0) * 16 * (4 * leaf + kc[1] * kc[1] * 4.0)),
-            ("combine_upper_levels", "pass", 0.0, B * max(N // 16, 0) * 16 * kc[1] * kc[1] * 4.0),
-            ("residual_energies", "pass", 0.0, B * (N * N + 2 * N + 2) * 4.0)]       # E, R from the tables
+    leaf = (kc[0] * kc[0] + 2 * kc[0] + 1) * 4.0           # one full leaf table's Gram reads (x 0.3 below: the lazy
+    # level-1 tables read ~ 85 of the 289 entries, DESIGN.md section 4)
+    lists0 = 2 * kc[0] * 5.0                               # two level-0 lists read (entry + score)
+    cats = [("logits_gemm_argmax", "once", gemm, B * (D * 4.0 + N), 0.0),
+            ("x_sumsq", "once", 0.0, B * (D * 4.0 + 4), 0.0),
+            ("stage0_tables", "pass", 0.0, B * N * (K * 4.0 + kc[0] * 5.0 + 5), B * N * N * K * 4.0),
+            ("xc_gemm", "once", gemm, B * (D * 4.0 + N * K * 4.0), 0.0),
+            ("combine_level0", "pass", 0.0, B * (N / 2) * (lists0 + kc[1] * 6.0), B * (N / 2) * leaf),
+            ("combine_level1", "pass", 0.0, B * (N / 4) * (2 * lists0 + 2 * kc[1] * 6.0 + kc[2] * 6.0), B * (N / 4) * 4 * leaf * 0.3),
+            ("tables_level1", "pass", 0.0, B * 4 * (N / 8) * (2 * lists0 + 2 * kc[1] * 6.0 + kc[1] * kc[1] * 4.0), B * 4 * (N / 8) * 4 * leaf * 0.3),
+            ("combine_level2", "pass", 0.0, B * (N / 8) * (4 * kc[1] * kc[1] * 4.0 + 2 * kc[2] * 6.0 + kc[3] * 6.0), 0.0),
+            ("tables_upper_levels", "pass", 0.0, B * max(N // 16, 0) * 16 * kc[1] * kc[1] * 4.0, B * max(N // 16, 0) * 16 * 4 * leaf * 0.3),
+            ("combine_upper_levels", "pass", 0.0, B * max(N // 16, 0) * 16 * kc[1] * kc[1] * 4.0, 0.0),
+            ("residual_energies", "pass", 0.0, B * (N + N * 4.0 + 8), B * (N * N + N) * 4.0)]       # E, R from the tables
     present = 5 if N >= 2 else 4
     present = 6 if N >= 4 else present
     present = 8 if N >= 8 else present
     present = 10 if N >= 16 else present
-    return [c if (i < present or i == 10) else ("unused_%d" % i, "pass", 0.0, 0.0) for i, c in enumerate(cats)]
+    return [c if (i < present or i == 10) else ("unused_%d" % i, "pass", 0.0, 0.0, 0.0) for i, c in enumerate(cats)]
 
 
 def load_quantizer(state, D, K, N, dev):
@@ -296,7 +300,7 @@ def main():
     acc = np.maximum(acc, 1e-9)
     cats = kernel_work(B, D, N, K)
     kernels = {}
-    for i, (name, when, fl, by) in enumerate(cats):
+    for i, (name, when, fl, by, tb) in enumerate(cats):
         if name.startswith("unused_"):
             continue
         launches = 1 if when == "once" else iters
@@ -304,11 +308,14 @@ def main():
         kernels[name] = {"launches_per_encode": launches, "avg_ms": round(float(avg_ms), 4),
                          "ms_per_encode": round(float(acc[i]), 3)}
         if fl > 0:
-            kernels[name].update(gflop_per_launch=round(fl / 1e9, 2), tflops=round(fl / (avg_ms * 1e-3) / 1e12, 2))
-        if by > 0:
-            kernels[name].update(gbyte_per_launch=round(by / 1e9, 3), gbytes_per_s=round(by / (avg_ms * 1e-3) / 1e9, 1))
-    dom = max(range(len(cats)), key=lambda i: acc[i])
-    dom_name, dom_when, dom_fl, dom_by = cats[dom]
+            tf_ = fl / (avg_ms * 1e-3) / 1e12
+            kernels[name].update(gflop_per_launch=round(fl / 1e9, 2), tflops=round(tf_, 2), frac_of_f32_mfma_peak=round(tf_ / PEAK_F32_MFMA_TFLOPS, 4))
+        else:
+            kernels[name].update(hbm_gbyte_per_launch=round(by / 1e9, 3), hbm_gbytes_per_s=round(by / (avg_ms * 1e-3) / 1e9, 1))
+            if tb > 0:
+                kernels[name].update(table_gbyte_per_launch=round(tb / 1e9, 3), table_gbytes_per_s_from_l2=round(tb / (avg_ms * 1e-3) / 1e9, 1))
+    dom = max((i for i in range(len(cats)) if not cats[i][0].startswith("unused_")), key=lambda i: acc[i])
+    dom_name, dom_when, dom_fl, dom_by, dom_tb = cats[dom]
     dom_ms = acc[dom] / (1 if dom_when == "once" else iters)
     # HBM-side traffic of the dominant kernel: from the committed rocprofv3 --pmc passes of this same
     # workload (counters cannot be collected from inside the timed process); null for other shapes / kernels
@@ -318,7 +325,8 @@ def main():
         pmc = json.load(open(pmc_file))
         if dom_name in pmc:
             traffic = pmc[dom_name]["traffic_bytes"]
-            traffic_note = "bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from profiles/r02_pmc_traffic.json"
+            traffic_note = ("bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 of kernel %s, profiles/r02_pmc_traffic.json"
+                            % pmc[dom_name]["kernel"])
     if dom_fl > 0:
         achieved = dom_fl / (dom_ms * 1e-3) / 1e12
         roofline = {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
@@ -331,8 +339,12 @@ def main():
                     "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBPS, 4), "traffic": traffic,
                     "traffic_note": traffic_note, "gbyte_per_launch": round(dom_by / 1e9, 3),
                     "avg_launch_ms": round(float(dom_ms), 4),
-                    "note": "a table kernel: its algorithmic bytes are 4-byte Gram entries served by the XCD's L2, "
-                            "priced against the HBM peak as the contract asks"}
+                    "table_gbyte_per_launch": round(dom_tb / 1e9, 3),
+                    "table_gbytes_per_s_from_l2": round(dom_tb / (dom_ms * 1e-3) / 1e9, 1),
+                    "note": "a table kernel: no FLOPs to price.  `achieved` prices the bytes it must exchange with HBM (per-vector "
+                            "inputs, lists written); what bounds it is the L2 -> L1 fabric that carries the Gram row segments "
+                            "(table_*: measured ceiling 17-25 TB/s for such pieces, DESIGN.md section 5).  The two GEMMs (same "
+                            "kernel template, 33 % of an encode together) are in `kernels` with their fraction of the fp32-MFMA peak"}
 
     fpv = reference_flops_per_vector(D, N, K, iters)
     exec_fpv = 2 * 2.0 * D * N * K          # the logits and x.C GEMMs only
