@@ -420,6 +420,26 @@ int run_encode(const float *x, long B, const void *prepared, float lscale, int N
     return 0;
 }
 
+// floats per lane of k_decode_backward: 4 (float4 loads) when every row involved is 16-byte aligned
+int db_cw(const void *g, const void *out, int D, long gsb, long gsn, const void *dotw = nullptr) {
+    const bool al = ((D & 3) == 0) && ((gsb & 3) == 0) && ((gsn & 3) == 0) && ((reinterpret_cast<uintptr_t>(g) & 15) == 0) &&
+                    ((reinterpret_cast<uintptr_t>(out) & 15) == 0) && ((reinterpret_cast<uintptr_t>(dotw) & 15) == 0);
+    return al ? 4 : 1;
+}
+int db_chunks(int D, int cw) { return (D + 64 * cw - 1) / (64 * cw); }
+
+template <typename IdxT>
+int launch_decode_backward(const float *g, const IdxT *idx, long B, int N, int K, int D, float *out, long gsb, long gsn,
+                           int idx_stride, hipStream_t st, const float *sa = nullptr, const float *sb = nullptr, float sc = 1.0f,
+                           const float *dotw = nullptr, float *dot_part = nullptr) {
+    const int cw = db_cw(g, out, D, gsb, gsn, dotw), chunks = db_chunks(D, cw);
+    const long waves = (long)N * K * chunks;
+    const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+    if (cw == 4) hipLaunchKernelGGL((k_decode_backward<IdxT, 4>), grid, block, 0, st, g, idx, B, N, K, D, chunks, out, gsb, gsn, idx_stride, sa, sb, sc, dotw, dot_part);
+    else hipLaunchKernelGGL((k_decode_backward<IdxT, 1>), grid, block, 0, st, g, idx, B, N, K, D, chunks, out, gsb, gsn, idx_stride, sa, sb, sc, dotw, dot_part);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
 }  // namespace
 
 extern "C" {
@@ -601,36 +621,21 @@ int mcq_decode_backward(const float *grad_out, const int64_t *idx, long B, int N
                         void *stream) {
     if (N <= 0 || K <= 0 || D <= 0 || B < 0 || !gC) return MCQ_EINVAL;
     if (B > 0 && (!grad_out || !idx)) return MCQ_EINVAL;
-    const int chunks = (D + 63) / 64;
-    const long waves = (long)N * K * chunks;
-    hipLaunchKernelGGL((k_decode_backward<int64_t>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), grad_out, idx, B, N, K, D, chunks, gC, (long)D, 0L, N);
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? 0 : (int)e;
+    return launch_decode_backward<int64_t>(grad_out, idx, B, N, K, D, gC, (long)D, 0L, N, static_cast<hipStream_t>(stream));
 }
 
 int mcq_decode_backward_u8(const float *grad_out, const uint8_t *codes, long B, int N, int K, int D, float *gC,
                            void *stream) {
     if (N <= 0 || K <= 0 || K > 256 || D <= 0 || B < 0 || !gC) return MCQ_EINVAL;
     if (B > 0 && (!grad_out || !codes)) return MCQ_EINVAL;
-    const int chunks = (D + 63) / 64;
-    const long waves = (long)N * K * chunks;
-    hipLaunchKernelGGL((k_decode_backward<uint8_t>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), grad_out, codes, B, N, K, D, chunks, gC, (long)D, 0L, N);
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? 0 : (int)e;
+    return launch_decode_backward<uint8_t>(grad_out, codes, B, N, K, D, gC, (long)D, 0L, N, static_cast<hipStream_t>(stream));
 }
 
 int mcq_scatter_rows(const float *grad, long stride_b, long stride_n, const int64_t *idx, int idx_stride, long B, int N,
                      int K, int D, float *out, void *stream) {
     if (N <= 0 || K <= 0 || D <= 0 || B < 0 || !out || idx_stride < N) return MCQ_EINVAL;
     if (B > 0 && (!grad || !idx)) return MCQ_EINVAL;
-    const int chunks = (D + 63) / 64;
-    const long waves = (long)N * K * chunks;
-    hipLaunchKernelGGL((k_decode_backward<int64_t>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), grad, idx, B, N, K, D, chunks, out, stride_b, stride_n, idx_stride);
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? 0 : (int)e;
+    return launch_decode_backward<int64_t>(grad, idx, B, N, K, D, out, stride_b, stride_n, idx_stride, static_cast<hipStream_t>(stream));
 }
 
 int mcq_jcl_prefix_fwd(const float *hp, const float *emb, const int64_t *idx, long B, int N, int K, int H, float scale,
@@ -772,7 +777,7 @@ int mcq_recon_fwd(const float *x, const int64_t *idx, long B, const void *prepar
 // ------------------------------------------------------------ parameter update
 namespace {
 int wgrad_splits(long B, int M, int D) {
-    const long tiles = (long)((M + 63) / 64) * ((D + 63) / 64);
+    const long tiles = (long)((M + kWgM - 1) / kWgM) * ((D + kWgN - 1) / kWgN);
     long s = 2048 / tiles;                 // ~8 workgroups per CU
     const long max_s = (B + 127) / 128;    // at least 128 rows of the batch per split
     s = s > max_s ? max_s : s;
@@ -793,11 +798,11 @@ int mcq_weight_grad(const float *G, const float *x, long B, int M, int D, const 
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int splits = wgrad_splits(B, M, D);
     long rps = (B + splits - 1) / splits;
-    rps = (rps + 15) / 16 * 16;
+    rps = (rps + 31) / 32 * 32;
     float *part = static_cast<float *>(workspace);
     float *partb = part + (size_t)splits * M * D;
-    const unsigned grid = (unsigned)(((M + 63) / 64) * ((D + 63) / 64) * splits);
-    hipLaunchKernelGGL(k_wgrad_tn, dim3(grid), dim3(256), 0, st, G, x, B, M, D, rps, part, partb);
+    const unsigned grid = (unsigned)(((M + kWgM - 1) / kWgM) * ((D + kWgN - 1) / kWgN) * splits);
+    hipLaunchKernelGGL((k_wgrad_tn<16>), dim3(grid), dim3(256), 0, st, G, x, B, M, D, rps, part, partb);   // (32-row stages: 129 vs 115 us)
     MCQ_LAUNCH_CHECK();
     const long MN = (long)M * D;
     hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((MN / 4 + 255) / 256)), dim3(256), 0, st, part, partb, splits, MN, M,
@@ -837,19 +842,19 @@ int mcq_scales_exp(const float *centers_scale, const float *logits_scale, float 
 
 // decode_backward_u8 with the trainer's epilogue: rows scaled by sa[0]*sb[0]*sc (device floats), and per-wave partials
 // of <unscaled sums, dotw> in dot_part[mcq_decode_backward_waves(N, K, D)]
-long mcq_decode_backward_waves(int N, int K, int D) { return (long)N * K * ((D + 63) / 64); }
+long mcq_decode_backward_waves(int N, int K, int D) { return (long)N * K * db_chunks(D, (D & 3) == 0 ? 4 : 1); }
 
 int mcq_decode_backward_u8_ex(const float *grad_out, const uint8_t *codes, long B, int N, int K, int D, float *gC,
                               const float *sa, const float *sb, float sc, const float *dotw, float *dot_part, void *stream) {
     if (N <= 0 || K <= 0 || K > 256 || D <= 0 || B < 0 || !gC) return MCQ_EINVAL;
     if (B > 0 && (!grad_out || !codes)) return MCQ_EINVAL;
     if ((dotw == nullptr) != (dot_part == nullptr)) return MCQ_EINVAL;
-    const int chunks = (D + 63) / 64;
-    const long waves = (long)N * K * chunks;
-    hipLaunchKernelGGL((k_decode_backward<uint8_t>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), grad_out, codes, B, N, K, D, chunks, gC, (long)D, 0L, N, sa, sb, sc,
-                       dotw, dot_part);
-    MCQ_LAUNCH_CHECK();
+    // the caller sized dot_part by mcq_decode_backward_waves: the wide kernel must be the one that runs when D % 4 == 0
+    if ((D & 3) == 0 && db_cw(grad_out, gC, D, D, 0, dotw) != 4) return MCQ_EINVAL;     // misaligned buffers
+    const int rc = launch_decode_backward<uint8_t>(grad_out, codes, B, N, K, D, gC, (long)D, 0L, N, static_cast<hipStream_t>(stream),
+                                                   sa, sb, sc, dotw, dot_part);
+    if (rc) return rc;
+    ++g_last_launches;
     return 0;
 }
 

@@ -970,20 +970,25 @@ __global__ void k_decode_reg(const uint8_t *__restrict__ codes, long B, const fl
 // Matching rows are fetched eight at a time so the loads overlap; the adds stay in order.
 // Generalised to per-(vector, codebook) gradients: the value added for vector b into row (n, k) is
 // gout[b * gsb + n * gsn + d] (decode: gsb = D, gsn = 0); idx[b * idx_stride + n]; negative indexes match no row.
-template <typename IdxT>   // int64 indexes, or uint8 codes (8x less index traffic: the scan is what bounds this kernel)
+// CW = floats per lane: a wave covers 64 * CW features of its row, so the index column is scanned D / (64 CW) times per
+// row instead of D / 64 (CW = 4 with float4 loads when rows are 16-byte aligned: 45.7 -> see DESIGN.md, trainer).
+template <typename IdxT, int CW>   // int64 indexes, or uint8 codes (8x less index traffic: the scan is what bounds this kernel)
 __global__ void k_decode_backward(const float *__restrict__ gout, const IdxT *__restrict__ idx, long B, int N, int K,
                                   int D, int chunks, float *__restrict__ gC, long gsb, long gsn, int idx_stride,
                                   const float *__restrict__ sa = nullptr, const float *__restrict__ sb = nullptr, float sc = 1.0f,
                                   const float *__restrict__ dotw = nullptr, float *__restrict__ dot_part = nullptr) {
+    typedef float vecw __attribute__((ext_vector_type(CW)));
     const long w = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (w >= (long)N * K * chunks) return;
     const int lane = lane_id();
     const long row = w / chunks;
-    const int d = (int)(w % chunks) * 64 + lane;
+    const int d = ((int)(w % chunks) * 64 + lane) * CW;       // CW > 1: D is a multiple of CW
     const bool dok = d < D;
     const int dc = dok ? d : 0;
     const int n = (int)(row / K), k = (int)(row % K);
-    float acc = 0.f;
+    vecw acc;
+#pragma unroll
+    for (int c = 0; c < CW; ++c) acc[c] = 0.f;
     // index loads in flight per scan step: with 1-byte codes several steps' worth are fetched together (with
     // 8-byte indexes that floods the L1 with uncoalesced lines and measured slower)
     constexpr int SC = sizeof(IdxT) == 1 ? 8 : 1;
@@ -1000,14 +1005,15 @@ __global__ void k_decode_backward(const float *__restrict__ gout, const IdxT *__
             const bool hit = (b0 + lane < B) && (iv[q] == (long)k);
             unsigned long long m = __ballot(hit);
             while (m) {
-                float v[8];
+                vecw v[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    v[u] = 0.f;
+#pragma unroll
+                    for (int c = 0; c < CW; ++c) v[u][c] = 0.f;
                     if (m) {   // wave-uniform
                         const int l = __ffsll((long long)m) - 1;
                         m &= m - 1;
-                        v[u] = gout[(b0 + l) * gsb + n * gsn + dc];
+                        v[u] = *reinterpret_cast<const vecw *>(gout + (b0 + l) * gsb + n * gsn + dc);
                     }
                 }
 #pragma unroll
@@ -1018,9 +1024,14 @@ __global__ void k_decode_backward(const float *__restrict__ gout, const IdxT *__
     // optional epilogue (trainer): the stored rows are scaled by f = sa[0] * sb[0] * sc, and the wave's share of
     // <sum, dotw> (the UNscaled sums against another [N*K][D] table) goes to dot_part[w] for a fixed-order reduction
     const float f = (sa ? *sa : 1.0f) * (sb ? *sb : 1.0f) * sc;
-    if (dok) gC[row * D + d] = (sa || sb || sc != 1.0f) ? acc * f : acc;
+    if (dok) *reinterpret_cast<vecw *>(gC + row * D + d) = (sa || sb || sc != 1.0f) ? acc * f : acc;
     if (dot_part != nullptr) {
-        float pd = dok ? acc * dotw[row * D + d] : 0.f;
+        float pd = 0.f;
+        if (dok) {
+            const vecw wv = *reinterpret_cast<const vecw *>(dotw + row * D + d);
+#pragma unroll
+            for (int c = 0; c < CW; ++c) pd = pd + acc[c] * wv[c];
+        }
         pd = wave_sum_butterfly(pd);
         if (lane == 0) dot_part[w] = pd;
     }

@@ -197,15 +197,31 @@ k_recon_fwd(const float *__restrict__ x, const int64_t *__restrict__ idx, long B
     float pn = 0.f, pd = 0.f;
     if (b < B) {
         const int64_t *id = idx + b * N;
-        for (int d = lane; d < D; d += 64) {
-            float t = C[((long)0 * K + (int)(id[0] & (K - 1))) * Dp + d];
-            for (int n = 1; n < N; ++n) t = t + C[((long)n * K + (int)(id[n] & (K - 1))) * Dp + d];
-            const float xv = x[b * D + d];
-            const float e = t - xv;
-            err[b * D + d] = e;
-            pn = fmaf(e, e, pn);
-            const float c = xv - mean[d];
-            pd = fmaf(c, c, pd);
+        const bool vec = ((D & 3) == 0) && (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(err) |
+                                               reinterpret_cast<uintptr_t>(mean)) & 15) == 0);
+        if (vec) {                       // 16 bytes per lane and row piece: a quarter of the load instructions
+            for (int q = lane; q < D / 4; q += 64) {
+                f32x4 t = *reinterpret_cast<const f32x4 *>(C + ((long)0 * K + (int)(id[0] & (K - 1))) * Dp + 4 * q);
+                for (int n = 1; n < N; ++n)
+                    t = t + *reinterpret_cast<const f32x4 *>(C + ((long)n * K + (int)(id[n] & (K - 1))) * Dp + 4 * q);
+                const f32x4 xv = *reinterpret_cast<const f32x4 *>(x + b * D + 4 * q);
+                const f32x4 e = t - xv;
+                *reinterpret_cast<f32x4 *>(err + b * D + 4 * q) = e;
+                const f32x4 c = xv - *reinterpret_cast<const f32x4 *>(mean + 4 * q);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { pn = fmaf(e[i], e[i], pn); pd = fmaf(c[i], c[i], pd); }
+            }
+        } else {
+            for (int d = lane; d < D; d += 64) {
+                float t = C[((long)0 * K + (int)(id[0] & (K - 1))) * Dp + d];
+                for (int n = 1; n < N; ++n) t = t + C[((long)n * K + (int)(id[n] & (K - 1))) * Dp + d];
+                const float xv = x[b * D + d];
+                const float e = t - xv;
+                err[b * D + d] = e;
+                pn = fmaf(e, e, pn);
+                const float c = xv - mean[d];
+                pd = fmaf(c, c, pd);
+            }
         }
     }
     pn = wave_sum_butterfly(pn);

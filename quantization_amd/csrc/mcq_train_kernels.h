@@ -15,21 +15,24 @@ namespace mcq {
 // Both operands are contiguous along the OUTPUT axes and strided along the contraction axis b, so tiles go to LDS as
 // they lie in memory ([b][64 + pad] rows, ds_write_b128) and the MFMA fragments are ds_read_b32 along b: lane (r, g)
 // feeds row 4j + g of a 16-row block to MFMA j (rows stride 80 floats = 16 banks apart: the two half-waves of a read
-// hit 32 distinct banks).  Workgroup = 64 x 64 outputs, four waves of 32 x 32 (2 x 2 MFMA tiles), 16 rows of b per
-// stage, two LDS buffers, one barrier per stage.  Workgroups of one G column slab share an XCD (id = nt * MT + mt).
-constexpr int kWgStride = 80;       // floats per LDS row: 64 + 16
-constexpr int kWgStage = 16;        // rows of b per stage
+// hit 32 distinct banks).  Two LDS buffers, one barrier per stage.  Workgroups of one G column slab share an XCD
+// (id = nt * MT + mt).
+// Workgroup = 128 (m) x 64 (n) outputs, four waves of 64 x 32 (4 x 2 MFMA tiles), ST rows of b per stage.
+constexpr int kWgM = 128, kWgN = 64;
+constexpr int kWgStrideA = kWgM + 16, kWgStrideB = kWgN + 16;     // floats per LDS row (stride = 16 mod 32 banks)
 
 // The batch axis is cut into `splits` ranges (split-K): workgroup (tile, split) writes its partial tile to
 // part[split][M][Nf] (and partial column sums to partb[split][M]); k_wgrad_reduce adds the splits in ascending order and
-// applies s.  With 64 x 64 tiles alone a 2048 x 512 gradient is 256 workgroups of 256 serial stages each; eight splits
-// put 8 workgroups on every CU and hide the stage latency.
+// applies s.  With tiles alone a 2048 x 512 gradient is 128 workgroups of hundreds of serial stages each; sixteen
+// splits put 8 workgroups on every CU and hide the stage latency.
+template <int ST>
 __global__ void __launch_bounds__(256)
 k_wgrad_tn(const float *__restrict__ G /*[B][M]*/, const float *__restrict__ X /*[B][Nf]*/, long B, int M, int Nf,
            long rows_per_split, float *__restrict__ gW /*part [splits][M][Nf]*/, float *__restrict__ gb /*partb [splits][M]*/) {
-    __shared__ __attribute__((aligned(16))) float lds[2][2][kWgStage * kWgStride];   // [buffer][A | B][row b][col]
-    __shared__ float colsum[16][64];
-    const int MT = (M + 63) / 64, NT = (Nf + 63) / 64;
+    __shared__ __attribute__((aligned(16))) float ldsA[2][ST * kWgStrideA];   // [buffer][row b][col m]
+    __shared__ __attribute__((aligned(16))) float ldsB[2][ST * kWgStrideB];   // [buffer][row b][col n]
+    __shared__ float colsum[8][kWgM];
+    const int MT = (M + kWgM - 1) / kWgM, NT = (Nf + kWgN - 1) / kWgN;
     const int tile = blockIdx.x % (MT * NT), split = blockIdx.x / (MT * NT);
     const int mt = tile % MT, nt = tile / MT;
     G += split * rows_per_split * M;
@@ -37,38 +40,56 @@ k_wgrad_tn(const float *__restrict__ G /*[B][M]*/, const float *__restrict__ X /
     B = (B - split * rows_per_split < rows_per_split) ? B - split * rows_per_split : rows_per_split;
     gW += (size_t)split * M * Nf;
     gb += (size_t)split * M;
-    const int m0 = 64 * mt, n0 = 64 * nt;
+    const int m0 = kWgM * mt, n0 = kWgN * nt;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave & 1, wn = wave >> 1;
     const int r = lane & 15, g = lane >> 4;
-    // staging: thread t moves the float4 at row (t / 16) of the stage, columns 4 * (t % 16) .. +3, of both tiles
-    const int srow = tid >> 4, scol = 4 * (tid & 15);
-    const bool acol_ok = m0 + scol < M;           // M = N*K is a multiple of 16
+    // staging: A tile rows of 32 float4 -> thread t moves float4 (t % 32) of rows t / 32 + 8 j; B tile rows of 16 float4 ->
+    // float4 (t % 16) of rows t / 16 + 16 j
+    constexpr int NA = ST / 8, NB = ST / 16;
+    const int arow = tid >> 5, acol = 4 * (tid & 31);
+    const int brow = tid >> 4, bcol = 4 * (tid & 15);
+    const bool acol_ok = m0 + acol < M;           // M = N*K is a multiple of 16
     const bool xvec = (Nf & 3) == 0;              // rows of x are 16-byte aligned
-    f32x4 acc[2][2];
+    f32x4 acc[4][2];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int u = 0; u < 2; ++u) acc[t][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
     f32x4 csum = {0.f, 0.f, 0.f, 0.f};
-    const long nst = (B + kWgStage - 1) / kWgStage;
-    f32x4 ra, rb;
+    const long nst = (B + ST - 1) / ST;
+    f32x4 ra[NA], rb[NB];
     auto load = [&](long st) {
-        const long b = st * kWgStage + srow;
-        const long bc = b < B ? b : B - 1;
-        ra = acol_ok ? *reinterpret_cast<const f32x4 *>(G + bc * M + m0 + scol) : (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (xvec) {
-            rb = (n0 + scol < Nf) ? *reinterpret_cast<const f32x4 *>(X + bc * Nf + n0 + scol) : (f32x4){0.f, 0.f, 0.f, 0.f};
-        } else {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) rb[c] = (n0 + scol + c < Nf) ? X[bc * Nf + n0 + scol + c] : 0.f;
+        for (int j = 0; j < NA; ++j) {
+            const long b = st * ST + arow + 8 * j;
+            const long bc = b < B ? b : B - 1;
+            ra[j] = (acol_ok && b < B) ? *reinterpret_cast<const f32x4 *>(G + bc * M + m0 + acol) : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-        if (b >= B) { ra = (f32x4){0.f, 0.f, 0.f, 0.f}; rb = ra; }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const long b = st * ST + brow + 16 * j;
+            const long bc = b < B ? b : B - 1;
+            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (b < B) {
+                if (xvec) {
+                    if (n0 + bcol < Nf) v = *reinterpret_cast<const f32x4 *>(X + bc * Nf + n0 + bcol);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] = (n0 + bcol + c < Nf) ? X[bc * Nf + n0 + bcol + c] : 0.f;
+                }
+            }
+            rb[j] = v;
+        }
     };
     auto store = [&](int buf) {
-        *reinterpret_cast<f32x4 *>(&lds[buf][0][srow * kWgStride + scol]) = ra;
-        *reinterpret_cast<f32x4 *>(&lds[buf][1][srow * kWgStride + scol]) = rb;
-        csum = csum + ra;                       // rows b = srow (mod 16) of this thread's four columns, b ascending
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            *reinterpret_cast<f32x4 *>(&ldsA[buf][(arow + 8 * j) * kWgStrideA + acol]) = ra[j];
+            csum = csum + ra[j];                    // rows b = arow (mod 8) of this thread's four columns, b ascending
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) *reinterpret_cast<f32x4 *>(&ldsB[buf][(brow + 16 * j) * kWgStrideB + bcol]) = rb[j];
     };
     load(0);
     store(0);
@@ -76,16 +97,16 @@ k_wgrad_tn(const float *__restrict__ G /*[B][M]*/, const float *__restrict__ X /
     if (nst > 1) load(1);
     for (long st = 0; st < nst; ++st) {
         const int buf = (int)(st & 1);
-        const float *A = lds[buf][0], *Bt = lds[buf][1];
+        const float *A = ldsA[buf], *Bt = ldsB[buf];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float a[2], b[2];
+        for (int j = 0; j < ST / 4; ++j) {
+            float a[4], b[2];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) a[t] = A[(4 * j + g) * kWgStride + 32 * wm + 16 * t + r];
+            for (int t = 0; t < 4; ++t) a[t] = A[(4 * j + g) * kWgStrideA + 64 * wm + 16 * t + r];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) b[u] = Bt[(4 * j + g) * kWgStride + 32 * wn + 16 * u + r];
+            for (int u = 0; u < 2; ++u) b[u] = Bt[(4 * j + g) * kWgStrideB + 32 * wn + 16 * u + r];
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int u = 0; u < 2; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[u], acc[t][u], 0, 0, 0);
         }
@@ -93,29 +114,28 @@ k_wgrad_tn(const float *__restrict__ G /*[B][M]*/, const float *__restrict__ X /
         __syncthreads();
         if (st + 2 < nst) load(st + 2);
     }
-    const float s = 1.0f;
-    // lane holds rows m = 32 wm + 16 t + 4 g + v, column n = 32 wn + 16 u + r
+    // lane holds rows m = 64 wm + 16 t + 4 g + v, column n = 32 wn + 16 u + r
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int n = n0 + 32 * wn + 16 * u + r;
             if (n < Nf) {
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
-                    const int m = m0 + 32 * wm + 16 * t + 4 * g + v;
-                    if (m < M) gW[(long)m * Nf + n] = s * acc[t][u][v];
+                    const int m = m0 + 64 * wm + 16 * t + 4 * g + v;
+                    if (m < M) gW[(long)m * Nf + n] = acc[t][u][v];
                 }
             }
         }
-    if (nt == 0) {     // column sums of this G slab: the 16 row classes are added in order
+    if (nt == 0) {     // column sums of this G slab: the 8 row classes are added in order
 #pragma unroll
-        for (int c = 0; c < 4; ++c) colsum[srow][scol + c] = csum[c];
+        for (int c = 0; c < 4; ++c) colsum[arow][acol + c] = csum[c];
         __syncthreads();
-        if (tid < 64) {
+        if (tid < kWgM) {
             float t = colsum[0][tid];
 #pragma unroll
-            for (int q = 1; q < 16; ++q) t = t + colsum[q][tid];
+            for (int q = 1; q < 8; ++q) t = t + colsum[q][tid];
             if (m0 + tid < M) gb[m0 + tid] = t;
         }
     }
