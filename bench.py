@@ -30,6 +30,8 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+PEAK_I8_MFMA_TOPS = 5033.0     # 2 x the dense bf16 peak (MI355X_MICROARCH.md: i8 = 2x bf16 rate; 256 CU x 4 SIMD x 2048 op/clk x 2.4 GHz)
+LIMB_PRODUCTS = 10             # i8 MFMA products per fixed-point product step (mcq_fix_kernels.h)
 PEAK_HBM_GBPS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec
 NEAR_TIE = 2e-6                # tests/golden/fixtures.py
 
@@ -57,7 +59,8 @@ def reference_flops_per_vector(D, N, K, iters):
 
 def kernel_work(B, D, N, K):
     """Per launch of each kernel category of mcq_profile_encode (in its order): (name, launches per encode as
-    'once' | 'pass', algorithmic FLOPs, algorithmic HBM bytes, table bytes).  The two GEMMs are the only MFMA work.  A
+    'once' | 'pass', multiply-adds x 2 of the product it forms, algorithmic HBM bytes, table bytes).  The two products (logits,
+    x.C) are the only matrix-core work: exact fixed-point products, ten i8 MFMA limb products per multiply-add.  A
     table kernel's HBM bytes are what it must exchange with memory (per-vector inputs, lists and tables written);
     its table bytes are the 4-byte Gram entries / Gram row segments it reads, which an XCD's L2 serves (the Gram matrix is
     resident state: 16 MB at 8 x 256)."""
@@ -66,10 +69,11 @@ def kernel_work(B, D, N, K):
     leaf = (kc[0] * kc[0] + 2 * kc[0] + 1) * 4.0           # one full leaf table's Gram reads (x 0.3 below: the lazy
     # level-1 tables read ~ 85 of the 289 entries)
     lists0 = 2 * kc[0] * 5.0                               # two level-0 lists read (entry + score)
-    cats = [("logits_gemm_argmax", "once", gemm, B * (D * 4.0 + N), 0.0),
-            ("x_sumsq", "once", 0.0, B * (D * 4.0 + 4), 0.0),
+    dq = (D + 127) // 128 * 128
+    cats = [("logits_product_argmax", "once", gemm, B * (dq * 4.0 + N), 0.0),
+            ("frames_to_limbs", "once", 0.0, B * (D * 4.0 + dq * 4.0 + 8), 0.0),
             ("stage0_tables", "pass", 0.0, B * N * (K * 4.0 + kc[0] * 5.0 + 5), B * N * N * K * 4.0),
-            ("xc_gemm", "once", gemm, B * (D * 4.0 + N * K * 4.0), 0.0),
+            ("xc_product", "once", gemm, B * (dq * 4.0 + N * K * 4.0), 0.0),
             ("combine_level0", "pass", 0.0, B * (N / 2) * (lists0 + kc[1] * 6.0), B * (N / 2) * leaf),
             ("combine_level1", "pass", 0.0, B * (N / 4) * (2 * lists0 + 2 * kc[1] * 6.0 + kc[2] * 6.0), B * (N / 4) * 4 * leaf * 0.3),
             ("tables_level1", "pass", 0.0, B * 4 * (N / 8) * (2 * lists0 + 2 * kc[1] * 6.0 + kc[1] * kc[1] * 4.0), B * 4 * (N / 8) * 4 * leaf * 0.3),
@@ -309,7 +313,10 @@ def main():
                          "ms_per_encode": round(float(acc[i]), 3)}
         if fl > 0:
             tf_ = fl / (avg_ms * 1e-3) / 1e12
-            kernels[name].update(gflop_per_launch=round(fl / 1e9, 2), tflops=round(tf_, 2), frac_of_f32_mfma_peak=round(tf_ / PEAK_F32_MFMA_TFLOPS, 4))
+            kernels[name].update(gflop_per_launch=round(fl / 1e9, 2), f32_equivalent_tflops=round(tf_, 2),
+                                 f32_equivalent_frac_of_f32_mfma_peak=round(tf_ / PEAK_F32_MFMA_TFLOPS, 4),
+                                 i8_tops=round(LIMB_PRODUCTS * tf_, 1), frac_of_i8_mfma_peak=round(LIMB_PRODUCTS * tf_ / PEAK_I8_MFMA_TOPS, 4),
+                                 hbm_gbyte_per_launch=round(by / 1e9, 3))
         else:
             kernels[name].update(hbm_gbyte_per_launch=round(by / 1e9, 3), hbm_gbytes_per_s=round(by / (avg_ms * 1e-3) / 1e9, 1))
             if tb > 0:
@@ -328,11 +335,13 @@ def main():
             traffic_note = ("bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 of kernel %s, profiles/r02_pmc_traffic.json"
                             % pmc[dom_name]["kernel"])
     if dom_fl > 0:
-        achieved = dom_fl / (dom_ms * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-                    "traffic_note": traffic_note, "gflop_per_launch": round(dom_fl / 1e9, 2),
-                    "avg_launch_ms": round(float(dom_ms), 4)}
+        achieved = LIMB_PRODUCTS * dom_fl / (dom_ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 1), "peak": PEAK_I8_MFMA_TOPS,
+                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_I8_MFMA_TOPS, 4), "traffic": traffic,
+                    "traffic_note": traffic_note, "gop_per_launch": round(LIMB_PRODUCTS * dom_fl / 1e9, 2),
+                    "avg_launch_ms": round(float(dom_ms), 4),
+                    "note": "i8 MFMA operations (ten limb products per multiply-add of the exact fixed-point product) against "
+                            "the dense i8 peak; unit reads TOP/s"}
     else:
         achieved = dom_by / (dom_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": PEAK_HBM_GBPS,
@@ -343,11 +352,11 @@ def main():
                     "table_gbytes_per_s_from_l2": round(dom_tb / (dom_ms * 1e-3) / 1e9, 1),
                     "note": "a table kernel: no FLOPs to price.  `achieved` prices the bytes it must exchange with HBM (per-vector "
                             "inputs, lists written); what bounds it is the L2 -> L1 fabric that carries the Gram row segments "
-                            "(table_*: measured ceiling 17-25 TB/s for such pieces, DESIGN.md section 5).  The two GEMMs (same "
-                            "kernel template, 33 % of an encode together) are in `kernels` with their fraction of the fp32-MFMA peak"}
+                            "(table_*: measured ceiling 17-25 TB/s for such pieces, DESIGN.md section 5).  The two matrix-core products "
+                            "(logits, x.C) are in `kernels` with their fraction of the i8-MFMA peak"}
 
     fpv = reference_flops_per_vector(D, N, K, iters)
-    exec_fpv = 2 * 2.0 * D * N * K          # the logits and x.C GEMMs only
+    exec_fpv = 2 * 2.0 * D * N * K          # the logits and x.C products only (each multiply-add = ten i8 limb products)
     value = world * B * args.steps / dt
     out = {
         "metric": "vectors encoded/sec at dim=512, 8 codebooks; uint8 codes bit-exact vs ref",
@@ -359,12 +368,14 @@ def main():
                                f"(BASELINE.json configs[1]), seeded synthetic codebooks",
                    "global_batch": world * B, "parallelism": f"batch-sharded x{world}, no collective"},
         "parity": parity,
-        "whole_encode": {"reference_flop_per_vector": fpv, "executed_mfma_flop_per_vector": exec_fpv,
+        "whole_encode": {"reference_flop_per_vector": fpv, "executed_product_flop_per_vector": exec_fpv,
+                         "executed_i8_mfma_op_per_vector": LIMB_PRODUCTS * exec_fpv,
                          "reference_tflops": round(value / world * fpv / 1e12, 2),
                          "frac_of_f32_mfma_peak": round(value / world * fpv / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                          "note": "reference_* prices the matmul FLOPs of the reference algorithm (SURVEY.md 8d: 6.12 M "
-                                 "vectors/s at the fp32-MFMA peak); the table form executes only the logits and x.C GEMMs "
-                                 "and reads the other inner products from the Gram matrix, so this fraction can exceed 1"},
+                                 "vectors/s at the fp32-MFMA peak); the table form executes only the logits and x.C products -- as exact "
+                                 "fixed-point products on the i8 matrix cores -- and reads the other inner products from the "
+                                 "Gram matrix, so this fraction can exceed 1"},
         "roofline": roofline,
         "kernels": kernels,
     }

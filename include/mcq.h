@@ -22,13 +22,18 @@
  *  - supported domain: codebook_size K a power of two in [16, 256], num_codebooks N
  *    a power of two, N <= 64 for K == 16 and N <= 32 for K >= 32 (what the reference's
  *    trainer can produce: bytes_per_frame <= 32, quantization/quantization.py:614), any
- *    dim D >= 1 (rows are zero-padded to a multiple of 16 inside `prepared`).  The reference crashes for K < 16
+ *    dim 1 <= D <= 16384 (rows are zero-padded to a multiple of 16 inside `prepared`; the i32 accumulators
+ *    of the fixed-point products bound D).  The reference crashes for K < 16
  *    (quantization/quantization.py:506) and needs K <= 256 for byte output (:271).
  *
- * Numerics: bit-identical to oracle/mcq_oracle.c (see its header for the spec:
- * v_mfma_f32_16x16x4_f32 k-order fmaf chains, wave64 butterfly reductions; the
- * refinement passes read their inner products from the Gram matrix of the centers
- * kept in `prepared` and from one x.C GEMM per call: the TABLE FORM).
+ * Numerics: bit-identical to oracle/mcq_oracle.c (see its header for the spec).  The
+ * three inner-product tables of the path -- the logits, x.C and the Gram matrix of the
+ * centers -- are EXACT fixed-point products ("fixdot": rows as 30-bit fixed point against
+ * their own largest magnitude, ten 8-bit limb products on the i8 matrix cores, one defined
+ * fp32 combination): nothing in them depends on a summation order.  Sums of squares are
+ * wave64 butterfly reductions; the refinement passes read their inner products from the
+ * Gram matrix kept in `prepared` and from one x.C product per call (the TABLE FORM).
+ * Non-finite inputs are outside the contract (the reference returns arbitrary codes for them).
  */
 #ifndef MCQ_H
 #define MCQ_H
@@ -44,7 +49,9 @@ extern "C" {
 #define MCQ_EUNSUPPORTED (-2) /* outside the supported (K, N) domain             */
 #define MCQ_EWORKSPACE (-3) /* workspace smaller than mcq_encode_workspace_bytes */
 
-#define MCQ_ABI_VERSION 3   /* 3: `prepared` also holds the Gram matrix (mcq_prepared_bytes grew) */
+#define MCQ_ABI_VERSION 4   /* 4: fixed-point products: `prepared` holds limb planes of the centers and the classifier
+                               (mcq_prepared_bytes changed), workspaces hold those of the frames (the workspace sizes
+                               depend on D), mcq_logits takes a workspace, mcq_logits_workspace_bytes is new */
 int mcq_abi_version(void);
 
 /* D rounded up to the padded row length used inside `prepared` and workspaces. */
@@ -54,9 +61,10 @@ int mcq_padded_dim(int D);
  * Replaces Quantizer.get_centers() (quantization/quantization.py:77-79, recomputed
  * on every call there) and the parameter reads of Quantizer._logits (:277-279).
  * `prepared` receives: scaled centers C[N][K][Dp] = cscale_exp * centers, their
- * sum of squares Q[N][K] (:411), to_logits.weight padded to Dp and the bias, and -- when
- * weight is given -- the Gram matrix G[N*K][N*K] of the scaled centers (16 MB at 8 x 256;
- * what the refinement passes read).
+ * sum of squares Q[N][K] (:411), the centers and the rows of to_logits.weight as 8-bit limb
+ * planes with their row exponents (the operands of the fixed-point products), the bias, and
+ * -- when weight is given -- the Gram matrix G[N*K][N*K] of the scaled centers (16 MB at
+ * 8 x 256; what the refinement passes read).
  * cscale_exp / lscale_exp = exp(10*centers_scale) / exp(10*logits_scale), formed
  * by the caller in fp32 exactly as the reference does (:78, :278).
  * weight/bias may be NULL when only decode is needed.                          */
@@ -131,7 +139,7 @@ int mcq_decode_backward(const float *grad_out, const int64_t *idx, long B, int N
  *
  * mcq_logits_argmax: logits fp32 [B][N*K] of Quantizer._logits (:277-279) AND their per-codebook
  * first-maximum argmax int64 [B][N] (:301) from one GEMM; the indexes then go through
- * mcq_refine_indexes.  workspace >= B*N bytes.  flags: MCQ_ENCODE_LSCALE_FROM_PREPARED, MCQ_ENCODE_X_FP16. */
+ * mcq_refine_indexes.  workspace >= mcq_logits_workspace_bytes(B, N, D).  flags: MCQ_ENCODE_LSCALE_FROM_PREPARED, MCQ_ENCODE_X_FP16. */
 int mcq_logits_argmax(const float *x, long B, const void *prepared, float lscale_exp, int N, int K, int D,
                       float *logits_out, int64_t *argmax_out, void *workspace, size_t workspace_bytes,
                       void *stream, unsigned flags);
@@ -228,8 +236,9 @@ int mcq_decode_backward_u8(const float *grad_out, const uint8_t *codes, long B, 
 /* ---- test / profiling hooks -------------------------------------------------
  * Logits of Quantizer._logits (:277-279) for a batch, fp32 [B][N*K]; used by the
  * parity tests to localise a divergence.                                       */
+size_t mcq_logits_workspace_bytes(long B, int N, int D);   /* also what mcq_logits_argmax needs */
 int mcq_logits(const float *x, long B, const void *prepared, float lscale_exp, int N, int K, int D,
-               float *out, void *stream);
+               float *out, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Name and launch count of the kernels enqueued by the last mcq_encode on this
  * thread (for bench.py's per-kernel HIP-event timing); returns the count.      */

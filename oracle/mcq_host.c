@@ -31,7 +31,7 @@ typedef struct {
 
 static int is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 static int domain_ok(int N, int K, int D) {
-    return is_pow2(K) && K >= 16 && K <= 256 && is_pow2(N) && N <= (K == 16 ? 64 : 32) && D >= 1;
+    return is_pow2(K) && K >= 16 && K <= 256 && is_pow2(N) && N <= (K == 16 ? 64 : 32) && D >= 1 && D <= 16384;
 }
 static int domain_err(int N, int K) { return (K < 16 || K > 256 || N > (K == 16 ? 64 : 32)) ? MCQ_EUNSUPPORTED : MCQ_EINVAL; }
 
@@ -155,8 +155,8 @@ int mcq_decode_host(const void *codes, int code_bytes, int codes_per_row, long B
 }
 
 int mcq_logits_host(const float *x, long B, const void *prepared, float lscale_exp, int N, int K, int D,
-                    float *out, void *stream) {
-    (void)stream;
+                    float *out, void *workspace, size_t workspace_bytes, void *stream) {
+    (void)stream; (void)workspace; (void)workspace_bytes;
     if (!domain_ok(N, K, D)) return MCQ_EUNSUPPORTED;
     if (B == 0) return 0;
     if (!x || !prepared || !out || B < 0) return MCQ_EINVAL;

@@ -28,7 +28,7 @@ int mcq_refine_indexes_host(const float *x, long B, const void *prepared, int N,
 int mcq_decode_host(const void *codes, int code_bytes, int codes_per_row, long B, const void *prepared,
                     int N, int K, int D, float *out, void *stream);
 int mcq_logits_host(const float *x, long B, const void *prepared, float lscale_exp, int N, int K, int D,
-                    float *out, void *stream);
+                    float *out, void *workspace, size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

@@ -22,10 +22,17 @@
  *
  * Numeric specification (this IS the spec the HIP kernels match bit-for-bit):
  *   Dp      = D rounded up to a multiple of 16, zero padded.
- *   dot16   = one fp32 fmaf chain, accumulator starting at +0, over k in the
- *             order  for blk: for i in 0..3: for g in 0..3: k = 16*blk + 4*g + i
- *             (the order a v_mfma_f32_16x16x4_f32 chain consumes k when lane
- *             (r, g) holds the float4 at 16*blk + 4*g).
+ *   fixdot  = the inner product of two rows held as 30-bit fixed point, formed EXACTLY in integers (no summation
+ *             order to specify; the kernels form it on the i8 MFMA):
+ *               e(v)  = max(biased exponent of max_k |v[k]|, 1) - 126, so max|v| < 2^e   (the row exponent)
+ *               q[k]  = (int) rintf(min(max(ldexpf(v[k], 30 - e), -2^30), 2^30))  (exact for elements >= 2^-6 of the max)
+ *               q     = l0*2^24 + l1*2^16 + l2*2^8 + l3, l3, l2, l1 the balanced signed bytes of q ([-128, 127]), l0 the rest
+ *               T_s   = sum_k sum_{i+j=s} la_i[k] * lb_j[k],  s = 0..3   (ten limb products, exact integers; those of
+ *                       weight 2^-32 and less against the leading one, i + j >= 4, are dropped)
+ *               t     = fmaf(T_0, 2^24, fmaf(T_1, 2^16, fmaf(T_2, 2^8, (float)T_3)))  (each (float)T_s rounds to nearest even)
+ *               fixdot(a, b) = ldexpf(t, e(a) + e(b) - 36)
+ *             Its error against the real inner product is about 2^-28 max|a| max|b| per term: below that of an fp32
+ *             fmaf chain, which is what the reference's own GEMMs carry.
  *   sumsq64 = 64 partial fmaf chains, partial l over the float4 groups q with
  *             (q mod 64) == l in increasing q, then the xor butterfly
  *             p[l] += p[l^m] for m = 32,16,8,4,2,1 (a wave64 reduction).
@@ -35,8 +42,8 @@
  * linear in codebook rows (:403-416, :533-535); here they are READ from two tables (SURVEY.md section 7 "hard
  * parts"; gate runs against every reference fixture: tools/exp_gram/results_r02.txt and
  * DESIGN.md section 2 -- the codes equal those of a direct restatement, which round 1 shipped, on all 58,880 cases):
- *   G[r][c]  = dot16(C[r], C[c])        Gram matrix of all N*K scaled centers (per state)
- *   XC[b][r] = dot16(C[r], x[b])        one GEMM per encode call (x zero padded, unscaled)
+ *   G[r][c]  = fixdot(C[r], C[c])        Gram matrix of all N*K scaled centers (per state)
+ *   XC[b][r] = fixdot(C[r], x[b])        one GEMM per encode call (x zero padded, unscaled)
  *   E, R:     x_err = sum_m o_m - x (o_m the current rows; :338-340), so with xx = sumsq64(x):
  *             E = (sum_{m,m'} G[o_m][o_m'] - 2 sum_m XC[b][o_m]) + xx      (both sums added as one wave adds them),
  *             R[n] = (E - 2 ((G[o_0][o_n] + ... + G[o_{N-1}][o_n]) - XC[b][o_n])) + G[o_n][o_n]    (:401-409);
@@ -65,13 +72,14 @@
 typedef struct {
     int N, K, D, Dp;
     float *C;      /* [N][K][Dp]   scaled centers, zero padded            */
-    float *CT;     /* [N][Dp][K]   row i = column order16[i] of C[n]      */
+    int8_t *Cl;    /* [N*K][4][Dp] limbs l0..l3 of the fixed-point centers  */
+    int *Ce;       /* [N*K]        row exponents                           */
     float *Q;      /* [N][K]       sumsq64 of each scaled center          */
-    float *WT;     /* [Dp][N*K]    to_logits.weight, chain order, padded  */
+    int8_t *Wl;    /* [N*K][4][Dp] limbs of the to_logits.weight rows      */
+    int *We;       /* [N*K]                                               */
     float *bias;   /* [N*K]                                               */
     float lscale;  /* exp(10*logits_scale), computed by the caller        */
-    int *order16;  /* [Dp]                                                */
-    float *G;      /* [N*K][N*K]   dot16(C[r], C[c]); built on first use  */
+    float *G;      /* [N*K][N*K]   fixdot(C[r], C[c]); built on first use  */
 } mcq_oracle;
 
 static int round_up16(int d) { return (d + 15) & ~15; }
@@ -92,44 +100,87 @@ static float sumsq64(const float *v, int Dp) {
     return p[0];
 }
 
+
+/* ---------------------------------------------------------------- fixdot */
+static int row_exponent(const float *v, int n) {
+    float m = 0.0f;
+    for (int k = 0; k < n; k++) m = fmaxf(m, fabsf(v[k]));
+    uint32_t bits; memcpy(&bits, &m, 4);
+    int be = (int)((bits >> 23) & 0xff);
+    return (be < 1 ? 1 : be) - 126;
+}
+
+static int32_t fix_q(float v, int e) {
+    float s = ldexpf(v, 30 - e);
+    s = fminf(fmaxf(s, -1073741824.0f), 1073741824.0f);
+    return (int32_t)rintf(s);
+}
+
+/* limbs l[0..3], most significant first */
+static void fix_split(int32_t q, int8_t l[4]) {
+    int32_t r = q;
+    for (int i = 3; i >= 1; i--) { l[i] = (int8_t)(r & 0xff); r = (r - l[i]) >> 8; }
+    l[0] = (int8_t)r;
+}
+
+/* rows [R][n valid of Dp] -> limb planes [R][4][Dp] and exponents */
+static void fix_rows(const float *v, size_t R, int stride, int Dp, int8_t *L, int *E) {
+    for (size_t r = 0; r < R; r++) {
+        const float *row = v + r * stride;
+        const int e = row_exponent(row, stride < Dp ? stride : Dp);
+        E[r] = e;
+        for (int k = 0; k < Dp; k++) {
+            int8_t l[4];
+            fix_split(k < stride ? fix_q(row[k], e) : 0, l);
+            for (int i = 0; i < 4; i++) L[(r * 4 + i) * Dp + k] = l[i];
+        }
+    }
+}
+
+static float fixdot(const int8_t *la /*[4][Dp]*/, int ea, const int8_t *lb /*[4][Dp]*/, int eb, int Dp) {
+    int32_t T[4] = {0, 0, 0, 0};
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; i + j < 4; j++) {
+            const int8_t *a = la + (size_t)i * Dp, *b = lb + (size_t)j * Dp;
+            int32_t t = 0;
+            for (int k = 0; k < Dp; k++) t += (int32_t)a[k] * (int32_t)b[k];
+            T[i + j] += t;
+        }
+    float t = (float)T[3];
+    t = fmaf((float)T[2], 256.0f, t);
+    t = fmaf((float)T[1], 65536.0f, t);
+    t = fmaf((float)T[0], 16777216.0f, t);
+    return ldexpf(t, ea + eb - 36);
+}
+
 mcq_oracle *mcq_oracle_create(const float *centers, float cscale_exp, const float *W,
                               const float *bias, float lscale_exp, int N, int K, int D) {
     mcq_oracle *o = (mcq_oracle *)calloc(1, sizeof(mcq_oracle));
     int Dp = round_up16(D);
     o->N = N; o->K = K; o->D = D; o->Dp = Dp; o->lscale = lscale_exp;
-    o->order16 = (int *)malloc(sizeof(int) * Dp);
-    for (int i = 0; i < Dp; i++) {
-        int blk = i / 16, w = i % 16;
-        o->order16[i] = 16 * blk + 4 * (w % 4) + (w / 4);
-    }
     size_t nk = (size_t)N * K;
     o->C = (float *)calloc(nk * Dp, sizeof(float));
-    o->CT = (float *)calloc(nk * Dp, sizeof(float));
+    o->Cl = (int8_t *)calloc(nk * 4 * Dp, 1);
+    o->Ce = (int *)calloc(nk, sizeof(int));
     o->Q = (float *)calloc(nk, sizeof(float));
     /* get_centers(): exp(centers_scale * 10) * centers   (:77-79) */
     for (size_t r = 0; r < nk; r++)
         for (int d = 0; d < D; d++) o->C[r * Dp + d] = cscale_exp * centers[r * D + d];
     for (size_t r = 0; r < nk; r++) o->Q[r] = sumsq64(o->C + r * Dp, Dp);  /* (:411) */
-    for (int n = 0; n < N; n++)
-        for (int i = 0; i < Dp; i++)
-            for (int k = 0; k < K; k++)
-                o->CT[((size_t)n * Dp + i) * K + k] = o->C[((size_t)n * K + k) * Dp + o->order16[i]];
+    fix_rows(o->C, nk, Dp, Dp, o->Cl, o->Ce);
     if (W) {
-        o->WT = (float *)calloc(nk * Dp, sizeof(float));
+        o->Wl = (int8_t *)calloc(nk * 4 * Dp, 1);
+        o->We = (int *)calloc(nk, sizeof(int));
         o->bias = (float *)malloc(nk * sizeof(float));
         memcpy(o->bias, bias, nk * sizeof(float));
-        for (int i = 0; i < Dp; i++) {
-            int d = o->order16[i];
-            if (d >= D) continue;
-            for (size_t r = 0; r < nk; r++) o->WT[(size_t)i * nk + r] = W[r * D + d];
-        }
+        fix_rows(W, nk, D, Dp, o->Wl, o->We);
     }
     return o;
 }
 
 void mcq_oracle_free(mcq_oracle *o) {
     if (!o) return;
-    free(o->C); free(o->CT); free(o->Q); free(o->WT); free(o->bias); free(o->order16); free(o->G); free(o);
+    free(o->C); free(o->Cl); free(o->Ce); free(o->Q); free(o->Wl); free(o->We); free(o->bias); free(o->G); free(o);
 }
 
 /* copy of the scaled centers (N,K,D) and their sumsq, for tests */
@@ -199,22 +250,28 @@ static void scratch_alloc(scratch *s, int N, int K, int Dp) {
 
 static void scratch_free(scratch *s) { free(s->xpad); free(s->S); free(s->pos); }
 
+/* the frame as fixed point: limbs [4][Dp] and its exponent (shared by the logits and the x.C products) */
+static int frame_limbs(const mcq_oracle *o, const float *x, int8_t *xl) {
+    int e;
+    fix_rows(x, 1, o->D, o->Dp, xl, &e);
+    return e;
+}
+
+/* logits (:277-279) of one frame: (fixdot(x, W[r]) * exp(logits_scale)) + bias[r] */
+static void frame_logits(const mcq_oracle *o, const int8_t *xl, int xe, float *out) {
+    const size_t nk = (size_t)o->N * o->K;
+    for (size_t r = 0; r < nk; r++)
+        out[r] = fixdot(xl, xe, o->Wl + r * 4 * o->Dp, o->We[r], o->Dp) * o->lscale + o->bias[r];
+}
+
 /* A.1: initial indexes from the logits (:297-301) */
-static void init_indexes(const mcq_oracle *o, const float *x, uint8_t *idx, float *acc /*[N*K]*/,
-                         float *sx /*[Dp]*/) {
-    int N = o->N, K = o->K, D = o->D, Dp = o->Dp;
-    size_t nk = (size_t)N * K;
-    for (int d = 0; d < Dp; d++) sx[d] = (d < D) ? o->lscale * x[d] : 0.0f;  /* (:278) */
-    for (size_t r = 0; r < nk; r++) acc[r] = 0.0f;
-    for (int i = 0; i < Dp; i++) {
-        float xv = sx[o->order16[i]];
-        const float *row = o->WT + (size_t)i * nk;
-        for (size_t r = 0; r < nk; r++) acc[r] = fmaf(row[r], xv, acc[r]);
-    }
+static void init_indexes(const mcq_oracle *o, const int8_t *xl, int xe, uint8_t *idx, float *acc /*[N*K]*/) {
+    int N = o->N, K = o->K;
+    frame_logits(o, xl, xe, acc);
     for (int n = 0; n < N; n++) {
-        int best = 0; float bv = acc[(size_t)n * K] + o->bias[(size_t)n * K];
+        int best = 0; float bv = acc[(size_t)n * K];
         for (int k = 1; k < K; k++) {
-            float v = acc[(size_t)n * K + k] + o->bias[(size_t)n * K + k];
+            float v = acc[(size_t)n * K + k];
             if (v > bv) { bv = v; best = k; }
         }
         idx[n] = (uint8_t)best;
@@ -222,28 +279,18 @@ static void init_indexes(const mcq_oracle *o, const float *x, uint8_t *idx, floa
 }
 
 /* ---------------------------------------------------------------- table form */
-/* G[r][c] = dot16(C[r], C[c]) for all pairs of rows.  fmaf(a, b, acc) is symmetric in a, b, so
- * G[c][r] == G[r][c] bit for bit. */
+/* G[r][c] = fixdot(C[r], C[c]) for all pairs of rows (symmetric: the kept limb products are) */
 static void build_gram(mcq_oracle *o) {
-    const int N = o->N, K = o->K, Dp = o->Dp;
-    const size_t nk = (size_t)N * K;
+    const int Dp = o->Dp;
+    const size_t nk = (size_t)o->N * o->K;
     float *G = (float *)calloc(nk * nk, sizeof(float));
 #pragma omp parallel for schedule(dynamic, 8)
-    for (long r = 0; r < (long)nk; r++) {
-        const float *cr = o->C + (size_t)r * Dp;
-        const int nr = (int)(r / K);
-        for (int m = nr; m < N; m++) {      /* blocks on and above the diagonal; the rest is mirrored */
-            float *acc = G + (size_t)r * nk + (size_t)m * K;
-            for (int i = 0; i < Dp; i++) {
-                const float xv = cr[o->order16[i]];
-                const float *ct = o->CT + ((size_t)m * Dp + i) * K;
-                for (int k = 0; k < K; k++) acc[k] = fmaf(ct[k], xv, acc[k]);
-            }
-        }
-    }
+    for (long r = 0; r < (long)nk; r++)
+        for (size_t c = (size_t)r; c < nk; c++)
+            G[(size_t)r * nk + c] = fixdot(o->Cl + (size_t)r * 4 * Dp, o->Ce[r], o->Cl + c * 4 * Dp, o->Ce[c], Dp);
     for (size_t r = 0; r < nk; r++)
-        for (size_t c = 0; c < (r / K) * K; c++) G[r * nk + c] = G[c * nk + r];
-    o->G = G;      /* (inside a diagonal block both triangles were computed: fmaf(a, b, .) == fmaf(b, a, .)) */
+        for (size_t c = 0; c < r; c++) G[r * nk + c] = G[c * nk + r];
+    o->G = G;
 }
 
 static void ensure_gram(const mcq_oracle *o) {
@@ -266,18 +313,10 @@ static float wave_sum(const float *t, int n) {
     return p[0];
 }
 
-/* XC[r] = dot16(C[r], x) for all N*K rows (x unscaled, zero padded) */
-static void compute_xc(const mcq_oracle *o, const float *x, float *xc) {
-    const int N = o->N, K = o->K, D = o->D, Dp = o->Dp;
-    for (size_t r = 0; r < (size_t)N * K; r++) xc[r] = 0.0f;
-    for (int n = 0; n < N; n++)
-        for (int i = 0; i < Dp; i++) {
-            const int d = o->order16[i];
-            const float xv = (d < D) ? x[d] : 0.0f;
-            const float *ct = o->CT + ((size_t)n * Dp + i) * K;
-            float *acc = xc + (size_t)n * K;
-            for (int k = 0; k < K; k++) acc[k] = fmaf(ct[k], xv, acc[k]);
-        }
+/* XC[r] = fixdot(C[r], x) for all N*K rows (x unscaled, zero padded) */
+static void compute_xc(const mcq_oracle *o, const int8_t *xl, int xe, float *xc) {
+    const size_t nk = (size_t)o->N * o->K;
+    for (size_t r = 0; r < nk; r++) xc[r] = fixdot(xl, xe, o->Cl + r * 4 * o->Dp, o->Ce[r], o->Dp);
 }
 
 #define MCQ_MAX_LEVELS 7   /* candidates of 1, 2, 4, ..., 64 codebooks */
@@ -463,7 +502,7 @@ static void refine_any(const mcq_oracle *o, const float *x, const float *xc, uin
 /* _compute_indexes for a batch (:281-305).  idx: uint8 [B][N]. */
 int mcq_oracle_compute_indexes(const mcq_oracle *o, const float *x, long B, int iters, uint8_t *idx,
                                int nthreads) {
-    if (!o->WT) return -1;
+    if (!o->Wl) return -1;
     const int N = o->N, K = o->K, D = o->D, Dp = o->Dp;
     if (K < 16 || K > 256) return -2;
 #ifdef _OPENMP
@@ -476,16 +515,17 @@ int mcq_oracle_compute_indexes(const mcq_oracle *o, const float *x, long B, int 
     {
         scratch s; scratch_alloc(&s, N, K, Dp);
         float *acc = (float *)malloc(sizeof(float) * N * K);
-        float *sx = (float *)malloc(sizeof(float) * Dp);
+        int8_t *xl = (int8_t *)malloc((size_t)4 * Dp);
         float *xc = (float *)malloc(sizeof(float) * N * K);
 #pragma omp for schedule(dynamic, 8)
         for (long b = 0; b < B; b++) {
             uint8_t *id = idx + (size_t)b * N;
-            init_indexes(o, x + (size_t)b * D, id, acc, sx);
-            if (iters > 0) compute_xc(o, x + (size_t)b * D, xc);
+            const int xe = frame_limbs(o, x + (size_t)b * D, xl);
+            init_indexes(o, xl, xe, id, acc);
+            if (iters > 0) compute_xc(o, xl, xe, xc);
             for (int it = 0; it < iters; it++) refine_any(o, x + (size_t)b * D, xc, id, &s, NULL);
         }
-        free(acc); free(sx); free(xc); scratch_free(&s);
+        free(acc); free(xl); free(xc); scratch_free(&s);
     }
     return 0;
 }
@@ -504,12 +544,13 @@ int mcq_oracle_refine(const mcq_oracle *o, const float *x, long B, int iters, ui
     {
         scratch s; scratch_alloc(&s, N, K, Dp);
         float *xc = (float *)malloc(sizeof(float) * N * K);
+        int8_t *xl = (int8_t *)malloc((size_t)4 * Dp);
 #pragma omp for schedule(dynamic, 8)
         for (long b = 0; b < B; b++) {
-            if (iters > 0) compute_xc(o, x + (size_t)b * D, xc);
+            if (iters > 0) compute_xc(o, xl, frame_limbs(o, x + (size_t)b * D, xl), xc);
             for (int it = 0; it < iters; it++) refine_any(o, x + (size_t)b * D, xc, idx + (size_t)b * N, &s, NULL);
         }
-        free(xc); scratch_free(&s);
+        free(xc); free(xl); scratch_free(&s);
     }
     return 0;
 }
@@ -520,31 +561,29 @@ int mcq_oracle_refine_trace(const mcq_oracle *o, const float *x, uint8_t *idx, f
     scratch s; scratch_alloc(&s, o->N, o->K, o->Dp);
     mcq_trace tr = {xerr, E, R, S0, sel_pos, sel_val, comb};
     float *xc = (float *)malloc(sizeof(float) * o->N * o->K);
+    int8_t *xl = (int8_t *)malloc((size_t)4 * o->Dp);
     ensure_gram(o);
-    compute_xc(o, x, xc);
+    compute_xc(o, xl, frame_limbs(o, x, xl), xc);
     refine_any(o, x, xc, idx, &s, &tr);
-    free(xc);
+    free(xc); free(xl);
     scratch_free(&s);
     return 0;
 }
 
 /* initial argmax only (iters == 0 path), exposing the logits for tests */
 int mcq_oracle_logits(const mcq_oracle *o, const float *x, long B, float *logits) {
-    if (!o->WT) return -1;
+    if (!o->Wl) return -1;
     size_t nk = (size_t)o->N * o->K;
-    float *sx = (float *)malloc(sizeof(float) * o->Dp);
-    for (long b = 0; b < B; b++) {
-        float *acc = logits + (size_t)b * nk;
-        for (int d = 0; d < o->Dp; d++) sx[d] = (d < o->D) ? o->lscale * x[(size_t)b * o->D + d] : 0.0f;
-        for (size_t r = 0; r < nk; r++) acc[r] = 0.0f;
-        for (int i = 0; i < o->Dp; i++) {
-            float xv = sx[o->order16[i]];
-            const float *row = o->WT + (size_t)i * nk;
-            for (size_t r = 0; r < nk; r++) acc[r] = fmaf(row[r], xv, acc[r]);
+#pragma omp parallel
+    {
+        int8_t *xl = (int8_t *)malloc((size_t)4 * o->Dp);
+#pragma omp for schedule(static)
+        for (long b = 0; b < B; b++) {
+            const int xe = frame_limbs(o, x + (size_t)b * o->D, xl);
+            frame_logits(o, xl, xe, logits + (size_t)b * nk);
         }
-        for (size_t r = 0; r < nk; r++) acc[r] = acc[r] + o->bias[r];
+        free(xl);
     }
-    free(sx);
     return 0;
 }
 

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libmcq_hip.so")
 # every symbol include/mcq.h declares
 SYMBOLS = (
     "mcq_abi_version", "mcq_padded_dim", "mcq_prepared_bytes", "mcq_prepare", "mcq_prepare_dev", "mcq_encode_workspace_bytes",
-    "mcq_encode", "mcq_encode_ex", "mcq_refine_indexes", "mcq_decode", "mcq_decode_backward", "mcq_logits", "mcq_last_encode_launches", "mcq_profile_encode",
+    "mcq_encode", "mcq_encode_ex", "mcq_refine_indexes", "mcq_decode", "mcq_decode_backward", "mcq_logits", "mcq_logits_workspace_bytes", "mcq_last_encode_launches", "mcq_profile_encode",
     "mcq_logits_argmax", "mcq_loss_workspace_bytes", "mcq_loss_fwd", "mcq_loss_bwd", "mcq_recon_fwd", "mcq_loss_tail",
     "mcq_jcl_prefix_fwd", "mcq_jcl_prefix_bwd", "mcq_scatter_rows", "mcq_decode_backward_u8",
     "mcq_weight_grad", "mcq_weight_grad_workspace_bytes", "mcq_adam_step", "mcq_loss_head", "mcq_scales_exp",
@@ -58,7 +58,9 @@ def lib():
     L.mcq_decode_backward.restype = i32
     L.mcq_decode_backward.argtypes = [vp, vp, i64, i32, i32, i32, vp, vp]
     L.mcq_logits.restype = i32
-    L.mcq_logits.argtypes = [vp, i64, vp, f32, i32, i32, i32, vp, vp]
+    L.mcq_logits.argtypes = [vp, i64, vp, f32, i32, i32, i32, vp, vp, sz, vp]
+    L.mcq_logits_workspace_bytes.restype = sz
+    L.mcq_logits_workspace_bytes.argtypes = [i64, i32, i32]
     L.mcq_logits_argmax.restype = i32
     L.mcq_logits_argmax.argtypes = [vp, i64, vp, f32, i32, i32, i32, vp, vp, vp, sz, vp, ctypes.c_uint]
     L.mcq_loss_workspace_bytes.restype = sz
@@ -103,7 +105,7 @@ def lib():
     L.mcq_last_encode_launches.restype = i32
     L.mcq_profile_encode.restype = i32
     L.mcq_profile_encode.argtypes = [vp, i64, vp, f32, i32, i32, i32, i32, vp, sz, vp, ctypes.POINTER(f32), i32]
-    assert L.mcq_abi_version() == 3
+    assert L.mcq_abi_version() == 4
     _lib = L
     return L
 

@@ -2,6 +2,7 @@
 // Host side only enqueues kernels on the caller's stream; see mcq.h for the contract.
 #include "../../include/mcq.h"
 #include "mcq_kernels.h"
+#include "mcq_fix_kernels.h"
 #include "mcq_loss_kernels.h"
 #include "mcq_tf_kernels.h"
 #include "mcq_train_kernels.h"
@@ -25,20 +26,26 @@ int k_cutoff(int K, int L) {
 }
 
 struct Prepared {
-    const float *C, *Q, *W, *bias, *scales, *G;
+    const float *C, *Q, *bias, *scales, *G;
+    const int8_t *Cf, *Wf;      // limb planes of the scaled centers / of to_logits.weight (mcq_fix_kernels.h)
+    const int *Ce, *We;         // their row exponents
 };
 
 struct PreparedLayout {
-    size_t offC, offQ, offW, offBias, offScales, offG, total;
+    size_t offC, offQ, offCf, offCe, offWf, offWe, offBias, offScales, offG, total;
 };
 
 PreparedLayout prepared_layout(int N, int K, int D) {
     const size_t nk = (size_t)N * K, Dp = round_up16(D);
+    const size_t planes = fix_plane_bytes((long)nk, D), exps = (size_t)fix_round_rows((long)nk) * 4;
     PreparedLayout l;
     l.offC = 0;
     l.offQ = align256(l.offC + nk * Dp * 4);
-    l.offW = align256(l.offQ + nk * 4);
-    l.offBias = align256(l.offW + nk * Dp * 4);
+    l.offCf = align256(l.offQ + nk * 4);
+    l.offCe = align256(l.offCf + planes);
+    l.offWf = align256(l.offCe + exps);
+    l.offWe = align256(l.offWf + planes);
+    l.offBias = align256(l.offWe + exps);
     l.offScales = align256(l.offBias + nk * 4);   // float[2] {cscale_exp, lscale_exp} (mcq_prepare_dev)
     l.offG = align256(l.offScales + 8);           // Gram matrix G[nk][nk] of the scaled centers
     l.total = align256(l.offG + nk * nk * 4);
@@ -49,14 +56,18 @@ Prepared prepared_view(const void *p, int N, int K, int D) {
     const PreparedLayout l = prepared_layout(N, K, D);
     const char *b = static_cast<const char *>(p);
     return Prepared{reinterpret_cast<const float *>(b + l.offC), reinterpret_cast<const float *>(b + l.offQ),
-                    reinterpret_cast<const float *>(b + l.offW), reinterpret_cast<const float *>(b + l.offBias),
-                    reinterpret_cast<const float *>(b + l.offScales), reinterpret_cast<const float *>(b + l.offG)};
+                    reinterpret_cast<const float *>(b + l.offBias), reinterpret_cast<const float *>(b + l.offScales),
+                    reinterpret_cast<const float *>(b + l.offG),
+                    reinterpret_cast<const int8_t *>(b + l.offCf), reinterpret_cast<const int8_t *>(b + l.offWf),
+                    reinterpret_cast<const int *>(b + l.offCe), reinterpret_cast<const int *>(b + l.offWe)};
 }
 
 struct Workspace {
     uint8_t *idx, *idxB, *idxC, *final_idx;   // B, C, final: fixed-point skipping only
     int *map[2], *cnt;
     float *E, *R, *xx, *XC;                   // per vector: |x_err|^2, |x_err - old_n|^2, |x|^2, x.C products
+    int8_t *xf;                               // limb planes of the frames of a chunk
+    int *xe;                                  // and their row exponents
     float *tabs[2];                           // group tables of two consecutive levels (ping-pong)
     TfLists tf;                               // candidate lists of every level
 };
@@ -78,23 +89,25 @@ size_t tf_tab_floats(int N, int K) {
     return best;
 }
 
-size_t workspace_per_vector(int N, int K) {
-    // idx x4, maps, E, xx, R, XC, lists (entries / positions / scores: <= 16 + 2*16 + 4*16 bytes per codebook and level), tabs x2
+size_t workspace_per_vector(int N, int K, int D) {
+    // idx x4, maps, E, xx, R, XC, lists (entries / positions / scores: <= 16 + 2*16 + 4*16 bytes per codebook and level), tabs x2,
+    // the frame as limb planes + its exponent
     return 4 * (size_t)N + 8 + 8 + 4 * (size_t)N + 4 * (size_t)N * K + (size_t)tf_levels(N) * N * (16 + 2 * 16 + 4 * 16) + 64 +
-           2 * 4 * tf_tab_floats(N, K);
+           2 * 4 * tf_tab_floats(N, K) + 4 * (size_t)fix_round_cols(D) + 4;
 }
-constexpr size_t kWorkspaceSlack = 48 * 256;
+// alignment of the carved arrays + the rows the limb planes are padded by (to a multiple of 128)
+size_t workspace_slack(int D) { return 48 * 256 + (size_t)kFixTile * (4 * (size_t)fix_round_cols(D) + 4); }
 
 // default chunk: 65,536 vectors, fewer when a vector's share of the workspace is large (N >= 32), so that the workspace
 // mcq_encode_workspace_bytes asks for stays near 2 GB
-long default_chunk(int N, int K) {
-    long c = (long)(((size_t)2 << 30) / workspace_per_vector(N, K));
+long default_chunk(int N, int K, int D) {
+    long c = (long)(((size_t)2 << 30) / workspace_per_vector(N, K, D));
     c = c > 65536 ? 65536 : c;
     c = c < 1024 ? 1024 : c;
-    return c & ~63L;
+    return c & ~127L;
 }
 
-Workspace carve(void *ws, long Bc, int N, int K) {
+Workspace carve(void *ws, long Bc, int N, int K, int D) {
     char *p = static_cast<char *>(ws);
     size_t off = 0;
     auto take = [&](size_t bytes) { char *q = p + off; off = align256(off + bytes); return q; };
@@ -109,6 +122,8 @@ Workspace carve(void *ws, long Bc, int N, int K) {
     w.R = reinterpret_cast<float *>(take((size_t)Bc * N * 4));
     w.xx = reinterpret_cast<float *>(take((size_t)Bc * 4));
     w.XC = reinterpret_cast<float *>(take((size_t)Bc * N * K * 4));
+    w.xf = reinterpret_cast<int8_t *>(take(fix_plane_bytes(Bc, D)));
+    w.xe = reinterpret_cast<int *>(take((size_t)fix_round_rows(Bc) * 4));
     const int nlev = tf_levels(N);
     w.tf.ent = nullptr;
     for (int v = 0; v < kTfLevels; ++v) {
@@ -128,9 +143,9 @@ Workspace carve(void *ws, long Bc, int N, int K) {
 
 // N <= 64 for 16-entry codebooks, N <= 32 otherwise (what QuantizerTrainer can produce: bytes_per_frame <= 32)
 bool domain_ok(int N, int K, int D) {
-    return is_pow2(K) && K >= 16 && K <= 256 && is_pow2(N) && N <= (K == 16 ? 64 : 32) && D >= 1;
+    return is_pow2(K) && K >= 16 && K <= 256 && is_pow2(N) && N <= (K == 16 ? 64 : 32) && D >= 1 && D <= 16384;
 }
-int domain_err(int N, int K) { return (K < 16 || K > 256 || N > (K == 16 ? 64 : 32)) ? MCQ_EUNSUPPORTED : MCQ_EINVAL; }
+int domain_err(int N, int K, int D = 1) { return (K < 16 || K > 256 || N > (K == 16 ? 64 : 32) || D > 16384) ? MCQ_EUNSUPPORTED : MCQ_EINVAL; }
 
 // optional per-launch timing (mcq_profile_encode)
 struct Prof {
@@ -161,41 +176,55 @@ thread_local int g_last_launches = 0;
         ++g_last_launches;                               \
     } while (0)
 
-// the two GEMMs of an encode (logits + argmax, x.C) and the Gram matrix of a state
-template <int MODE>
-int launch_gemm(int K, const float *Bm, const float *xin, float lscale, const float *bias, long B, int N, int D, int Dp,
-                uint8_t *idx_out, float *out, hipStream_t st, const float *lscale_ptr = nullptr, int xh = 0) {
-    // default: k_gemm8s with 8 waves (64 vectors); tuning hooks: MCQ_GEMM_16W=1 -> 16 waves (128
-    // vectors), MCQ_GEMM4=1 -> the 4-wave 32-float-stage kernel k_gemm (always used for K == 16)
-    static const bool four_wave = getenv("MCQ_GEMM4") != nullptr;
-    static const bool big_block = getenv("MCQ_GEMM_16W") != nullptr;
-    const unsigned grid64 = (unsigned)(((B + 63) / 64) * N), grid128 = (unsigned)(((B + 127) / 128) * N);
-#define MCQ_GEMM_ARGS Bm, xin, lscale, bias, B, N, D, Dp, idx_out, out, lscale_ptr, xh
-    auto lds8 = [&](int K_, int vec) { return (size_t)2 * (K_ * 4 + vec * 4) * 16; };
-#define MCQ_GEMM_CASE(TT)                                                                                       \
-    case 16 * TT:                                                                                               \
-        if (four_wave || TT == 1)                                                                               \
-            hipLaunchKernelGGL((k_gemm<TT, MODE>), dim3(grid64), dim3(256), ((size_t)16 * TT * 8 + 64 * 8) * 16, st, \
-                               MCQ_GEMM_ARGS);                                                                  \
-        else if (big_block)                                                                                     \
-            hipLaunchKernelGGL((k_gemm8s<(TT > 1 ? TT : 2), MODE, 8>), dim3(grid128), dim3(1024), lds8(16 * TT, 128), st, \
-                               MCQ_GEMM_ARGS);                                                                  \
-        else                                                                                                    \
-            hipLaunchKernelGGL((k_gemm8s<(TT > 1 ? TT : 2), MODE, 4>), dim3(grid64), dim3(512), lds8(16 * TT, 64), st, \
-                               MCQ_GEMM_ARGS);                                                                  \
-        break;
-    switch (K) {
-        MCQ_GEMM_CASE(1)
-        MCQ_GEMM_CASE(2)
-        MCQ_GEMM_CASE(4)
-        MCQ_GEMM_CASE(8)
-        MCQ_GEMM_CASE(16)
-        default: return MCQ_EUNSUPPORTED;
-    }
-#undef MCQ_GEMM_CASE
-#undef MCQ_GEMM_ARGS
+// rows -> limb planes + exponents (+ |row|^2): the operands of every product of the path
+int launch_fix_rows(const float *src, int xh, long R, int D, long ld, int8_t *planes, int *exps, float *xx, hipStream_t st) {
+    const long Rp = fix_round_rows(R);
+    hipLaunchKernelGGL(k_fix_rows, dim3((unsigned)(Rp / 16)), dim3(256), 0, st, src, xh, R, Rp, D, ld, fix_round_cols(D), planes,
+                       exps, xx);
     MCQ_LAUNCH_CHECK();
     return 0;
+}
+
+// the fixed-point GEMM: persistent workgroups, one per CU
+template <int MODE>
+int launch_fgemm(FixGemm g, hipStream_t st) {
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fgemm<MODE>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, kFixLds);
+    if (attr != hipSuccess) return (int)attr;
+    const long MT = g.RA / kFixTile, NT = g.RB / kFixTile;
+    const int H = (MODE == FG_LOGITS && g.K > kFixTile) ? g.K / kFixTile : 1;
+    const long big = g.walk_rows ? NT : MT, small_units = (g.walk_rows ? MT : NT) / H;
+    long units = (big + 7) / 8 * small_units;          // per XCD
+    if (units > 32) units = 32;                        // 32 CUs per XCD, one workgroup each
+    hipLaunchKernelGGL((k_fgemm<MODE>), dim3((unsigned)(8 * units)), dim3(256), kFixLds, st, g);
+    MCQ_LAUNCH_CHECK();
+    return 0;
+}
+
+// XC[b][r] = fixdot(x_b, C_r) (or the Gram matrix with the centers as "frames"): frames stream, the centers are the table
+int launch_xc(const int8_t *xf, const int *xe, long B, const int8_t *Cf, const int *Ce, long nk, int D, float *out,
+              hipStream_t st) {
+    FixGemm g{};
+    g.A = xf; g.ea = xe; g.RA = fix_round_rows(B); g.M = B;
+    g.B = Cf; g.eb = Ce; g.RB = fix_round_rows(nk); g.N = nk;
+    g.Dq = fix_round_cols(D);
+    g.walk_rows = 0;
+    g.out = out; g.ldo = nk;
+    return launch_fgemm<FG_STORE>(g, st);
+}
+
+// logits[b][r] = fixdot(x_b, W_r) * lscale + bias[r] (stored when logits != nullptr) and the arg max per codebook
+int launch_logits(const int8_t *xf, const int *xe, long B, const Prepared &P, int N, int K, int D, float lscale,
+                  const float *lscale_ptr, float *logits, uint8_t *idx, hipStream_t st) {
+    const long nk = (long)N * K;
+    FixGemm g{};
+    g.A = P.Wf; g.ea = P.We; g.RA = fix_round_rows(nk); g.M = nk;
+    g.B = xf; g.eb = xe; g.RB = fix_round_rows(B); g.N = B;
+    g.Dq = fix_round_cols(D);
+    g.walk_rows = 1;
+    g.bias = P.bias; g.lscale = lscale; g.lscale_ptr = lscale_ptr;
+    g.logits = logits; g.ldo = nk; g.idx = idx; g.K = K; g.ncb = N;
+    return launch_fgemm<FG_LOGITS>(g, st);
 }
 
 // ---------------------------------------------------------------- the refinement pass
@@ -334,17 +363,16 @@ int run_encode(const float *x, long B, const void *prepared, float lscale, int N
                uint8_t *out_u8, int64_t *out_i64, void *workspace, size_t workspace_bytes, hipStream_t st,
                Prof *prof, const int64_t *init_idx = nullptr, unsigned flags = 0) {
     g_last_launches = 0;
-    if (!domain_ok(N, K, D)) return domain_err(N, K);
+    if (!domain_ok(N, K, D)) return domain_err(N, K, D);
     if (B < 0 || iters < 0 || iters > 60 || (out_u8 == nullptr) == (out_i64 == nullptr)) return MCQ_EINVAL;
     if (B == 0) return 0;
     if (!x || !prepared || !workspace) return MCQ_EINVAL;
-    const int Dp = round_up16(D);
-    const size_t per = workspace_per_vector(N, K);
-    if (workspace_bytes < kWorkspaceSlack + per) return MCQ_EWORKSPACE;
-    long chunk = (long)((workspace_bytes - kWorkspaceSlack) / per);
+    const size_t per = workspace_per_vector(N, K, D), slack = workspace_slack(D);
+    if (workspace_bytes < slack + per) return MCQ_EWORKSPACE;
+    long chunk = (long)((workspace_bytes - slack) / per);
     if (chunk > B) chunk = B;
-    if (chunk < B && chunk < 64) return MCQ_EWORKSPACE;
-    if (chunk < B) chunk &= ~63L;
+    if (chunk < B && chunk < 128) return MCQ_EWORKSPACE;
+    if (chunk < B) chunk &= ~127L;
     const Prepared P = prepared_view(prepared, N, K, D);
     const int pack = (out_u8 != nullptr && K == 16 && N >= 2) ? 2 : 1;
     // fixed-point skipping (opt-in): vectors whose indexes a pass leaves unchanged drop out of the later
@@ -353,29 +381,33 @@ int run_encode(const float *x, long B, const void *prepared, float lscale, int N
 
     for (long lo = 0; lo < B; lo += chunk) {
         const long Bc = (B - lo < chunk) ? (B - lo) : chunk;
-        const Workspace w = carve(workspace, Bc, N, K);
+        const Workspace w = carve(workspace, Bc, N, K, D);
         const int xh = (flags & MCQ_ENCODE_X_FP16) ? 1 : 0;   // rows of 2-byte elements
         const float *xc = xh ? reinterpret_cast<const float *>(reinterpret_cast<const uint16_t *>(x) + lo * D) : x + lo * D;
         int rc;
+        // the frames as limb planes (and |x|^2), once per call: both products of the call read them
+        if (init_idx == nullptr || iters > 0) {
+            if (prof) prof->begin();
+            rc = launch_fix_rows(xc, xh, Bc, D, D, w.xf, w.xe, w.xx, st);
+            if (rc) return rc;
+            if (prof) prof->end(CAT_XX);
+        }
         if (init_idx != nullptr) {
             hipLaunchKernelGGL(k_import_indexes, dim3((unsigned)((Bc * N + 255) / 256)), dim3(256), 0, st,
                                init_idx + lo * N, Bc * N, K, w.idx);
             MCQ_LAUNCH_CHECK();
         } else {
             if (prof) prof->begin();
-            rc = launch_gemm<MODE_LOGITS>(K, P.W, xc, lscale, P.bias, Bc, N, D, Dp, w.idx, nullptr, st,
-                                          (flags & MCQ_ENCODE_LSCALE_FROM_PREPARED) ? P.scales + 1 : nullptr, xh);
+            rc = launch_logits(w.xf, w.xe, Bc, P, N, K, D, lscale,
+                               (flags & MCQ_ENCODE_LSCALE_FROM_PREPARED) ? P.scales + 1 : nullptr, nullptr, w.idx, st);
             if (rc) return rc;
             if (prof) prof->end(CAT_LOGITS);
         }
-        if (iters > 0) {   // what the passes read per vector: the x.C products and |x|^2, once per call
+        if (iters > 0) {   // what the passes read per vector: the x.C products, once per call
             if (prof) prof->begin();
-            rc = launch_gemm<MODE_XC>(K, P.C, xc, 1.0f, nullptr, Bc, N, D, Dp, nullptr, w.XC, st, nullptr, xh);
+            rc = launch_xc(w.xf, w.xe, Bc, P.Cf, P.Ce, (long)N * K, D, w.XC, st);
             if (rc) return rc;
-            if (prof) { prof->end(CAT_XC); prof->begin(); }
-            hipLaunchKernelGGL(k_tf_xx, dim3((unsigned)((Bc + 3) / 4)), dim3(256), 0, st, xc, Bc, D, Dp, w.xx, xh);
-            MCQ_LAUNCH_CHECK();
-            if (prof) prof->end(CAT_XX);
+            if (prof) prof->end(CAT_XC);
         }
         // without skipping: indexes are refined in place in w.idx, nothing is packed
         uint8_t *idx_cur = w.idx, *idx_new = skip ? w.idxB : w.idx, *idx_pk = w.idxC;
@@ -455,7 +487,7 @@ size_t mcq_prepared_bytes(int N, int K, int D) {
 
 static int prepare_impl(const float *centers, float cscale_exp, const float *scales_dev, const float *weight,
                         const float *bias, int N, int K, int D, void *prepared, void *stream) {
-    if (!domain_ok(N, K, D)) return domain_err(N, K);
+    if (!domain_ok(N, K, D)) return domain_err(N, K, D);
     if (!centers || !prepared || ((weight == nullptr) != (bias == nullptr))) return MCQ_EINVAL;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const PreparedLayout l = prepared_layout(N, K, D);
@@ -467,12 +499,15 @@ static int prepare_impl(const float *centers, float cscale_exp, const float *sca
                        reinterpret_cast<float *>(b + l.offC), reinterpret_cast<float *>(b + l.offQ), scales_dev);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
+    // the scaled centers (and the classifier rows) as limb planes: the tables of the fixed-point products
+    const float *C = reinterpret_cast<const float *>(b + l.offC);
+    int rc = launch_fix_rows(C, 0, rows, Dp, Dp, reinterpret_cast<int8_t *>(b + l.offCf), reinterpret_cast<int *>(b + l.offCe),
+                             nullptr, st);
+    if (rc) return rc;
     if (weight) {
-        hipLaunchKernelGGL(k_prepare_rows, dim3(grid), dim3(256), 0, st, weight, 1.0f, 0, rows, D, Dp,
-                           reinterpret_cast<float *>(b + l.offW), static_cast<float *>(nullptr),
-                           static_cast<const float *>(nullptr));
-        e = hipGetLastError();
-        if (e != hipSuccess) return (int)e;
+        rc = launch_fix_rows(weight, 0, rows, D, D, reinterpret_cast<int8_t *>(b + l.offWf), reinterpret_cast<int *>(b + l.offWe),
+                             nullptr, st);
+        if (rc) return rc;
         e = hipMemcpyAsync(b + l.offBias, bias, (size_t)rows * 4, hipMemcpyDeviceToDevice, st);
         if (e != hipSuccess) return (int)e;
     }
@@ -481,9 +516,10 @@ static int prepare_impl(const float *centers, float cscale_exp, const float *sca
         if (e != hipSuccess) return (int)e;
     }
     if (weight) {
-        // Gram matrix of the scaled centers: the same GEMM kernel with the padded rows themselves as the "vectors"
-        const float *C = reinterpret_cast<const float *>(b + l.offC);
-        const int rc = launch_gemm<MODE_XC>(K, C, C, 1.0f, nullptr, rows, N, Dp, Dp, nullptr, reinterpret_cast<float *>(b + l.offG), st);
+        // Gram matrix of the scaled centers: the x.C product with the centers themselves as the frames
+        rc = launch_xc(reinterpret_cast<const int8_t *>(b + l.offCf), reinterpret_cast<const int *>(b + l.offCe), rows,
+                       reinterpret_cast<const int8_t *>(b + l.offCf), reinterpret_cast<const int *>(b + l.offCe), rows, D,
+                       reinterpret_cast<float *>(b + l.offG), st);
         if (rc) return rc;
     }
     return 0;
@@ -501,9 +537,9 @@ int mcq_prepare_dev(const float *centers, const float *scales_exp, const float *
 }
 
 size_t mcq_encode_workspace_bytes(long B, int N, int K, int D) {
-    if (B <= 0 || N <= 0 || K <= 0 || D <= 0 || !domain_ok(N, K, D)) return kWorkspaceSlack;
-    const long dc = default_chunk(N, K), chunk = B < dc ? B : dc;
-    return kWorkspaceSlack + workspace_per_vector(N, K) * (size_t)chunk;
+    if (B <= 0 || N <= 0 || K <= 0 || D <= 0 || !domain_ok(N, K, D)) return 48 * 256;
+    const long dc = default_chunk(N, K, D), chunk = B < dc ? B : dc;
+    return workspace_slack(D) + workspace_per_vector(N, K, D) * (size_t)chunk;
 }
 
 int mcq_encode(const float *x, long B, const void *prepared, float lscale_exp, int N, int K, int D, int refine_iters,
@@ -660,14 +696,46 @@ int mcq_jcl_prefix_bwd(const float *A, const float *gA, long B, int N, int H, fl
     return e == hipSuccess ? 0 : (int)e;
 }
 
+namespace {
+// workspace of the logits entry points: arg max bytes, then the frames as limb planes and their exponents
+struct LogitsWs {
+    uint8_t *idx8;
+    int8_t *xf;
+    int *xe;
+    size_t total;
+};
+LogitsWs logits_ws(void *ws, long B, int N, int D) {
+    char *p = static_cast<char *>(ws);
+    LogitsWs w;
+    size_t off = 0;
+    w.idx8 = reinterpret_cast<uint8_t *>(p + off);
+    off = align256(off + (size_t)B * N);
+    w.xf = reinterpret_cast<int8_t *>(p + off);
+    off = align256(off + fix_plane_bytes(B, D));
+    w.xe = reinterpret_cast<int *>(p + off);
+    off = align256(off + (size_t)fix_round_rows(B) * 4);
+    w.total = off;
+    return w;
+}
+}  // namespace
+
+size_t mcq_logits_workspace_bytes(long B, int N, int D) {
+    if (B <= 0 || N <= 0 || D <= 0) return 256;
+    return logits_ws(nullptr, B, N, D).total;
+}
+
 int mcq_logits(const float *x, long B, const void *prepared, float lscale_exp, int N, int K, int D, float *out,
-               void *stream) {
+               void *workspace, size_t workspace_bytes, void *stream) {
     if (!domain_ok(N, K, D)) return MCQ_EUNSUPPORTED;
     if (B == 0) return 0;
-    if (!x || !prepared || !out || B < 0) return MCQ_EINVAL;
+    if (!x || !prepared || !out || B < 0 || !workspace) return MCQ_EINVAL;
+    if (workspace_bytes < mcq_logits_workspace_bytes(B, N, D)) return MCQ_EWORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
     const Prepared P = prepared_view(prepared, N, K, D);
-    return launch_gemm<MODE_LOGITS_OUT>(K, P.W, x, lscale_exp, P.bias, B, N, D, round_up16(D), nullptr, out,
-                                        static_cast<hipStream_t>(stream));
+    const LogitsWs w = logits_ws(workspace, B, N, D);
+    int rc = launch_fix_rows(x, 0, B, D, D, w.xf, w.xe, nullptr, st);
+    if (rc) return rc;
+    return launch_logits(w.xf, w.xe, B, P, N, K, D, lscale_exp, nullptr, out, nullptr, st);
 }
 
 // ------------------------------------------------------------------ trainer pieces
@@ -678,15 +746,16 @@ int mcq_logits_argmax(const float *x, long B, const void *prepared, float lscale
     if (B < 0) return MCQ_EINVAL;
     if (B == 0) return 0;
     if (!x || !prepared || !logits_out || !argmax_out || !workspace) return MCQ_EINVAL;
-    if (workspace_bytes < (size_t)B * N) return MCQ_EWORKSPACE;
+    if (workspace_bytes < mcq_logits_workspace_bytes(B, N, D)) return MCQ_EWORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const Prepared P = prepared_view(prepared, N, K, D);
-    uint8_t *idx8 = static_cast<uint8_t *>(workspace);
-    int rc = launch_gemm<MODE_LOGITS_OUT>(K, P.W, x, lscale_exp, P.bias, B, N, D, round_up16(D), idx8, logits_out, st,
-                                          (flags & MCQ_ENCODE_LSCALE_FROM_PREPARED) ? P.scales + 1 : nullptr,
-                                          (flags & MCQ_ENCODE_X_FP16) ? 1 : 0);
+    const LogitsWs w = logits_ws(workspace, B, N, D);
+    int rc = launch_fix_rows(x, (flags & MCQ_ENCODE_X_FP16) ? 1 : 0, B, D, D, w.xf, w.xe, nullptr, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_export_indexes, dim3((unsigned)((B * N + 255) / 256)), dim3(256), 0, st, idx8, B * N, argmax_out);
+    rc = launch_logits(w.xf, w.xe, B, P, N, K, D, lscale_exp,
+                       (flags & MCQ_ENCODE_LSCALE_FROM_PREPARED) ? P.scales + 1 : nullptr, logits_out, w.idx8, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_export_indexes, dim3((unsigned)((B * N + 255) / 256)), dim3(256), 0, st, w.idx8, B * N, argmax_out);
     MCQ_LAUNCH_CHECK();
     return 0;
 }

@@ -1,0 +1,412 @@
+// mcq_fix_kernels.h -- the three inner-product tables of the path (logits :277-279, x.C and the Gram matrix of the
+// centers: oracle/mcq_oracle.c "fixdot") as EXACT fixed-point products on the i8 matrix cores of gfx950.
+//
+// A row v is held as 30-bit fixed point against its own largest magnitude (row exponent e: max|v| < 2^e,
+// q = rint(v * 2^(30-e))) and q as four signed 8-bit limbs, q = l0*2^24 + l1*2^16 + l2*2^8 + l3.  The product of two rows is
+//     T_s = sum_k sum_{i+j=s} la_i[k] * lb_j[k]          s = 0..3: ten limb products, four i32 accumulator sets
+//     t   = fma(T_0, 2^24, fma(T_1, 2^16, fma(T_2, 2^8, (float)T_3)))     (int -> float conversions round to nearest even)
+//     fixdot = ldexp(t, ea + eb - 36)
+// The T_s are exact integers, so nothing depends on the order the matrix cores add in; products of weight 2^-32 and
+// below (i + j >= 4) are dropped.  v_mfma_i32_32x32x32_i8 runs at 32x the rate of the fp32 MFMA; ten of them replace one
+// fp32 product step.
+//
+// Layout of a limb matrix with R rows (R a multiple of 128) and Dq columns (a multiple of 128): one "plane" per
+// (16-column chunk c, limb l), each plane R x 16 bytes:  byte ((c * 4 + l) * R + row) * 16 + (k % 16).  A 128-row tile of
+// one plane is 2 KB contiguous: the GEMM brings it into LDS with two 1 KB LDS-DMA loads and reads MFMA fragments
+// (16 consecutive k of one row) straight out of it with ds_read_b128, 16 lanes per 256 contiguous bytes.
+#pragma once
+#include "mcq_kernels.h"
+
+namespace mcq {
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kFixTile = 128;          // rows per tile, both operands
+constexpr int kFixColPad = 128;        // columns are padded to a multiple of this (four k steps of 32)
+constexpr int kFixRing = 4;            // LDS ring slots, one k step (32 columns) each
+constexpr int kFixSlot = 32768;        // 2 operands x 8 planes x 2 KB
+constexpr int kFixOperand = 16384;
+constexpr int kFixInfo = kFixRing * kFixSlot;      // per-tile row / column data after the ring (4 KB)
+constexpr int kFixLds = kFixInfo + 4096;
+
+__host__ __device__ inline long fix_round_rows(long r) { return (r + kFixTile - 1) / kFixTile * kFixTile; }
+__host__ __device__ inline int fix_round_cols(int d) { return (d + kFixColPad - 1) / kFixColPad * kFixColPad; }
+// bytes of the planes / of the exponents of an R x D matrix
+__host__ __device__ inline size_t fix_plane_bytes(long R, int D) { return (size_t)fix_round_rows(R) * fix_round_cols(D) * 4; }
+
+// ------------------------------------------------------------------ rows -> limb planes
+__device__ __forceinline__ int fix_q(float v, int e) {
+    float s = ldexpf(v, 30 - e);
+    s = fminf(fmaxf(s, -1073741824.0f), 1073741824.0f);
+    return (int)rintf(s);
+}
+
+// Workgroup = 16 rows (wave w: rows 4w .. 4w+3).  Pass 1: the row exponent (and, for frames, |x|^2 as k_tf_xx formed it:
+// lane l adds the float4 groups l, l + 64, ... then the butterfly).  Pass 2, per block of 512 columns: limbs to LDS as
+// [plane][row][16 bytes], then 256-byte runs (16 rows of one plane) to the planes.
+// src: fp32 rows of `ld` floats (or fp16 rows of `ld` halves when xh), D valid columns; rows >= R are written as zeros.
+__global__ void __launch_bounds__(256)
+k_fix_rows(const float *__restrict__ src, int xh, long R, long Rp, int D, long ld, int Dq, int8_t *__restrict__ planes,
+           int *__restrict__ exps, float *__restrict__ xx) {
+    __shared__ __attribute__((aligned(16))) unsigned tile[128 * 16 * 4];      // [plane of the block][row][4 words]
+    __shared__ int es[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long row0 = (long)blockIdx.x * 16;
+    const _Float16 *srch = reinterpret_cast<const _Float16 *>(src);
+    const bool vec_ok = ((ld & 3) == 0) && ((D & 3) == 0) && ((reinterpret_cast<uintptr_t>(src) & (xh ? 7 : 15)) == 0);
+    auto load4 = [&](long row, int q) -> f32x4 {      // float4 group q of a row, zero past D
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (row >= R || 4 * q >= D) return v;
+        if (vec_ok) return xh ? load_h4(srch + row * ld + 4 * q) : *reinterpret_cast<const f32x4 *>(src + row * ld + 4 * q);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (4 * q + c < D) v[c] = xh ? (float)srch[row * ld + 4 * q + c] : src[row * ld + 4 * q + c];
+        return v;
+    };
+    for (int rr = 0; rr < 4; ++rr) {
+        const long row = row0 + 4 * wave + rr;
+        float m = 0.f, pe = 0.f;
+        for (int q = lane; q < (D + 3) / 4; q += 64) {
+            const f32x4 v = load4(row, q);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                m = fmaxf(m, fabsf(v[c]));
+                pe = fmaf(v[c], v[c], pe);
+            }
+        }
+        for (int s = 32; s >= 1; s >>= 1) m = fmaxf(m, __shfl_xor(m, s, 64));
+        if (xx) pe = wave_sum_butterfly(pe);
+        if (lane == 0) {
+            const int be = (int)((__float_as_uint(m) >> 23) & 0xff);
+            const int e = (be < 1 ? 1 : be) - 126;
+            es[4 * wave + rr] = e;
+            if (row < Rp) exps[row] = e;
+            if (xx && row < R) xx[row] = pe;
+        }
+    }
+    __syncthreads();
+    for (int c0 = 0; c0 < Dq; c0 += 512) {
+        const int ncol = (Dq - c0 < 512) ? Dq - c0 : 512;          // columns of this block (a multiple of 128)
+        for (int rr = 0; rr < 4; ++rr) {
+            const int rl = 4 * wave + rr;
+            const int e = es[rl];
+            for (int q = lane; q < ncol / 4; q += 64) {
+                const f32x4 v = load4(row0 + rl, c0 / 4 + q);
+                unsigned w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    int r = fix_q(v[c], e);
+#pragma unroll
+                    for (int i = 3; i >= 1; --i) {
+                        const int l = (int)(int8_t)(r & 0xff);
+                        w[i] |= (unsigned)(l & 0xff) << (8 * c);
+                        r = (r - l) >> 8;
+                    }
+                    w[0] |= (unsigned)(r & 0xff) << (8 * c);
+                }
+                const int chunk = q >> 2, word = q & 3;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) tile[((chunk * 4 + i) * 16 + rl) * 4 + word] = w[i];
+            }
+        }
+        __syncthreads();
+        const int nplanes = ncol / 16 * 4;
+        for (int p = tid >> 4; p < nplanes; p += 16) {
+            const int rl = tid & 15;
+            if (row0 + rl < Rp) {
+                const i32x4 v = *reinterpret_cast<const i32x4 *>(&tile[(p * 16 + rl) * 4]);
+                *reinterpret_cast<i32x4 *>(planes + (((long)(c0 / 16) * 4 + p) * Rp + row0 + rl) * 16) = v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------ the GEMM
+// out-of-kernel description of what the epilogue does with a tile of t values
+enum { FG_STORE = 0, FG_LOGITS = 1 };
+
+struct FixGemm {
+    const int8_t *A, *B;           // limb planes: A rows are the tile rows (M), B rows the tile columns (N)
+    const int *ea, *eb;            // row exponents
+    long RA, RB;                   // padded row counts (multiples of 128)
+    long M, N;                     // valid rows / columns
+    int Dq;                        // padded inner dimension
+    int walk_rows;                 // 0: an XCD owns row tiles and walks the column tiles (A streams, B is the table);
+                                   // 1: the other way round (B streams)
+    // FG_STORE: out[row * ldo + col] = fixdot
+    float *out;
+    long ldo;
+    // FG_LOGITS: rows are (codebook, entry) pairs, columns are frames; value = fixdot * lscale + bias[row];
+    //            logits[col * ldo + row] = value when logits != nullptr; idx[col * ncb + codebook] = first arg max
+    const float *bias;
+    const float *lscale_ptr;       // device scalar, or nullptr: lscale
+    float lscale;
+    float *logits;
+    uint8_t *idx;
+    int K, ncb;
+};
+
+// Persistent workgroups (one per CU: 132 KB of LDS, 512 registers per lane): workgroup w takes the tiles w, w + grid, ...
+// of an XCD-aware order and runs their k steps as ONE stream through the LDS ring -- the first steps of the next tile are
+// in flight while this one finishes and stores.  Four waves, each a 64 x 64 corner of the 128 x 128 tile (2 x 2 MFMA tiles x
+// 4 accumulator sets = 256 accumulator registers).  A k step: 40 MFMAs per wave against 16 ds_read_b128 (fragments of the
+// next step) and 8 LDS-DMA pieces of 1 KB (the step three ahead), dealt in four groups so that all three pipes stay busy.
+template <int MODE>
+__global__ void __launch_bounds__(256)
+k_fgemm(const FixGemm g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int r32 = lane & 31, kh = lane >> 5;
+    const long MT = g.RA / kFixTile, NT = g.RB / kFixTile;
+    // K = 256 logits: the two row tiles of a codebook are consecutive tiles of one workgroup (running arg max in registers)
+    const int H = (MODE == FG_LOGITS && g.K > kFixTile) ? g.K / kFixTile : 1;
+    const long big = g.walk_rows ? NT : MT, small_units = (g.walk_rows ? MT : NT) / H;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+    auto tile_of = [&](long t, long &m0, long &n0) -> bool {      // t-th tile of this workgroup
+        const long unit = t / H, half = t % H;
+        const long idx = slot + unit * per_xcd;
+        const long bt = (idx / small_units) * 8 + xcd, st = (idx % small_units) * H + half;
+        m0 = (g.walk_rows ? st : bt) * kFixTile;
+        n0 = (g.walk_rows ? bt : st) * kFixTile;
+        return bt < big;
+    };
+    i32x16 acc[2][2][4];
+    const int nst = g.Dq / 32;
+    // this wave's 8 pieces of a stage (1 KB each): waves 0, 1 bring operand A, waves 2, 3 operand B; wave & 1 picks the
+    // 16-column chunk, g4 = 0..3 the limb plane; the two 64-row halves go out as one base with offset 0 / 1024 (the
+    // instruction offset applies to the global and to the LDS address alike)
+    const int wu = __builtin_amdgcn_readfirstlane(wave);
+    const int op = wu >> 1;
+    const long R = op ? g.RB : g.RA;
+    const long pl = R * 16, sstride = 8 * R * 16;
+    const unsigned dbase = (unsigned)(size_t)smem + op * kFixOperand + (4 * (wu & 1)) * 2048;
+    const unsigned voff = lane * 16;
+    auto base_of = [&](long m0, long n0) { return (op ? g.B + n0 * 16 : g.A + m0 * 16) + (long)(4 * (wu & 1)) * R * 16; };
+    auto issue1 = [&](const int8_t *p, int st, int g4) {
+        const int8_t *pg = p + g4 * pl;
+        const unsigned d = dbase + (st % kFixRing) * kFixSlot + g4 * 2048;
+        asm volatile(
+            "s_mov_b32 m0, %[d]\n\ts_nop 0\n\t"
+            "global_load_lds_dwordx4 %[vo], %[p]\n\t"
+            "global_load_lds_dwordx4 %[vo], %[p] offset:1024\n\t"
+            :
+            : [vo] "v"(voff), [p] "s"(pg), [d] "s"(d)
+            : "memory");
+    };
+    long m0, n0, m0n = 0, n0n = 0;
+    if (!tile_of(0, m0, n0)) return;
+    const int8_t *pcur = base_of(m0, n0), *pnext = pcur;
+    auto step = [&](int st, bool has_next, const i32x4 (&a)[2][4], const i32x4 (&b)[2][4], i32x4 (&an)[2][4], i32x4 (&bn)[2][4]) {
+        const char *base = smem + ((st + 1) % kFixRing) * kFixSlot;
+        const bool load = (st + 4 < nst) || has_next;
+        const int8_t *p = (st + 4 < nst) ? pcur + (st + 4) * sstride : pnext + (st + 4 - nst) * sstride;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            if (load) issue1(p, st, g4);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                an[t][g4] = *reinterpret_cast<const i32x4 *>(base + (kh * 4 + g4) * 2048 + (64 * wm + 32 * t + r32) * 16);
+                bn[t][g4] = *reinterpret_cast<const i32x4 *>(base + kFixOperand + (kh * 4 + g4) * 2048 + (64 * wn + 32 * t + r32) * 16);
+            }
+            constexpr int PI[10] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 3};      // limb pairs (i, j), i + j <= 3, dealt 3, 3, 2, 2
+            constexpr int PJ[10] = {0, 1, 0, 2, 1, 0, 3, 2, 1, 0};
+            constexpr int LO[5] = {0, 3, 6, 8, 10};
+#pragma unroll
+            for (int q = LO[g4]; q < LO[g4 + 1]; ++q)
+#pragma unroll
+                for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+                    for (int tb = 0; tb < 2; ++tb)
+                        acc[ta][tb][PI[q] + PJ[q]] =
+                            __builtin_amdgcn_mfma_i32_32x32x32_i8(a[ta][PI[q]], b[tb][PJ[q]], acc[ta][tb][PI[q] + PJ[q]], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    i32x4 a0[2][4], b0[2][4], a1[2][4], b1[2][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) issue1(pcur + q * sstride, q, g4);
+    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            a0[t][l] = *reinterpret_cast<const i32x4 *>(smem + (kh * 4 + l) * 2048 + (64 * wm + 32 * t + r32) * 16);
+            b0[t][l] = *reinterpret_cast<const i32x4 *>(smem + kFixOperand + (kh * 4 + l) * 2048 + (64 * wn + 32 * t + r32) * 16);
+        }
+    int *info = reinterpret_cast<int *>(smem + kFixInfo);      // [0..127] ea of the tile rows, [128..255] eb of the columns,
+    float *infof = reinterpret_cast<float *>(smem + kFixInfo); // [256..383] bias of the rows, [384..] arg-max exchange
+    // running arg max of a codebook that spans several row tiles: per lane, its two columns
+    float runv[2] = {0.f, 0.f};
+    int runk[2] = {0, 0};
+    for (long t = 0;; ++t) {
+        const bool has_next = tile_of(t + 1, m0n, n0n);
+        pnext = base_of(m0n, n0n);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) acc[a][b][s][v] = 0;
+        // before the reads of stage st + 1: it has landed everywhere and every wave has left slot st % ring.  Two later
+        // stages stay in flight (ordinary loads and stores of the epilogue only make the count conservative: loads
+        // complete in order)
+        auto sync = [&](int st) {
+            const int ahead = has_next ? 2 : (nst - 1 < st + 3 ? nst - 1 : st + 3) - (st + 1);
+            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        };
+        for (int st = 0; st < nst; st += 2) {
+            sync(st);
+            step(st, has_next, a0, b0, a1, b1);
+            sync(st + 1);
+            step(st + 1, has_next, a1, b1, a0, b0);      // (reads past the end of the last tile hit a slot nobody uses)
+        }
+        // ---- epilogue: exponents (and bias) of the tile's rows and columns through LDS
+        if (tid < 128) {
+            info[tid] = g.ea[m0 + tid];
+            if (MODE == FG_LOGITS) infof[256 + tid] = (m0 + tid < g.M) ? g.bias[m0 + tid] : 0.f;
+        } else {
+            info[tid] = g.eb[n0 + tid - 128];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        auto value = [&](int ta, int tb, int v, int e) -> float {
+            float tt = (float)acc[ta][tb][3][v];
+            tt = __builtin_fmaf((float)acc[ta][tb][2][v], 256.0f, tt);
+            tt = __builtin_fmaf((float)acc[ta][tb][1][v], 65536.0f, tt);
+            tt = __builtin_fmaf((float)acc[ta][tb][0][v], 16777216.0f, tt);
+            return ldexpf(tt, e);
+        };
+        // lane-dependent offsets are formed anew for every tile (hoisted out of the tile loop they would cost 128 registers)
+        int rbase = 64 * wm + 4 * kh, cbase = 64 * wn + r32;
+        asm volatile("" : "+v"(rbase), "+v"(cbase));
+        if (MODE == FG_STORE) {
+            const int rows_left = (int)((g.M - m0 - rbase) > 128 ? 128 : (g.M - m0 - rbase));
+            float *orow = g.out + (m0 + rbase) * g.ldo + n0 + cbase;
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb) {
+                const bool col_ok = n0 + cbase + 32 * tb < g.N;
+                const int ecol = info[128 + cbase + 32 * tb] - 36;
+#pragma unroll
+                for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) {
+                        const int ro = 32 * ta + 8 * (v >> 2) + (v & 3);          // row of the lane's block
+                        const float val = value(ta, tb, v, info[rbase + ro] + ecol);
+                        if (col_ok && ro < rows_left) orow[(long)ro * g.ldo + 32 * tb] = val;
+                    }
+            }
+        } else {
+            const float ls = g.lscale_ptr ? *g.lscale_ptr : g.lscale;
+            // per lane: columns (frames) cl(tb), rows 64 wm + 32 ta + 8 (v >> 2) + 4 kh + (v & 3), ascending in (ta, v)
+            float bv[2][4];       // best of the 16-row group (ta, v >> 3), this lane's 8 rows of it
+            int bk[2][4];
+            const int rows_left = (int)((g.M - m0 - rbase) > 128 ? 128 : (g.M - m0 - rbase));
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb) {
+                const long col = n0 + cbase + 32 * tb;
+                const int ecol = info[128 + cbase + 32 * tb] - 36;
+                float *lrow = g.logits ? g.logits + col * g.ldo + m0 + rbase : nullptr;
+#pragma unroll
+                for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+                    for (int v4 = 0; v4 < 4; ++v4) {
+                        f32x4 q4;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const int v = 4 * v4 + c;
+                            const int rl = rbase + 32 * ta + 8 * v4 + c;
+                            const float val = __fadd_rn(__fmul_rn(value(ta, tb, v, info[rl] + ecol), ls), infof[256 + rl]);
+                            q4[c] = val;
+                            const int gi = 2 * ta + (v4 >> 1);
+                            if ((v4 & 1) == 0 && c == 0) { bv[tb][gi] = val; bk[tb][gi] = rl; }
+                            else if (val > bv[tb][gi]) { bv[tb][gi] = val; bk[tb][gi] = rl; }
+                        }
+                        if (g.logits && col < g.N && 32 * ta + 8 * v4 < rows_left)
+                            *reinterpret_cast<f32x4 *>(lrow + 32 * ta + 8 * v4) = q4;
+                    }
+            }
+            if (g.idx) {
+                // a value beats another when it is larger, or equal with the lower row
+                auto better = [](float v1, int k1, float v2, int k2) { return v1 > v2 || (v1 == v2 && k1 < k2); };
+                const int K = g.K;
+#pragma unroll
+                for (int tb = 0; tb < 2; ++tb) {
+                    // the other half-wave holds the other 8 rows of every 16-row group
+#pragma unroll
+                    for (int gi = 0; gi < 4; ++gi) {
+                        const float ov = __shfl_xor(bv[tb][gi], 32, 64);
+                        const int ok = __shfl_xor(bk[tb][gi], 32, 64);
+                        if (better(ov, ok, bv[tb][gi], bk[tb][gi])) { bv[tb][gi] = ov; bk[tb][gi] = ok; }
+                    }
+                    // groups of 16 rows -> codebooks of K rows inside this wave's 64 rows (the later group wins only
+                    // with a strictly larger value)
+                    if (K >= 32) {
+                        if (bv[tb][1] > bv[tb][0]) { bv[tb][0] = bv[tb][1]; bk[tb][0] = bk[tb][1]; }
+                        if (bv[tb][3] > bv[tb][2]) { bv[tb][2] = bv[tb][3]; bk[tb][2] = bk[tb][3]; }
+                    }
+                    if (K >= 64 && bv[tb][2] > bv[tb][0]) { bv[tb][0] = bv[tb][2]; bk[tb][0] = bk[tb][2]; }
+                }
+                const int cl0 = cbase;
+                if (K <= 64) {
+                    if (kh == 0) {
+#pragma unroll
+                        for (int tb = 0; tb < 2; ++tb) {
+                            const long col = n0 + cl0 + 32 * tb;
+                            const int span = K / 16;
+#pragma unroll
+                            for (int gi = 0; gi < 4; ++gi) {
+                                const long row = m0 + bk[tb][gi];
+                                if ((gi % span) == 0 && col < g.N && row < g.M) g.idx[col * g.ncb + row / K] = (uint8_t)(row % K);
+                            }
+                        }
+                    }
+                } else {
+                    // K = 128: the two waves of a column meet in LDS; K = 256: and the two row tiles in registers
+                    float *exv = infof + 384;
+                    int *exk = info + 384 + 128;
+                    if (wm == 1 && kh == 0) {
+#pragma unroll
+                        for (int tb = 0; tb < 2; ++tb) { exv[cl0 + 32 * tb] = bv[tb][0]; exk[cl0 + 32 * tb] = bk[tb][0]; }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    if (wm == 0 && kh == 0) {
+                        const int half = (int)(t % H);
+#pragma unroll
+                        for (int tb = 0; tb < 2; ++tb) {
+                            const int cl = cl0 + 32 * tb;
+                            float v = bv[tb][0];
+                            long k = m0 + bk[tb][0];
+                            if (better(exv[cl], exk[cl], bv[tb][0], bk[tb][0])) { v = exv[cl]; k = m0 + exk[cl]; }
+                            if (half > 0 && !(v > runv[tb])) { v = runv[tb]; k = runk[tb]; }      // earlier rows win ties
+                            runv[tb] = v;
+                            runk[tb] = (int)k;
+                            const long col = n0 + cl;
+                            if (half == H - 1 && col < g.N && k < g.M) g.idx[col * g.ncb + k / K] = (uint8_t)(k % K);
+                        }
+                    }
+                }
+            }
+        }
+        if (!has_next) break;
+        // the info words are rewritten in the next epilogue: every wave must have read them
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        m0 = m0n;
+        n0 = n0n;
+        pcur = pnext;
+    }
+}
+
+}  // namespace mcq

@@ -349,364 +349,7 @@ __global__ void k_prepare_rows(const float *__restrict__ src, float scale, int a
     if (Q != nullptr && lane == 0) Q[row] = part;
 }
 
-// ---------------------------------------------------------------------- GEMM
-// out[b][n][k] = dot16(Bm[n][k][:], A[b][:]) for a 64-vector tile and one
-// codebook n per workgroup.  MFMA rows = codebook entries, columns = vectors, so the K
-// scores of one vector live in the 4 lanes {c, c+16, c+32, c+48}.
-//   MODE_LOGITS    : A[b] = lscale * x[b]   (quantization.py:278); epilogue: + bias, first-max argmax over k (:279, :301):
-//                    the logits never reach HBM
-//   MODE_LOGITS_OUT: as MODE_LOGITS and the logits are stored too (trainer: logits AND their argmax from one GEMM)
-//   MODE_XC        : A[b] = x[b] as is; epilogue: the raw products dot16(Bm[n][k], x[b]) are stored.  Builds the
-//                    table form's XC (Bm = C) and, with the scaled centers themselves as "vectors", the Gram matrix.
-enum { MODE_LOGITS = 0, MODE_LOGITS_OUT = 2, MODE_XC = 4 };
-
-constexpr int kGemmVec = 64;  // vectors per workgroup
-constexpr int kGemmBK = 32;   // floats of the feature axis per LDS stage (2 k-blocks)
-
-// LDS image of a [rows][32 floats] stage: 16-byte units at
-//   kb*4*rows + g*rows + (row ^ (g | kb<<2))      kb in {0,1}, g in 0..3
-// conflict-free for the fragment ds_read_b128 (lane (r,g) reads row base+r, unit g)
-// and for the staging ds_write_b128 (8 consecutive lanes write one row's 8 units).
-__device__ __forceinline__ int lds_unit(int rows, int row, int kb, int g) {
-    return kb * 4 * rows + g * rows + (row ^ (g | (kb << 2)));
-}
-
-template <int T, int MODE>
-__global__ void __launch_bounds__(256, 2)
-k_gemm(const float *__restrict__ Bm /*[N][K][Dp]*/, const float *__restrict__ xin /*x [B][D]*/, float lscale,
-       const float *__restrict__ bias, long B, int N, int D, int Dp, uint8_t *__restrict__ idx_out, float *__restrict__ out,
-       const float *__restrict__ lscale_ptr /* overrides lscale when non-null */, int xh /* x is fp16 */) {
-    constexpr int K = 16 * T;
-    if (lscale_ptr) lscale = *lscale_ptr;
-    const int nsh = __builtin_ctz((unsigned)N);    // N is a power of two: shift / mask instead of a division sequence
-    if ((long)(blockIdx.x >> nsh) * kGemmVec >= B) return;   // whole tile past the active list (uniform)
-    constexpr int A_UNITS = K * 8;           // 16-byte units of the entries tile per stage
-    constexpr int A_PER_THREAD = (A_UNITS + 255) / 256;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    f32x4 *ldsA = reinterpret_cast<f32x4 *>(smem);
-    f32x4 *ldsB = ldsA + A_UNITS;
-
-    const int n = blockIdx.x & (N - 1);
-    const long b0 = (long)(blockIdx.x >> nsh) * kGemmVec;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 15, g = lane >> 4;
-
-    const float *Bn = Bm + (long)n * K * Dp;
-    const int xstride = D;
-    const bool x_vec = ((D & 3) == 0) && ((reinterpret_cast<uintptr_t>(xin) & 15) == 0);
-
-    // staging assignment: unit f -> (row = f / 8, c = f % 8 -> kb = c / 4, g = c % 4).
-    // Every staging load is UNCONDITIONAL (row and k indices are clamped into range instead of
-    // guarded): a guarded load costs a branch and a full vmcnt(0) drain each.  Clamped loads fetch
-    // data that is never used: rows past the batch are dropped in the epilogue, the k-block past Dp
-    // of an odd tail is skipped by the MFMA loop.
-    long brow[2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        const long row = b0 + ((tid + 256 * s) >> 3);
-        brow[s] = row < B ? row : B - 1;
-    }
-    // the x rows of the logits pass are unpadded: vector loads only when D is already a multiple of 16
-    const bool fast = x_vec && D == Dp && !xh;
-    const _Float16 *xin_h = reinterpret_cast<const _Float16 *>(xin);
-    const bool fast_h = xh && D == Dp && ((reinterpret_cast<uintptr_t>(xin) & 7) == 0);
-
-    f32x4 acc[T];
-#pragma unroll
-    for (int t = 0; t < T; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    f32x4 stA[A_PER_THREAD], stB[2];
-    const int nkb = Dp / 16;
-    const int nsteps = (nkb + 1) / 2;
-
-    auto load_stage = [&](int step) {
-        const int k0 = step * kGemmBK;
-#pragma unroll
-        for (int s = 0; s < A_PER_THREAD; ++s) {
-            const int f = tid + 256 * s;
-            int row = f >> 3;
-            row = row < K ? row : K - 1;
-            int k = k0 + 4 * (f & 7);
-            k = k < Dp ? k : Dp - 4;
-            stA[s] = *reinterpret_cast<const f32x4 *>(Bn + (long)row * Dp + k);
-        }
-        if (fast) {
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                int k = k0 + 4 * ((tid + 256 * s) & 7);
-                k = k < Dp ? k : Dp - 4;
-                // raw loads only: the scaling happens when the stage is stored to LDS, so
-                // these loads stay in flight under the MFMAs of the current stage
-                stB[s] = *reinterpret_cast<const f32x4 *>(xin + brow[s] * xstride + k);
-            }
-        } else if (fast_h) {
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                int k = k0 + 4 * ((tid + 256 * s) & 7);
-                k = k < Dp ? k : Dp - 4;
-                stB[s] = load_h4(xin_h + brow[s] * xstride + k);
-            }
-        } else {
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int k = k0 + 4 * ((tid + 256 * s) & 7);
-                const float *xr = xin + brow[s] * xstride;
-                const _Float16 *xrh = xin_h + brow[s] * xstride;
-                f32x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int ke = (k + e < xstride) ? k + e : 0;
-                    const float val = xh ? (float)xrh[ke] : xr[ke];
-                    v[e] = (k + e < xstride) ? val : 0.f;
-                }
-                stB[s] = v;
-            }
-        }
-    };
-
-    load_stage(0);
-    for (int step = 0; step < nsteps; ++step) {
-#pragma unroll
-        for (int s = 0; s < A_PER_THREAD; ++s) {
-            const int f = tid + 256 * s;
-            if (f < A_UNITS) ldsA[lds_unit(K, f >> 3, (f & 7) >> 2, f & 3)] = stA[s];
-        }
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int f = tid + 256 * s;
-            const f32x4 v = (MODE == MODE_XC) ? stB[s] : stB[s] * lscale;
-            ldsB[lds_unit(kGemmVec, f >> 3, (f & 7) >> 2, f & 3)] = v;
-        }
-        __syncthreads();
-        if (step + 1 < nsteps) load_stage(step + 1);
-        const int kbs = (2 * step + 1 < nkb) ? 2 : 1;
-        for (int kb = 0; kb < kbs; ++kb) {
-            const f32x4 bf = ldsB[lds_unit(kGemmVec, 16 * wave + r, kb, g)];
-            f32x4 af[T];
-#pragma unroll
-            for (int t = 0; t < T; ++t) af[t] = ldsA[lds_unit(K, 16 * t + r, kb, g)];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-#pragma unroll
-                for (int t = 0; t < T; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t][i], bf[i], acc[t], 0, 0, 0);
-            }
-        }
-        __syncthreads();
-    }
-
-    // epilogue: lane holds, for vector b0 + 16*wave + r, entries k = 16t + 4g + v
-    const long b = b0 + 16 * wave + r;
-    if (MODE == MODE_XC) {
-        if (b < B) {
-#pragma unroll
-            for (int t = 0; t < T; ++t) *reinterpret_cast<f32x4 *>(out + (b * N + n) * (long)K + 16 * t + 4 * g) = acc[t];
-        }
-    } else {
-        float best = -INFINITY;
-        int bk = 0;
-        bool first = true;
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-            const f32x4 bi = *reinterpret_cast<const f32x4 *>(bias + (long)n * K + 16 * t + 4 * g);
-            f32x4 lv;
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                lv[v] = acc[t][v] + bi[v];
-                const int k = 16 * t + 4 * g + v;
-                if (first || lv[v] > best) { best = lv[v]; bk = k; first = false; }
-            }
-            if (MODE == MODE_LOGITS_OUT && b < B)
-                *reinterpret_cast<f32x4 *>(out + (b * N + n) * (long)K + 16 * t + 4 * g) = lv;
-        }
-        if (MODE == MODE_LOGITS || (MODE == MODE_LOGITS_OUT && idx_out != nullptr)) {
-            // combine the 4 lanes of this vector: first maximum = greatest value, lowest k on ties
-#pragma unroll
-            for (int m = 16; m <= 32; m <<= 1) {
-                const float ov = __shfl_xor(best, m, 64);
-                const int ok = __shfl_xor(bk, m, 64);
-                const bool take = (ov > best) || (ov == best && ok < bk);
-                best = take ? ov : best;
-                bk = take ? ok : bk;
-            }
-            if (g == 0 && b < B) idx_out[b * N + n] = (uint8_t)bk;
-        }
-    }
-}
-
-// ---- 8/16-wave variant (K >= 32): the default GEMM -----------------------------------------
-// Same tile and numerics as k_gemm, but the K entries are split over two groups of VGN waves: each
-// wave owns 16 vectors x K/2 entries (half the accumulators and fragments: <= 128 VGPRs, 4 waves per
-// SIMD).  A stage is ONE k-block (20 KB at K = 256) and there are two LDS buffers, so a wave stores
-// stage s+1 right after issuing its MFMAs of stage s while the other waves of the SIMD are still
-// computing; the loads of stage s+2 are issued after the barrier (one barrier per stage).
-// Ablation (dim 512): without the per-stage LDS stores the loop runs at 135 TFLOP/s, without the global loads 125,
-// as is 108-115: barriers are free, and LDS-DMA staging, 32-float stages, 32 x 32 MFMA tiles with a third fewer fragment
-// reads, register-prefetched fragments and two-block-ahead global loads all measured no better.
-// one k-block stage: row-major [row][4 units], unit index xor-ed with bits 1-2 of the row:
-// conflict-free for the fragment ds_read_b128 and for the staging ds_write_b128 (4 lanes per row),
-// checked by brute force in tools/lds_conflicts.py
-__device__ __forceinline__ int lds_unit1(int rows, int row, int g) { (void)rows; return row * 4 + (g ^ ((row >> 1) & 3)); }
-
-template <int T, int MODE, int VGN>
-__global__ void __launch_bounds__(128 * VGN, 4)
-k_gemm8s(const float *__restrict__ Bm, const float *__restrict__ xin, float lscale, const float *__restrict__ bias, long B,
-         int N, int D, int Dp, uint8_t *__restrict__ idx_out, float *__restrict__ out,
-         const float *__restrict__ lscale_ptr /* overrides lscale when non-null */, int xh /* x is fp16 */) {
-    if (lscale_ptr) lscale = *lscale_ptr;
-    const int nsh = __builtin_ctz((unsigned)N);    // N is a power of two: shift / mask instead of a division sequence
-    static_assert(T >= 2 && T % 2 == 0, "k_gemm8s splits the entry tiles over two wave groups");
-    constexpr int K = 16 * T;
-    constexpr int TW = T / 2;
-    constexpr int NT = 128 * VGN;             // VGN vector groups x 2 entry halves, one wave each
-    constexpr int VEC = 16 * VGN;              // vectors per workgroup
-    constexpr int A_UNITS = K * 4;                 // 16-byte units of one k-block of the entries tile
-    constexpr int B_UNITS = VEC * 4;
-    constexpr int A_PER_THREAD = (A_UNITS + NT - 1) / NT;
-    constexpr int STAGE_UNITS = A_UNITS + B_UNITS;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    f32x4 *lds = reinterpret_cast<f32x4 *>(smem);  // [2][STAGE_UNITS]
-
-    const int n = blockIdx.x & (N - 1);
-    const long b0 = (long)(blockIdx.x >> nsh) * VEC;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int vg = wave % VGN, eh = wave / VGN;
-    const int r = lane & 15, g = lane >> 4;
-    const float *Bn = Bm + (long)n * K * Dp;
-    const int xstride = D;
-    const bool x_vec = ((D & 3) == 0) && ((reinterpret_cast<uintptr_t>(xin) & 15) == 0);
-    const bool fast = x_vec && D == Dp && !xh;
-    const bool fast_h = xh && D == Dp && ((reinterpret_cast<uintptr_t>(xin) & 7) == 0);
-
-    // staging: unit f -> (row = f / 4, g = f % 4); threads 0..255 also stage the vector tile
-    const bool has_b = tid < B_UNITS;
-    long browl = b0 + ((tid & (B_UNITS - 1)) >> 2);
-    browl = browl < B ? browl : B - 1;
-    const float *xbase = xin + b0 * xstride;
-    const _Float16 *xbase_h = reinterpret_cast<const _Float16 *>(xin) + b0 * xstride;
-    const uint32_t xoff = (uint32_t)((browl - b0) * xstride) + 4 * (tid & 3);
-    uint32_t aoff[A_PER_THREAD];
-#pragma unroll
-    for (int s = 0; s < A_PER_THREAD; ++s) {
-        int row = (tid + NT * s) >> 2;
-        row = row < K ? row : K - 1;
-        aoff[s] = (uint32_t)(row * Dp) + 4 * (tid & 3);
-    }
-
-    f32x4 acc[TW];
-#pragma unroll
-    for (int t = 0; t < TW; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    f32x4 stA[A_PER_THREAD], stB = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int nkb = Dp / 16;
-
-    auto load_stage = [&](int kb) {
-        const uint32_t k = (uint32_t)(16 * kb);
-#pragma unroll
-        for (int s = 0; s < A_PER_THREAD; ++s) stA[s] = *reinterpret_cast<const f32x4 *>(Bn + (aoff[s] + k));
-        if (has_b) {
-            if (fast) {
-                stB = *reinterpret_cast<const f32x4 *>(xbase + (xoff + k));
-            } else if (fast_h) {
-                stB = load_h4(xbase_h + (xoff + k));
-            } else {
-                const int kk = 16 * kb + 4 * (tid & 3);
-                const float *xr = xbase + (xoff - 4 * (tid & 3));
-                const _Float16 *xrh = xbase_h + (xoff - 4 * (tid & 3));
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int ke = (kk + e < xstride) ? kk + e : 0;
-                    const float val = xh ? (float)xrh[ke] : xr[ke];
-                    stB[e] = (kk + e < xstride) ? val : 0.f;
-                }
-            }
-        }
-    };
-    auto store_stage = [&](int buf) {
-        f32x4 *sa = lds + (size_t)buf * STAGE_UNITS, *sb = sa + A_UNITS;
-#pragma unroll
-        for (int s = 0; s < A_PER_THREAD; ++s) {
-            const int f = tid + NT * s;
-            if (f < A_UNITS) sa[lds_unit1(K, f >> 2, f & 3)] = stA[s];
-        }
-        if (has_b) {
-            const f32x4 v = (MODE == MODE_XC) ? stB : stB * lscale;
-            sb[lds_unit1(VEC, tid >> 2, tid & 3)] = v;
-        }
-    };
-
-    load_stage(0);
-    store_stage(0);
-    __syncthreads();
-    if (nkb > 1) load_stage(1);
-    // one k-block: fragments from buffer BUF (a compile-time constant: every LDS address of the loop body is a
-    // loop-invariant register plus an immediate), MFMAs, then the next stage goes to the other buffer
-    auto kstep = [&](int kb, auto BUF) {
-        constexpr int buf = decltype(BUF)::value;
-        const f32x4 *sa = lds + (size_t)buf * STAGE_UNITS, *sb = sa + A_UNITS;
-        const f32x4 bf = sb[lds_unit1(VEC, 16 * vg + r, g)];
-        f32x4 af[TW];
-#pragma unroll
-        for (int t = 0; t < TW; ++t) af[t] = sa[lds_unit1(K, 16 * (eh * TW + t) + r, g)];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int t = 0; t < TW; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t][i], bf[i], acc[t], 0, 0, 0);
-        if (kb + 1 < nkb) store_stage(buf ^ 1);
-        __syncthreads();
-        if (kb + 2 < nkb) load_stage(kb + 2);
-    };
-    for (int kb = 0; kb < nkb; kb += 2) {
-        kstep(kb, std::integral_constant<int, 0>{});
-        if (kb + 1 < nkb) kstep(kb + 1, std::integral_constant<int, 1>{});
-    }
-
-    // epilogue: lane holds, for vector b0 + 16*vg + r, entries 16*(eh*TW+t) + 4g + v
-    const long b = b0 + 16 * vg + r;
-    if (MODE == MODE_XC) {
-        if (b < B) {
-#pragma unroll
-            for (int t = 0; t < TW; ++t)
-                *reinterpret_cast<f32x4 *>(out + (b * N + n) * (long)K + 16 * (eh * TW + t) + 4 * g) = acc[t];
-        }
-    } else {
-        float best = -INFINITY;
-        int bk = 0;
-        bool first = true;
-#pragma unroll
-        for (int t = 0; t < TW; ++t) {
-            const int k0 = 16 * (eh * TW + t) + 4 * g;
-            const f32x4 bi = *reinterpret_cast<const f32x4 *>(bias + (long)n * K + k0);
-            f32x4 lv;
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                lv[v] = acc[t][v] + bi[v];
-                if (first || lv[v] > best) { best = lv[v]; bk = k0 + v; first = false; }
-            }
-            if (MODE == MODE_LOGITS_OUT && b < B) *reinterpret_cast<f32x4 *>(out + (b * N + n) * (long)K + k0) = lv;
-        }
-        if (MODE == MODE_LOGITS || (MODE == MODE_LOGITS_OUT && idx_out != nullptr)) {
-#pragma unroll
-            for (int m = 16; m <= 32; m <<= 1) {
-                const float ov = __shfl_xor(best, m, 64);
-                const int ok = __shfl_xor(bk, m, 64);
-                const bool take = (ov > best) || (ov == best && ok < bk);
-                best = take ? ov : best;
-                bk = take ? ok : bk;
-            }
-            float *cv = reinterpret_cast<float *>(smem);
-            int *ck = reinterpret_cast<int *>(smem) + VEC;
-            __syncthreads();   // every wave is done reading the last stage
-            if (eh == 1 && g == 0) { cv[16 * vg + r] = best; ck[16 * vg + r] = bk; }
-            __syncthreads();
-            if (eh == 0 && g == 0 && b < B) {
-                const float ov = cv[16 * vg + r];
-                const int ok = ck[16 * vg + r];
-                idx_out[b * N + n] = (uint8_t)((ov > best) ? ok : bk);
-            }
-        }
-    }
-}
+// (the inner-product tables of the path -- logits, x.C, the Gram matrix -- are formed by mcq_fix_kernels.h)
 
 // ------------------------------------------------------- fixed-point skipping
 // _refine_indexes is a deterministic map F of (x, indexes): once F(idx) == idx every later pass

@@ -410,8 +410,9 @@ class Quantizer(nn.Module):
             blob = self._prepared()
         with torch.cuda.device(x2d.device):
             st = torch.cuda.current_stream(x2d.device).cuda_stream
+            ws = torch.empty(L.mcq_logits_workspace_bytes(x2d.shape[0], N, D), dtype=torch.uint8, device=x2d.device)
             rc = L.mcq_logits(x2d.data_ptr(), x2d.shape[0], blob.data_ptr(), self._lscale_exp, N, K, D,
-                              out.data_ptr(), st)
+                              out.data_ptr(), ws.data_ptr(), ws.numel(), st)
         _lib.check(rc, "mcq_logits")
         return out
 

@@ -25,7 +25,7 @@ def lib():
     H.mcq_encode_host.argtypes = [vp, i64, vp, f32, i32, i32, i32, i32, vp, vp, vp, sz, vp]
     H.mcq_refine_indexes_host.argtypes = [vp, i64, vp, i32, i32, i32, i32, vp, vp, vp, sz, vp]
     H.mcq_decode_host.argtypes = [vp, i32, i32, i64, vp, i32, i32, i32, vp, vp]
-    H.mcq_logits_host.argtypes = [vp, i64, vp, f32, i32, i32, i32, vp, vp]
+    H.mcq_logits_host.argtypes = [vp, i64, vp, f32, i32, i32, i32, vp, vp, ctypes.c_size_t, vp]
     _h = H
     return H
 

@@ -142,8 +142,9 @@ def test_one_argument_list_through_both_libraries(name):
     # -- logits (first 64 vectors)
     hl = np.zeros((64, N * K), np.float32)
     dl = torch.zeros((64, N * K), dtype=torch.float32, device=dev)
-    lg = lambda x, blob, out: (x, 64, blob, ls, N, K, D, out, None)
-    assert H.mcq_logits_host(*lg(ht.ptr(host["x"]), ht.ptr(hblob), ht.ptr(hl))) == 0
-    assert L.mcq_logits(*lg(d["x"].data_ptr(), dblob.data_ptr(), dl.data_ptr())) == 0
+    lws = torch.zeros(L.mcq_logits_workspace_bytes(64, N, D), dtype=torch.uint8, device=dev)
+    lg = lambda x, blob, out, ws, wsn: (x, 64, blob, ls, N, K, D, out, ws, wsn, None)
+    assert H.mcq_logits_host(*lg(ht.ptr(host["x"]), ht.ptr(hblob), ht.ptr(hl), None, 0)) == 0
+    assert L.mcq_logits(*lg(d["x"].data_ptr(), dblob.data_ptr(), dl.data_ptr(), lws.data_ptr(), lws.numel())) == 0
     torch.cuda.synchronize()
     assert np.array_equal(dl.cpu().numpy().view(np.uint32), hl.view(np.uint32)), "logits not bit-identical"
