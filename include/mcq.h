@@ -69,6 +69,9 @@ int mcq_padded_dim(int D);
  * by the caller in fp32 exactly as the reference does (:78, :278).
  * weight/bias may be NULL when only decode is needed.                          */
 size_t mcq_prepared_bytes(int N, int K, int D);
+/* byte offset inside `prepared` of float[mcq_padded_dim(D)]: get_data_mean() (:67-75) of the scaled centers,
+ * sum_n mean_k C[n][k][:] (the scaled centers themselves are at offset 0, [N][K][mcq_padded_dim(D)])            */
+size_t mcq_prepared_mean_offset(int N, int K, int D);
 int mcq_prepare(const float *centers, float cscale_exp, const float *weight, const float *bias,
                 int N, int K, int D, void *prepared, void *stream);
 
@@ -142,6 +145,12 @@ int mcq_decode_backward(const float *grad_out, const int64_t *idx, long B, int N
  * mcq_refine_indexes.  workspace >= mcq_logits_workspace_bytes(B, N, D).  flags: MCQ_ENCODE_LSCALE_FROM_PREPARED, MCQ_ENCODE_X_FP16. */
 int mcq_logits_argmax(const float *x, long B, const void *prepared, float lscale_exp, int N, int K, int D,
                       float *logits_out, int64_t *argmax_out, void *workspace, size_t workspace_bytes,
+                      void *stream, unsigned flags);
+
+/* mcq_logits_argmax followed by mcq_refine_indexes in one call (what compute_loss needs, :211-219): logits_out as above,
+ * idx_out int64 [B][N] = the indexes after `refine_iters` passes.  workspace as for mcq_encode.             */
+int mcq_logits_refine(const float *x, long B, const void *prepared, float lscale_exp, int N, int K, int D,
+                      int refine_iters, float *logits_out, int64_t *idx_out, void *workspace, size_t workspace_bytes,
                       void *stream, unsigned flags);
 
 /* Log-softmax statistics of logits [B][N*K] against indexes int64 [B][N] (:221-240):

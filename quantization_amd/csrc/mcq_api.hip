@@ -32,7 +32,7 @@ struct Prepared {
 };
 
 struct PreparedLayout {
-    size_t offC, offQ, offCf, offCe, offWf, offWe, offBias, offScales, offG, total;
+    size_t offC, offQ, offCf, offCe, offWf, offWe, offBias, offScales, offMean, offG, total;
 };
 
 PreparedLayout prepared_layout(int N, int K, int D) {
@@ -47,7 +47,8 @@ PreparedLayout prepared_layout(int N, int K, int D) {
     l.offWe = align256(l.offWf + planes);
     l.offBias = align256(l.offWe + exps);
     l.offScales = align256(l.offBias + nk * 4);   // float[2] {cscale_exp, lscale_exp} (mcq_prepare_dev)
-    l.offG = align256(l.offScales + 8);           // Gram matrix G[nk][nk] of the scaled centers
+    l.offMean = align256(l.offScales + 8);        // get_data_mean() of the scaled centers, float[Dp]
+    l.offG = align256(l.offMean + Dp * 4);        // Gram matrix G[nk][nk] of the scaled centers
     l.total = align256(l.offG + nk * nk * 4);
     return l;
 }
@@ -177,10 +178,15 @@ thread_local int g_last_launches = 0;
     } while (0)
 
 // rows -> limb planes + exponents (+ |row|^2): the operands of every product of the path
-int launch_fix_rows(const float *src, int xh, long R, int D, long ld, int8_t *planes, int *exps, float *xx, hipStream_t st) {
+int launch_fix_rows(const float *src, int xh, long R, int D, long ld, int8_t *planes, int *exps, float *xx, hipStream_t st,
+                    const float *bias_src = nullptr, float *bias_dst = nullptr) {
     const long Rp = fix_round_rows(R);
-    hipLaunchKernelGGL(k_fix_rows, dim3((unsigned)(Rp / 16)), dim3(256), 0, st, src, xh, R, Rp, D, ld, fix_round_cols(D), planes,
-                       exps, xx);
+    if (Rp / 16 >= 1024)      // many rows: 16 per workgroup (256-byte runs into the planes)
+        hipLaunchKernelGGL(k_fix_rows<16>, dim3((unsigned)(Rp / 16)), dim3(256), 0, st, src, xh, R, Rp, D, ld, fix_round_cols(D),
+                           planes, exps, xx, bias_src, bias_dst);
+    else                      // few rows (a codebook set, a trainer batch): 4 per workgroup, one per wave
+        hipLaunchKernelGGL(k_fix_rows<4>, dim3((unsigned)(Rp / 4)), dim3(256), 0, st, src, xh, R, Rp, D, ld, fix_round_cols(D),
+                           planes, exps, xx, bias_src, bias_dst);
     MCQ_LAUNCH_CHECK();
     return 0;
 }
@@ -361,7 +367,7 @@ int run_tf_combines(const float *G, const uint8_t *idx_cur, uint8_t *idx_new, co
 
 int run_encode(const float *x, long B, const void *prepared, float lscale, int N, int K, int D, int iters,
                uint8_t *out_u8, int64_t *out_i64, void *workspace, size_t workspace_bytes, hipStream_t st,
-               Prof *prof, const int64_t *init_idx = nullptr, unsigned flags = 0) {
+               Prof *prof, const int64_t *init_idx = nullptr, unsigned flags = 0, float *logits_out = nullptr) {
     g_last_launches = 0;
     if (!domain_ok(N, K, D)) return domain_err(N, K, D);
     if (B < 0 || iters < 0 || iters > 60 || (out_u8 == nullptr) == (out_i64 == nullptr)) return MCQ_EINVAL;
@@ -399,7 +405,8 @@ int run_encode(const float *x, long B, const void *prepared, float lscale, int N
         } else {
             if (prof) prof->begin();
             rc = launch_logits(w.xf, w.xe, Bc, P, N, K, D, lscale,
-                               (flags & MCQ_ENCODE_LSCALE_FROM_PREPARED) ? P.scales + 1 : nullptr, nullptr, w.idx, st);
+                               (flags & MCQ_ENCODE_LSCALE_FROM_PREPARED) ? P.scales + 1 : nullptr,
+                               logits_out ? logits_out + lo * N * K : nullptr, w.idx, st);
             if (rc) return rc;
             if (prof) prof->end(CAT_LOGITS);
         }
@@ -496,24 +503,23 @@ static int prepare_impl(const float *centers, float cscale_exp, const float *sca
     const int Dp = round_up16(D);
     const unsigned grid = (unsigned)((rows + 3) / 4);
     hipLaunchKernelGGL(k_prepare_rows, dim3(grid), dim3(256), 0, st, centers, cscale_exp, 1, rows, D, Dp,
-                       reinterpret_cast<float *>(b + l.offC), reinterpret_cast<float *>(b + l.offQ), scales_dev);
+                       reinterpret_cast<float *>(b + l.offC), reinterpret_cast<float *>(b + l.offQ), scales_dev,
+                       scales_dev ? reinterpret_cast<float *>(b + l.offScales) : static_cast<float *>(nullptr));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
-    // the scaled centers (and the classifier rows) as limb planes: the tables of the fixed-point products
     const float *C = reinterpret_cast<const float *>(b + l.offC);
+    hipLaunchKernelGGL(k_centers_mean, dim3((unsigned)((Dp + 63) / 64)), dim3(256), 0, st, C, N, K, Dp,
+                       reinterpret_cast<float *>(b + l.offMean));
+    e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    // the scaled centers (and the classifier rows) as limb planes: the tables of the fixed-point products
     int rc = launch_fix_rows(C, 0, rows, Dp, Dp, reinterpret_cast<int8_t *>(b + l.offCf), reinterpret_cast<int *>(b + l.offCe),
                              nullptr, st);
     if (rc) return rc;
     if (weight) {
         rc = launch_fix_rows(weight, 0, rows, D, D, reinterpret_cast<int8_t *>(b + l.offWf), reinterpret_cast<int *>(b + l.offWe),
-                             nullptr, st);
+                             nullptr, st, bias, reinterpret_cast<float *>(b + l.offBias));      // (the bias rides along)
         if (rc) return rc;
-        e = hipMemcpyAsync(b + l.offBias, bias, (size_t)rows * 4, hipMemcpyDeviceToDevice, st);
-        if (e != hipSuccess) return (int)e;
-    }
-    if (scales_dev) {
-        e = hipMemcpyAsync(b + l.offScales, scales_dev, 8, hipMemcpyDeviceToDevice, st);
-        if (e != hipSuccess) return (int)e;
     }
     if (weight) {
         // Gram matrix of the scaled centers: the x.C product with the centers themselves as the frames
@@ -523,6 +529,11 @@ static int prepare_impl(const float *centers, float cscale_exp, const float *sca
         if (rc) return rc;
     }
     return 0;
+}
+
+size_t mcq_prepared_mean_offset(int N, int K, int D) {
+    if (N <= 0 || K <= 0 || D <= 0) return 0;
+    return prepared_layout(N, K, D).offMean;
 }
 
 int mcq_prepare(const float *centers, float cscale_exp, const float *weight, const float *bias, int N, int K, int D,
@@ -758,6 +769,16 @@ int mcq_logits_argmax(const float *x, long B, const void *prepared, float lscale
     hipLaunchKernelGGL(k_export_indexes, dim3((unsigned)((B * N + 255) / 256)), dim3(256), 0, st, w.idx8, B * N, argmax_out);
     MCQ_LAUNCH_CHECK();
     return 0;
+}
+
+// logits (stored) + arg max + refinement passes in one call: the frames become limb planes once, the indexes stay bytes
+// until the end (what QuantizerTrainer.step runs: mcq_logits_argmax followed by mcq_refine_indexes, without the detours)
+int mcq_logits_refine(const float *x, long B, const void *prepared, float lscale_exp, int N, int K, int D, int refine_iters,
+                      float *logits_out, int64_t *idx_out, void *workspace, size_t workspace_bytes, void *stream,
+                      unsigned flags) {
+    if (B > 0 && (!logits_out || !idx_out)) return MCQ_EINVAL;
+    return run_encode(x, B, prepared, lscale_exp, N, K, D, refine_iters, nullptr, idx_out, workspace, workspace_bytes,
+                      static_cast<hipStream_t>(stream), nullptr, nullptr, flags & ~MCQ_ENCODE_SKIP_FIXED_POINTS, logits_out);
 }
 
 namespace {

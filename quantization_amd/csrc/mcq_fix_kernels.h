@@ -42,17 +42,22 @@ __device__ __forceinline__ int fix_q(float v, int e) {
     return (int)rintf(s);
 }
 
-// Workgroup = 16 rows (wave w: rows 4w .. 4w+3).  Pass 1: the row exponent (and, for frames, |x|^2 as k_tf_xx formed it:
-// lane l adds the float4 groups l, l + 64, ... then the butterfly).  Pass 2, per block of 512 columns: limbs to LDS as
-// [plane][row][16 bytes], then 256-byte runs (16 rows of one plane) to the planes.
+// Workgroup = RW rows (16, or 4 when there are few rows: more workgroups), wave w takes RW / 4 of them.  Pass 1: the row
+// exponent (and, for frames, |x|^2 as the sum of squares of the path is formed: lane l adds the float4 groups l, l + 64,
+// ... then the butterfly); rows of up to 1,024 columns stay in registers for pass 2.  Pass 2, per block of 512 columns:
+// limbs to LDS as [plane][row][16 bytes], then runs of RW x 16 bytes (RW rows of one plane) to the planes.
 // src: fp32 rows of `ld` floats (or fp16 rows of `ld` halves when xh), D valid columns; rows >= R are written as zeros.
+// bias_src / bias_dst: optional copy of R floats riding along (the classifier's bias into `prepared`).
+template <int RW>
 __global__ void __launch_bounds__(256)
 k_fix_rows(const float *__restrict__ src, int xh, long R, long Rp, int D, long ld, int Dq, int8_t *__restrict__ planes,
-           int *__restrict__ exps, float *__restrict__ xx) {
-    __shared__ __attribute__((aligned(16))) unsigned tile[128 * 16 * 4];      // [plane of the block][row][4 words]
-    __shared__ int es[16];
+           int *__restrict__ exps, float *__restrict__ xx, const float *__restrict__ bias_src, float *__restrict__ bias_dst) {
+    constexpr int RPW = RW / 4;
+    __shared__ __attribute__((aligned(16))) unsigned tile[128 * RW * 4];      // [plane of the block][row][4 words]
+    __shared__ int es[RW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long row0 = (long)blockIdx.x * 16;
+    const long row0 = (long)blockIdx.x * RW;
+    if (bias_src && tid < RW && row0 + tid < R) bias_dst[row0 + tid] = bias_src[row0 + tid];
     const _Float16 *srch = reinterpret_cast<const _Float16 *>(src);
     const bool vec_ok = ((ld & 3) == 0) && ((D & 3) == 0) && ((reinterpret_cast<uintptr_t>(src) & (xh ? 7 : 15)) == 0);
     auto load4 = [&](long row, int q) -> f32x4 {      // float4 group q of a row, zero past D
@@ -64,15 +69,30 @@ k_fix_rows(const float *__restrict__ src, int xh, long R, long Rp, int D, long l
             if (4 * q + c < D) v[c] = xh ? (float)srch[row * ld + 4 * q + c] : src[row * ld + 4 * q + c];
         return v;
     };
-    for (int rr = 0; rr < 4; ++rr) {
-        const long row = row0 + 4 * wave + rr;
-        float m = 0.f, pe = 0.f;
-        for (int q = lane; q < (D + 3) / 4; q += 64) {
-            const f32x4 v = load4(row, q);
+    const bool cached = D <= 1024;
+    f32x4 cache[RPW][4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                m = fmaxf(m, fabsf(v[c]));
-                pe = fmaf(v[c], v[c], pe);
+    for (int rr = 0; rr < RPW; ++rr) {
+        const long row = row0 + RPW * wave + rr;
+        float m = 0.f, pe = 0.f;
+        if (cached) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cache[rr][j] = load4(row, lane + 64 * j);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    m = fmaxf(m, fabsf(cache[rr][j][c]));
+                    pe = fmaf(cache[rr][j][c], cache[rr][j][c], pe);      // (groups past D are zeros: fmaf(0, 0, pe) == pe)
+                }
+        } else {
+            for (int q = lane; q < (D + 3) / 4; q += 64) {
+                const f32x4 v = load4(row, q);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    m = fmaxf(m, fabsf(v[c]));
+                    pe = fmaf(v[c], v[c], pe);
+                }
             }
         }
         for (int s = 32; s >= 1; s >>= 1) m = fmaxf(m, __shfl_xor(m, s, 64));
@@ -80,7 +100,7 @@ k_fix_rows(const float *__restrict__ src, int xh, long R, long Rp, int D, long l
         if (lane == 0) {
             const int be = (int)((__float_as_uint(m) >> 23) & 0xff);
             const int e = (be < 1 ? 1 : be) - 126;
-            es[4 * wave + rr] = e;
+            es[RPW * wave + rr] = e;
             if (row < Rp) exps[row] = e;
             if (xx && row < R) xx[row] = pe;
         }
@@ -88,11 +108,15 @@ k_fix_rows(const float *__restrict__ src, int xh, long R, long Rp, int D, long l
     __syncthreads();
     for (int c0 = 0; c0 < Dq; c0 += 512) {
         const int ncol = (Dq - c0 < 512) ? Dq - c0 : 512;          // columns of this block (a multiple of 128)
-        for (int rr = 0; rr < 4; ++rr) {
-            const int rl = 4 * wave + rr;
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int rl = RPW * wave + rr;
             const int e = es[rl];
-            for (int q = lane; q < ncol / 4; q += 64) {
-                const f32x4 v = load4(row0 + rl, c0 / 4 + q);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int q = lane + 64 * j;
+                if (q >= ncol / 4) continue;
+                const f32x4 v = cached ? cache[rr][(c0 >> 9) * 2 + j] : load4(row0 + rl, c0 / 4 + q);
                 unsigned w[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
@@ -107,15 +131,15 @@ k_fix_rows(const float *__restrict__ src, int xh, long R, long Rp, int D, long l
                 }
                 const int chunk = q >> 2, word = q & 3;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) tile[((chunk * 4 + i) * 16 + rl) * 4 + word] = w[i];
+                for (int i = 0; i < 4; ++i) tile[((chunk * 4 + i) * RW + rl) * 4 + word] = w[i];
             }
         }
         __syncthreads();
         const int nplanes = ncol / 16 * 4;
-        for (int p = tid >> 4; p < nplanes; p += 16) {
-            const int rl = tid & 15;
+        for (int p = tid / RW; p < nplanes; p += 256 / RW) {
+            const int rl = tid % RW;
             if (row0 + rl < Rp) {
-                const i32x4 v = *reinterpret_cast<const i32x4 *>(&tile[(p * 16 + rl) * 4]);
+                const i32x4 v = *reinterpret_cast<const i32x4 *>(&tile[(p * RW + rl) * 4]);
                 *reinterpret_cast<i32x4 *>(planes + (((long)(c0 / 16) * 4 + p) * Rp + row0 + rl) * 16) = v;
             }
         }

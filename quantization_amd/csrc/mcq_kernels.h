@@ -325,11 +325,15 @@ __device__ __forceinline__ void wave_select_fast(const float (&v)[VPL], const in
 // (get_centers(), quantization.py:77-79; all_centers_sumsq, :411)
 __global__ void k_prepare_rows(const float *__restrict__ src, float scale, int apply_scale, long rows, int D,
                                int Dp, float *__restrict__ dst, float *__restrict__ Q,
-                               const float *__restrict__ scale_ptr /* overrides `scale` when non-null */) {
+                               const float *__restrict__ scale_ptr /* overrides `scale` when non-null */,
+                               float *__restrict__ scales_out /* optional: scale_ptr[0..1] is copied here */) {
     const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= rows) return;
-    if (scale_ptr) scale = *scale_ptr;
     const int lane = lane_id();
+    if (scale_ptr) {
+        scale = *scale_ptr;
+        if (scales_out && row == 0 && lane < 2) scales_out[lane] = scale_ptr[lane];
+    }
     const float *s = src + row * D;
     float *d = dst + row * Dp;
     float part = 0.f;

@@ -4,6 +4,7 @@
 //   k_adam       torch.optim.Adam's update on one flat parameter / gradient / moment bucket (:712, :722-727)
 //   k_loss_head  the four batch sums mcq_loss_tail consumes, from the forward kernels' partials
 //   k_scales     exp(speed * scale) of the two scale parameters, on the device
+//   k_centers_mean  get_data_mean() (:67-75) of the scaled centers
 // Reductions have a fixed order (no float atomics): a training run is bit-reproducible.
 #pragma once
 #include "mcq_kernels.h"
@@ -254,6 +255,29 @@ __global__ void k_scales(const float *__restrict__ centers_scale, const float *_
                          float *__restrict__ out) {
     if (threadIdx.x == 0) out[0] = expf(*centers_scale * speed);
     if (threadIdx.x == 1) out[1] = expf(*logits_scale * speed);
+}
+
+// mean[d] = sum_n (sum_k C[n][k][d]) / K   (get_data_mean, :67-75: centers.mean(dim=1).sum(dim=0)), k and n ascending.
+// Workgroup = 64 columns; wave w adds the codebooks w, w + 4, ...; wave 0 adds the per-codebook means.
+__global__ void __launch_bounds__(256)
+k_centers_mean(const float *__restrict__ C /*[N][K][Dp]*/, int N, int K, int Dp, float *__restrict__ mean /*[Dp]*/) {
+    __shared__ float part[64][64];      // [codebook][column]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int d = blockIdx.x * 64 + lane;
+    for (int n = wave; n < N; n += 4) {
+        float s = 0.f;
+        if (d < Dp) {
+            const float *c = C + (size_t)n * K * Dp + d;
+            for (int k = 0; k < K; ++k) s = s + c[(size_t)k * Dp];
+        }
+        part[n][lane] = s / (float)K;
+    }
+    __syncthreads();
+    if (wave == 0 && d < Dp) {
+        float t = part[0][lane];
+        for (int n = 1; n < N; ++n) t = t + part[n][lane];
+        mean[d] = t;
+    }
 }
 
 }  // namespace mcq

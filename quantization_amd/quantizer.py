@@ -539,8 +539,8 @@ class _LossState:
 
 
 def _loss_forward_kernels(module, x, iters, blob, lscale_exp, flags, prob_sum=None, count=None) -> _LossState:
-    """mcq_logits_argmax (one GEMM gives the logits AND the initial indexes), mcq_refine_indexes,
-    mcq_recon_fwd, mcq_loss_fwd on x (B, dim) fp32/fp16 on the HIP device."""
+    """mcq_logits_refine (one product gives the logits AND the initial indexes, the passes follow), mcq_recon_fwd,
+    mcq_loss_fwd on x (B, dim) fp32/fp16 on the HIP device."""
     L = _lib.lib()
     N, K, D = module.num_codebooks, module.codebook_size, module.dim
     x_fp16 = x.dtype == torch.float16
@@ -552,10 +552,10 @@ def _loss_forward_kernels(module, x, iters, blob, lscale_exp, flags, prob_sum=No
     st_.idx = torch.empty((B, N), dtype=torch.int64, device=dev)
     ws = module._workspace(B, dev)
     st_.xf = xk.float() if x_fp16 else xk
-    # get_data_mean() (:67-75) from the scaled centers already sitting in the prepared blob
+    # get_data_mean() (:67-75) of the scaled centers: formed by mcq_prepare inside the prepared blob
     Dp = L.mcq_padded_dim(D)
-    C = blob[:N * K * Dp * 4].view(torch.float32).view(N, K, Dp)
-    mean = C.mean(dim=1).sum(dim=0)[:D].contiguous()
+    moff = L.mcq_prepared_mean_offset(N, K, D)
+    mean = blob[moff:moff + 4 * Dp].view(torch.float32)[:D]
     st_.err = torch.empty((B, D), **f32)
     st_.parts = torch.empty((2, (B + 3) // 4), **f32)
     st_.lse = torch.empty((B, N), **f32)
@@ -565,12 +565,9 @@ def _loss_forward_kernels(module, x, iters, blob, lscale_exp, flags, prob_sum=No
     lws = torch.empty(L.mcq_loss_workspace_bytes(B, N, K), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         st = torch.cuda.current_stream(dev).cuda_stream
-        _lib.check(L.mcq_logits_argmax(xk.data_ptr(), B, blob.data_ptr(), lscale_exp, N, K, D, st_.logits.data_ptr(),
+        _lib.check(L.mcq_logits_refine(xk.data_ptr(), B, blob.data_ptr(), lscale_exp, N, K, D, iters, st_.logits.data_ptr(),
                                        st_.idx.data_ptr(), ws.data_ptr(), ws.numel(), st, flags | (4 if x_fp16 else 0)),
-                   "mcq_logits_argmax")
-        if iters > 0:
-            _lib.check(L.mcq_refine_indexes(st_.xf.data_ptr(), B, blob.data_ptr(), N, K, D, iters, st_.idx.data_ptr(),
-                                            st_.idx.data_ptr(), ws.data_ptr(), ws.numel(), st), "mcq_refine_indexes")
+                   "mcq_logits_refine")
         _lib.check(L.mcq_recon_fwd(st_.xf.data_ptr(), st_.idx.data_ptr(), B, blob.data_ptr(), mean.data_ptr(), N, K, D,
                                    st_.err.data_ptr(), st_.parts[0].data_ptr(), st_.parts[1].data_ptr(), st), "mcq_recon_fwd")
         _lib.check(L.mcq_loss_fwd(st_.logits.data_ptr(), st_.idx.data_ptr(), B, N, K, st_.lse.data_ptr(),

@@ -80,7 +80,8 @@ k_limb_gemm(const int8_t *__restrict__ A, long RA, const int8_t *__restrict__ Bm
         const int8_t *p = (st + 4 < nst) ? pcur + (st + 4) * sstride : pnext + (st + 4 - nst) * sstride;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            if (load) issue1(p, st, g);
+            if (load && !(mode & 16)) issue1(p, st, g);
+            if (!(mode & 32))
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 an[t][g] = *reinterpret_cast<const v4i *>(base + (kh * 4 + g) * 2048 + (64 * wm + 32 * t + r32) * 16);
@@ -129,11 +130,11 @@ k_limb_gemm(const int8_t *__restrict__ A, long RA, const int8_t *__restrict__ Bm
         // before the reads of stage st + 1: it has landed everywhere and every wave has left slot st % NBUF.  Two later
         // stages stay in flight (stores of the previous tile's results only make the count conservative)
         auto sync = [&](int st) {
-            const int ahead = has_next ? 2 : (nst - 1 < st + 3 ? nst - 1 : st + 3) - (st + 1);
+            const int ahead = (mode & 16) ? 0 : has_next ? 2 : (nst - 1 < st + 3 ? nst - 1 : st + 3) - (st + 1);
             if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
             else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+            if (!(mode & 64)) __builtin_amdgcn_s_barrier();
         };
         for (int st = 0; st < nst; st += 2) {
             sync(st);
@@ -147,7 +148,7 @@ k_limb_gemm(const int8_t *__restrict__ A, long RA, const int8_t *__restrict__ Bm
             for (int tb = 0; tb < 2; ++tb)
 #pragma unroll
                 for (int v = 0; v < 16; ++v) {
-                    if (mode == 5 && v != 0) continue;
+                    if ((mode == 5 || (mode & 128)) && v != 0) continue;
                     const long row = m0 + 64 * wm + 32 * ta + 8 * (v >> 2) + 4 * kh + (v & 3);
                     const int col = n0 + 64 * wn + 32 * tb + r32;
                     float t = (float)acc[ta][tb][3][v];
