@@ -508,7 +508,7 @@ static int prepare_impl(const float *centers, float cscale_exp, const float *sca
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     const float *C = reinterpret_cast<const float *>(b + l.offC);
-    hipLaunchKernelGGL(k_centers_mean, dim3((unsigned)((Dp + 63) / 64)), dim3(256), 0, st, C, N, K, Dp,
+    hipLaunchKernelGGL(k_centers_mean, dim3((unsigned)(Dp / 16)), dim3(1024), 0, st, C, N, K, Dp,
                        reinterpret_cast<float *>(b + l.offMean));
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;

@@ -69,21 +69,21 @@ k_fix_rows(const float *__restrict__ src, int xh, long R, long Rp, int D, long l
             if (4 * q + c < D) v[c] = xh ? (float)srch[row * ld + 4 * q + c] : src[row * ld + 4 * q + c];
         return v;
     };
-    const bool cached = D <= 1024;
-    f32x4 cache[RPW][4];
+    const bool cached = (RW == 4) && D <= 1024;      // (16-row workgroups: measured slower with the rows held, 0.126 vs 0.083 ms)
+    f32x4 cache[RW == 4 ? RPW : 1][4];
 #pragma unroll
     for (int rr = 0; rr < RPW; ++rr) {
         const long row = row0 + RPW * wave + rr;
         float m = 0.f, pe = 0.f;
         if (cached) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) cache[rr][j] = load4(row, lane + 64 * j);
+            for (int j = 0; j < 4; ++j) cache[RW == 4 ? rr : 0][j] = load4(row, lane + 64 * j);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    m = fmaxf(m, fabsf(cache[rr][j][c]));
-                    pe = fmaf(cache[rr][j][c], cache[rr][j][c], pe);      // (groups past D are zeros: fmaf(0, 0, pe) == pe)
+                    m = fmaxf(m, fabsf(cache[RW == 4 ? rr : 0][j][c]));
+                    pe = fmaf(cache[RW == 4 ? rr : 0][j][c], cache[RW == 4 ? rr : 0][j][c], pe);      // (groups past D are zeros: fmaf(0, 0, pe) == pe)
                 }
         } else {
             for (int q = lane; q < (D + 3) / 4; q += 64) {
@@ -116,7 +116,7 @@ k_fix_rows(const float *__restrict__ src, int xh, long R, long Rp, int D, long l
             for (int j = 0; j < 2; ++j) {
                 const int q = lane + 64 * j;
                 if (q >= ncol / 4) continue;
-                const f32x4 v = cached ? cache[rr][(c0 >> 9) * 2 + j] : load4(row0 + rl, c0 / 4 + q);
+                const f32x4 v = cached ? cache[RW == 4 ? rr : 0][((c0 >> 9) * 2 + j) & 3] : load4(row0 + rl, c0 / 4 + q);
                 unsigned w[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {

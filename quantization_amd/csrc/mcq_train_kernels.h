@@ -257,25 +257,29 @@ __global__ void k_scales(const float *__restrict__ centers_scale, const float *_
     if (threadIdx.x == 1) out[1] = expf(*logits_scale * speed);
 }
 
-// mean[d] = sum_n (sum_k C[n][k][d]) / K   (get_data_mean, :67-75: centers.mean(dim=1).sum(dim=0)), k and n ascending.
-// Workgroup = 64 columns; wave w adds the codebooks w, w + 4, ...; wave 0 adds the per-codebook means.
-__global__ void __launch_bounds__(256)
+// mean[d] = sum_n (sum_k C[n][k][d]) / K   (get_data_mean, :67-75: centers.mean(dim=1).sum(dim=0)).
+// Workgroup = 16 columns x 16 waves; wave w takes the codebooks w, w + 16, ...; its lanes are 16 columns x 4 quarters of
+// the entries: a quarter is added k ascending, the quarters as (q0 + q1) + (q2 + q3); wave 0 adds the codebook means, n
+// ascending.
+__global__ void __launch_bounds__(1024)
 k_centers_mean(const float *__restrict__ C /*[N][K][Dp]*/, int N, int K, int Dp, float *__restrict__ mean /*[Dp]*/) {
-    __shared__ float part[64][64];      // [codebook][column]
+    __shared__ float part[64][16];      // [codebook][column]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int d = blockIdx.x * 64 + lane;
-    for (int n = wave; n < N; n += 4) {
+    const int c = lane & 15, kq = lane >> 4;
+    const int d = blockIdx.x * 16 + c;          // Dp is a multiple of 16
+    const int kn = K / 4;                       // K >= 16
+    for (int n = wave; n < N; n += 16) {
+        const float *p = C + ((size_t)n * K + (size_t)kq * kn) * Dp + d;
         float s = 0.f;
-        if (d < Dp) {
-            const float *c = C + (size_t)n * K * Dp + d;
-            for (int k = 0; k < K; ++k) s = s + c[(size_t)k * Dp];
-        }
-        part[n][lane] = s / (float)K;
+        for (int k = 0; k < kn; ++k) s = s + p[(size_t)k * Dp];
+        s = s + __shfl_xor(s, 16, 64);
+        s = s + __shfl_xor(s, 32, 64);
+        if (kq == 0) part[n][c] = s / (float)K;
     }
     __syncthreads();
-    if (wave == 0 && d < Dp) {
-        float t = part[0][lane];
-        for (int n = 1; n < N; ++n) t = t + part[n][lane];
+    if (threadIdx.x < 16) {
+        float t = part[0][c];
+        for (int n = 1; n < N; ++n) t = t + part[n][c];
         mean[d] = t;
     }
 }
