@@ -194,9 +194,16 @@ int launch_fix_rows(const float *src, int xh, long R, int D, long ld, int8_t *pl
 // the fixed-point GEMM: persistent workgroups, one per CU
 template <int MODE>
 int launch_fgemm(FixGemm g, hipStream_t st) {
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fgemm<MODE>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, kFixLds);
-    if (attr != hipSuccess) return (int)attr;
+    // the kernel's 132 KB of dynamic LDS has to be allowed once per device (a process may drive several)
+    static bool allowed[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 63;
+    if (!allowed[dev] || dev == 63) {
+        const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fgemm<MODE>),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, kFixLds);
+        if (attr != hipSuccess) return (int)attr;
+        allowed[dev] = true;
+    }
     const long MT = g.RA / kFixTile, NT = g.RB / kFixTile;
     const int H = (MODE == FG_LOGITS && g.K > kFixTile) ? g.K / kFixTile : 1;
     const long big = g.walk_rows ? NT : MT, small_units = (g.walk_rows ? MT : NT) / H;

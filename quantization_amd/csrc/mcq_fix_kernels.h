@@ -209,6 +209,8 @@ k_fgemm(const FixGemm g) {
     const unsigned dbase = (unsigned)(size_t)smem + op * kFixOperand + (4 * (wu & 1)) * 2048;
     const unsigned voff = lane * 16;
     auto base_of = [&](long m0, long n0) { return (op ? g.B + n0 * 16 : g.A + m0 * 16) + (long)(4 * (wu & 1)) * R * 16; };
+    // (m0 is written without being declared clobbered -- the compiler rejects it as a reserved register; nothing else in
+    // this kernel uses m0: LDS instructions need no m0 on gfx9+, and the kernel has no LDS-DMA builtin, movrel or GWS)
     auto issue1 = [&](const int8_t *p, int st, int g4) {
         const int8_t *pg = p + g4 * pl;
         const unsigned d = dbase + (st % kFixRing) * kFixSlot + g4 * 2048;
