@@ -601,6 +601,29 @@ int mcq_decode(const void *codes, int code_bytes, int codes_per_row, long B, con
     // (N >= 8: with fewer rows per vector the L2 gathers of the sliced kernel measured faster; 36.9 vs 52.2 us at 8 x 256, 65,536 vectors)
     const char *lds_env = getenv("MCQ_DECODE_LDS_MIN");   // test / tuning hook, read per call
     const long lds_min_b = lds_env ? atol(lds_env) : 16384;
+    // pipelined LDS-resident kernel for packed byte codes, 8 or 16 per vector; 16 x 256 (slice too large for the LDS) as 8 + 8
+    {
+        const bool fits = (size_t)N * K * 64 <= 144 * 1024;
+        if (sliced_ok && rep == 1 && code_bytes == 1 && B >= lds_min_b && K >= 32 && (D & 3) == 0 &&
+            ((reinterpret_cast<uintptr_t>(codes) & 15) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0) &&
+            ((N == 8 && fits) || (N == 16 && (fits || (K == 256 && B >= 32768))))) {      // (8 + 8 below 32,768 vectors: sliced wins, 54 vs 57 us)
+            const int ns = Dp / 16, per_xcd = (ns + 7) / 8;
+            int groups = 256 / (8 * per_xcd);            // one workgroup per CU
+            groups = groups < 1 ? 1 : groups;
+            const unsigned g = (unsigned)(8 * per_xcd * groups);
+            const int nl = fits ? N : 8;
+            const size_t lds = (size_t)nl * K * 64;
+            const uint8_t *cp = static_cast<const uint8_t *>(codes);
+            const bool two = B > 200000;                 // vectors per lane and trip: 1, or 2 for large batches (measured)
+#define MCQ_DECP(NLL, NGG, UU) hipLaunchKernelGGL((k_decode_hyb<NLL, NGG, UU>), dim3(g), dim3(1024), lds, st, cp, B, P.C, N, K, D, Dp, groups, out)
+            if (N == 8) { if (two) MCQ_DECP(8, 0, 2); else MCQ_DECP(8, 0, 1); }
+            else if (fits) { if (two) MCQ_DECP(16, 0, 2); else MCQ_DECP(16, 0, 1); }
+            else MCQ_DECP(8, 8, 1);
+#undef MCQ_DECP
+            hipError_t e5 = hipGetLastError();
+            return e5 == hipSuccess ? 0 : (int)e5;
+        }
+    }
     if (sliced_ok && rep == 1 && B >= lds_min_b && (size_t)N * K * 64 <= 144 * 1024 && K >= 32 && N >= 8) {
         const int ns = Dp / 16, per_xcd = (ns + 7) / 8;
         int groups = 256 / (8 * per_xcd);            // one workgroup per CU

@@ -570,6 +570,87 @@ k_decode_lds(const CodeT *__restrict__ codes, long B, const float *__restrict__ 
     }
 }
 
+// Pipelined LDS-resident decode for packed byte codes (N = 8 or 16), optionally hybrid: the slice of the first NL
+// codebooks' rows sits in LDS (as in k_decode_lds), the rows of the other NGT come from the XCD's L2 as 64-byte pieces --
+// for 16 x 256 codebooks, whose slice (256 KB) does not fit the LDS: 8 + 8 (194 vs 219 us for the sliced kernel at dim 1024,
+// 65,536 vectors).  Sums in the same order (n ascending: the LDS rows first, the gathered ones after them).  Three trips are
+// in flight per lane: the codes of the vectors two trips ahead, the gathered rows of the next trip, the sums of this one.
+// With NGT = 0 and one vector per lane and trip (UNR = 1) this is the fastest decode of 8 x 256 at 65,536 vectors: 30.7-31.9 us
+// against 36.9-40 us for k_decode_lds (whose codes are requested one trip ahead, four vectors at a time) -- the time of a
+// plain fill of the same 134 MB (29 us); larger batches prefer UNR = 2 (681 vs 729 us at 1,048,576 vectors) and settle at
+// 3.0-3.2 TB/s, bound by the LDS bank conflicts of random 64-byte rows and the 64-byte output pieces.
+template <int NL, int NGT, int UNR>
+__global__ void __launch_bounds__(1024)
+k_decode_hyb(const uint8_t *__restrict__ codes, long B, const float *__restrict__ C, int N, int K, int D, int Dp,
+             int groups /* workgroups per slice */, float *__restrict__ out) {
+    constexpr int W = 16, LPV = W / 4;
+    constexpr int NGMAX = NGT > 0 ? NGT : 1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4 *rows = reinterpret_cast<f32x4 *>(smem);            // [NL*K][LPV]
+    const int ns = Dp / W;
+    const int xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
+    const int per_xcd = (ns + 7) / 8;
+    const int slice = xcd * per_xcd + within % per_xcd;
+    const int grp = within / per_xcd;
+    if (slice >= ns) return;
+    const int tid = threadIdx.x;
+    for (int u = tid; u < NL * K * LPV; u += blockDim.x)
+        rows[u] = *reinterpret_cast<const f32x4 *>(C + (long)(u / LPV) * Dp + slice * W + 4 * (u % LPV));
+    __syncthreads();
+    const long per = (B + groups - 1) / groups;
+    const long b_lo = grp * per, b_hi = (b_lo + per < B) ? b_lo + per : B;
+    if (b_lo >= b_hi) return;
+    const int q = tid % LPV;
+    const int off = slice * W + 4 * q;
+    const long stride = blockDim.x / LPV;
+    const int NG = N - NL;
+    const float *Cg = C + off;
+    auto fetch = [&](long b, unsigned long long (&w)[2]) {
+        const long bc = b < b_hi ? b : b_hi - 1;
+        const unsigned long long *p = reinterpret_cast<const unsigned long long *>(codes + bc * N);
+        w[0] = p[0];
+        w[1] = (N == 16) ? p[1] : 0ull;
+    };
+    auto code_of = [&](const unsigned long long (&w)[2], int n) { return (int)((w[n >> 3] >> (8 * (n & 7))) & 0xffull) & (K - 1); };
+    static_assert(NL + NGT == 8 || NL + NGT == 16, "packed codes: 8 or 16 per vector");
+    auto gather = [&](const unsigned long long (&w)[2], f32x4 (&g)[NGMAX]) {
+#pragma unroll
+        for (int j = 0; j < NGMAX; ++j)
+            if (j < NG) g[j] = *reinterpret_cast<const f32x4 *>(Cg + ((long)(NL + j) * K + code_of(w, NL + j)) * Dp);
+    };
+    unsigned long long c0[UNR][2], c1[UNR][2], c2[UNR][2];      // codes of this trip, the next, the one after
+    f32x4 g0[UNR][NGMAX], g1[UNR][NGMAX];                        // gathered rows of this trip, the next
+    long b = b_lo + tid / LPV;
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) { fetch(b + u * stride, c0[u]); fetch(b + (UNR + u) * stride, c1[u]); }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) gather(c0[u], g0[u]);
+    for (; b < b_hi; b += UNR * stride) {
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) fetch(b + (2 * UNR + u) * stride, c2[u]);
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) gather(c1[u], g1[u]);
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            f32x4 t = rows[code_of(c0[u], 0) * LPV + q];
+#pragma unroll
+            for (int n = 1; n < NL; ++n) t = t + rows[(n * K + code_of(c0[u], n)) * LPV + q];
+#pragma unroll
+            for (int j = 0; j < NGMAX; ++j)
+                if (j < NG) t = t + g0[u][j];
+            const long bb = b + u * stride;
+            if (bb < b_hi) __builtin_nontemporal_store(t, reinterpret_cast<f32x4 *>(out + bb * D + off));      // (plain stores: no better)
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            c0[u][0] = c1[u][0]; c0[u][1] = c1[u][1];
+            c1[u][0] = c2[u][0]; c1[u][1] = c2[u][1];
+#pragma unroll
+            for (int j = 0; j < NGMAX; ++j) g0[u][j] = g1[u][j];
+        }
+    }
+}
+
 // Fast path for unpacked uint8 codes and the common small shapes: all NN x J row pieces of a
 // vector are requested before the first add (16 gathers in flight per lane at dim 512 / 8 codebooks).
 template <int NN, int J>
