@@ -639,7 +639,7 @@ k_decode_hyb(const uint8_t *__restrict__ codes, long B, const float *__restrict_
             for (int j = 0; j < NGMAX; ++j)
                 if (j < NG) t = t + g0[u][j];
             const long bb = b + u * stride;
-            if (bb < b_hi) __builtin_nontemporal_store(t, reinterpret_cast<f32x4 *>(out + bb * D + off));      // (plain stores: no better)
+            if (bb < b_hi && off < D) __builtin_nontemporal_store(t, reinterpret_cast<f32x4 *>(out + bb * D + off));      // (D % 4 == 0; the last slice may reach into the padding.  Plain stores: no better)
         }
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {

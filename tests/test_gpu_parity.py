@@ -404,7 +404,8 @@ def test_fp16_frames_are_widened_in_the_load_path(name):
     assert torch.equal(q.encode_from_host(xh, 5, as_bytes=False, chunk=300).cuda(), got)
 
 
-@pytest.mark.parametrize("D,K,N", [(40, 64, 8), (30, 32, 4), (100, 256, 2), (512, 256, 8), (1024, 256, 16), (260, 64, 32), (64, 16, 8)])
+@pytest.mark.parametrize("D,K,N", [(40, 64, 8), (30, 32, 4), (100, 256, 2), (512, 256, 8), (1024, 256, 16), (260, 64, 32), (64, 16, 8),
+                                   (1000, 64, 8), (100, 128, 16), (36, 256, 8), (72, 256, 16)])
 def test_decode_of_big_batches_takes_the_xcd_sliced_kernel_and_stays_bit_exact(D, K, N):
     """B >= 4096 unpacked codes go through k_decode_sliced (feature axis cut in eight, one slice per XCD):
     same sums in the same order as the oracle, for ragged dims, uint8 and int64 codes, ragged batch sizes"""
@@ -419,7 +420,9 @@ def test_decode_of_big_batches_takes_the_xcd_sliced_kernel_and_stays_bit_exact(D
     got64 = q.decode(torch.from_numpy(codes).cuda())
     assert np.array_equal(got8.cpu().numpy().view(np.uint32), want.view(np.uint32))
     assert torch.equal(got8, got64)
-    # the LDS-resident kernel of very large batches (threshold lowered through its test hook)
+    # the LDS-resident kernels of large batches (threshold lowered through its test hook): the pipelined one for packed byte
+    # codes of 8 / 16 codebooks (8 + 8 hybrid for 16 x 256), k_decode_lds for the rest; dims whose last 16-float slice reaches
+    # into the padding must not write past a row
     os.environ["MCQ_DECODE_LDS_MIN"] = "4096"
     try:
         lds8 = q.decode(torch.from_numpy(codes.astype(np.uint8)).cuda())
@@ -427,6 +430,19 @@ def test_decode_of_big_batches_takes_the_xcd_sliced_kernel_and_stays_bit_exact(D
     finally:
         del os.environ["MCQ_DECODE_LDS_MIN"]
     assert torch.equal(lds8, got8) and torch.equal(lds64, got8)
+
+
+@pytest.mark.parametrize("D", [72, 256])
+def test_decode_hybrid_kernel_for_sixteen_big_codebooks(D):
+    """16 x 256 codebooks: the 64-byte slices of all rows (256 KB) do not fit the LDS; from 32,768 vectors mcq_decode keeps the
+    first eight codebooks' slices there and gathers the other eight rows from L2 -- same sums, n ascending"""
+    state = gen.synthetic_state(33, D, 256, 16)
+    q = load_quantizer(state, D, 256, 16)
+    oq = OracleQuantizer.from_state_dict(state)
+    B = 33001
+    codes = np.random.default_rng(6).integers(0, 256, size=(B, 16), dtype=np.uint8)
+    got = q.decode(torch.from_numpy(codes).cuda()).cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), oq.decode(codes).view(np.uint32))
 
 
 def test_derived_state_follows_fused_optimizer_steps():
