@@ -67,6 +67,7 @@ struct Workspace {
     uint8_t *idx, *idxB, *idxC, *final_idx;   // B, C, final: fixed-point skipping only
     int *map[2], *cnt;
     float *E, *R, *xx, *XC;                   // per vector: |x_err|^2, |x_err - old_n|^2, |x|^2, x.C products
+    float *gterms;                            // per vector: the N*N Gram entries G[o_m][o_m2] of the current indexes
     int8_t *xf;                               // limb planes of the frames of a chunk
     int *xe;                                  // and their row exponents
     float *tabs[2];                           // group tables of two consecutive levels (ping-pong)
@@ -92,9 +93,9 @@ size_t tf_tab_floats(int N, int K) {
 
 size_t workspace_per_vector(int N, int K, int D) {
     // idx x4, maps, E, xx, R, XC, lists (entries / positions / scores: <= 16 + 2*16 + 4*16 bytes per codebook and level), tabs x2,
-    // the frame as limb planes + its exponent
+    // the frame as limb planes + its exponent, the N*N Gram terms of E / R
     return 4 * (size_t)N + 8 + 8 + 4 * (size_t)N + 4 * (size_t)N * K + (size_t)tf_levels(N) * N * (16 + 2 * 16 + 4 * 16) + 64 +
-           2 * 4 * tf_tab_floats(N, K) + 4 * (size_t)fix_round_cols(D) + 4;
+           2 * 4 * tf_tab_floats(N, K) + 4 * (size_t)fix_round_cols(D) + 4 + 4 * (size_t)N * N;
 }
 // alignment of the carved arrays + the rows the limb planes are padded by (to a multiple of 128)
 size_t workspace_slack(int D) { return 48 * 256 + (size_t)kFixTile * (4 * (size_t)fix_round_cols(D) + 4); }
@@ -122,6 +123,7 @@ Workspace carve(void *ws, long Bc, int N, int K, int D) {
     w.E = reinterpret_cast<float *>(take((size_t)Bc * 4));
     w.R = reinterpret_cast<float *>(take((size_t)Bc * N * 4));
     w.xx = reinterpret_cast<float *>(take((size_t)Bc * 4));
+    w.gterms = reinterpret_cast<float *>(take((size_t)Bc * N * N * 4));
     w.XC = reinterpret_cast<float *>(take((size_t)Bc * N * K * 4));
     w.xf = reinterpret_cast<int8_t *>(take(fix_plane_bytes(Bc, D)));
     w.xe = reinterpret_cast<int *>(take((size_t)fix_round_rows(Bc) * 4));
@@ -275,9 +277,15 @@ int launch_tf_stage0(int K, int N, const float *G, const float *XC, const uint8_
 }
 
 int launch_tf_er(int N, const float *G, const float *XC, const uint8_t *idx, const float *xx, long B, int K, float *E, float *R,
-                 const int *nact, const int *map, hipStream_t st) {
+                 float *gterms, const int *nact, const int *map, hipStream_t st) {
     const dim3 grid((unsigned)((B + 3) / 4)), block(256);
-#define MCQ_ER_CASE(NN) case NN: hipLaunchKernelGGL((k_tf_er<NN>), grid, block, 0, st, G, XC, idx, xx, B, K, E, R, nact, map); break;
+#define MCQ_ER_CASE(NN)                                                                                                  \
+    case NN:                                                                                                             \
+        hipLaunchKernelGGL((k_tf_gram_terms<NN>), dim3((unsigned)(((B + 4 * (64 / NN) - 1) / (4 * (64 / NN))) * NN)), block, 0, st, G, idx, \
+                           B, K, gterms, nact);                                                                          \
+        MCQ_LAUNCH_CHECK();                                                                                              \
+        hipLaunchKernelGGL((k_tf_er<NN>), grid, block, 0, st, gterms, XC, idx, xx, B, K, E, R, nact, map);                 \
+        break;
     switch (N) {
         MCQ_ER_CASE(1) MCQ_ER_CASE(2) MCQ_ER_CASE(4) MCQ_ER_CASE(8) MCQ_ER_CASE(16) MCQ_ER_CASE(32) MCQ_ER_CASE(64)
         default: return MCQ_EUNSUPPORTED;
@@ -433,7 +441,7 @@ int run_encode(const float *x, long B, const void *prepared, float lscale, int N
         }
         for (int it = 0; it < iters; ++it) {
             if (prof) prof->begin();
-            rc = launch_tf_er(N, P.G, w.XC, idx_cur, w.xx, Bc, K, w.E, w.R, nact, map_cur, st);
+            rc = launch_tf_er(N, P.G, w.XC, idx_cur, w.xx, Bc, K, w.E, w.R, w.gterms, nact, map_cur, st);
             if (rc) return rc;
             if (prof) { prof->end(CAT_ER); prof->begin(); }
             rc = launch_tf_stage0(K, N, P.G, w.XC, idx_cur, w.R, P.Q, Bc, (N == 1) ? 1 : w.tf.kc[0], w.tf.ent, w.tf.S[0],

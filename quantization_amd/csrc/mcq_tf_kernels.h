@@ -63,12 +63,31 @@ k_tf_xx(const float *__restrict__ x, long B, int D, int Dp, float *__restrict__ 
 }
 
 // --------------------------------------------------------------------- E, R
-// One wave per vector: E = |x_err|^2 and R[n] = |x_err - old_n|^2 (:401-409) from N*N Gram entries, N entries of XC
-// and |x|^2 (oracle "TABLE FORM", E, R).  Its reads go all over G, which is why it is not part of k_tf_stage0 (whose
-// XCD-local L2 footprint they would break: tried, stage 0 went from 0.31 to 0.62 ms); 260 bytes per vector here.
+// The N*N Gram entries G[o_m][o_m2] of a vector lie all over the matrix: gathered by one wave per vector they miss the
+// 4 MB L2s (16 MB matrix at 8 x 256: 203 MB fetched from the fabric per launch for 21 MB of useful reads, 0.061 ms).
+// k_tf_gram_terms gathers them XCD by XCD instead: workgroup id mod N = m, a wave takes 64 / N vectors x the N entries of
+// row block m, so an XCD only ever touches the rows of its own codebooks (2 MB); the terms go to gterms[b][m][m2] and
+// k_tf_er reads its 64 terms as one coalesced line.
 template <int N>
 __global__ void __launch_bounds__(256)
-k_tf_er(const float *__restrict__ G, const float *__restrict__ XC, const uint8_t *__restrict__ idx,
+k_tf_gram_terms(const float *__restrict__ G, const uint8_t *__restrict__ idx, long B, int K, float *__restrict__ gterms,
+                const int *__restrict__ nact) {
+    constexpr int VW = 64 / N;                     // vectors per wave
+    if (nact) B = *nact;
+    const int m = (int)(blockIdx.x % N);
+    const long b = ((long)(blockIdx.x / N) * 4 + (threadIdx.x >> 6)) * VW + lane_id() / N;
+    const int m2 = lane_id() % N;
+    if (b >= B) return;
+    const uint8_t *id = idx + b * N;
+    const int NK = N * K;
+    gterms[(b * N + m) * N + m2] = G[(size_t)(m * K + id[m]) * NK + m2 * K + id[m2]];
+}
+
+// One wave per vector: E = |x_err|^2 and R[n] = |x_err - old_n|^2 (:401-409) from the N*N Gram terms, N entries of XC
+// and |x|^2 (oracle "TABLE FORM", E, R).
+template <int N>
+__global__ void __launch_bounds__(256)
+k_tf_er(const float *__restrict__ gterms, const float *__restrict__ XC, const uint8_t *__restrict__ idx,
         const float *__restrict__ xx, long B, int K, float *__restrict__ E_out, float *__restrict__ R_out,
         const int *__restrict__ nact, const int *__restrict__ map) {
     constexpr int NT = (N * N + 63) / 64;          // Gram terms per lane
@@ -85,7 +104,7 @@ k_tf_er(const float *__restrict__ G, const float *__restrict__ XC, const uint8_t
     for (int j = 0; j < NT; ++j) {
         const int t = lane + 64 * j;
         const int tc = t < N * N ? t : 0;
-        const float g = G[(size_t)((tc / N) * K + id[tc / N]) * NK + (tc % N) * K + id[tc % N]];
+        const float g = gterms[b * (N * N) + tc];
         gt[j] = t < N * N ? g : 0.f;
     }
     const int lm = lane < N ? lane : 0;
