@@ -32,35 +32,7 @@ __device__ __forceinline__ float shfl_f(float v, int src) {
     return __int_as_float(__builtin_amdgcn_ds_bpermute(src << 2, __float_as_int(v)));
 }
 
-// ------------------------------------------------------------------- |x|^2
-// xx[b] = sumsq64(x[b]) (zero padded), once per encode call: the constant of E in table form.  One wave per vector.
-__global__ void __launch_bounds__(256)
-k_tf_xx(const float *__restrict__ x, long B, int D, int Dp, float *__restrict__ xx, int xh /* x is fp16 */) {
-    const long b = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= B) return;
-    const int lane = lane_id();
-    const float *xb = x + b * D;
-    const _Float16 *xbh = reinterpret_cast<const _Float16 *>(x) + b * D;
-    const bool vec_ok = ((D & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & (xh ? 7 : 15)) == 0);
-    float pe = 0.f;
-    for (int q = lane; q < Dp / 4; q += 64) {
-        f32x4 xv;
-        if (vec_ok && 4 * q + 3 < D) {
-            xv = xh ? load_h4(xbh + 4 * q) : *reinterpret_cast<const f32x4 *>(xb + 4 * q);
-        } else {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int kc = (4 * q + c < D) ? 4 * q + c : 0;
-                const float val = xh ? (float)xbh[kc] : xb[kc];
-                xv[c] = (4 * q + c < D) ? val : 0.f;
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) pe = fmaf(xv[c], xv[c], pe);
-    }
-    pe = wave_sum_butterfly(pe);
-    if (lane == 0) xx[b] = pe;
-}
+// (|x|^2, the constant of E, is formed by k_fix_rows while it turns the frames into limb planes)
 
 // --------------------------------------------------------------------- E, R
 // The N*N Gram entries G[o_m][o_m2] of a vector lie all over the matrix: gathered by one wave per vector they miss the

@@ -486,3 +486,34 @@ def test_encode_does_not_depend_on_the_callers_autograd_mode():
         got_idx = q._compute_indexes(x, 3)
     assert torch.equal(got, want) and torch.equal(got_idx.to(torch.uint8), want)
     fixtures.check_codes(fx, 5, q.encode(torch.from_numpy(fx["x"]).cuda(), 5).cpu().numpy(), "enable_grad encode")
+
+
+def test_logits_refine_is_logits_argmax_then_refine_indexes():
+    """mcq_logits_refine (one call: the frames become limb planes once, the indexes stay bytes) gives the logits of
+    mcq_logits_argmax and the indexes mcq_refine_indexes returns from that arg max"""
+    from quantization_amd import _lib
+    fx = fixtures.load("trained_d64_b8_p2")
+    q = load_quantizer(fx["state"], fx["D"], fx["K"], fx["N"])
+    N, K, D = fx["N"], fx["K"], fx["D"]
+    L = _lib.lib()
+    x = torch.from_numpy(fx["x"][:777]).cuda()
+    B = x.shape[0]
+    with torch.no_grad():
+        blob = q._prepared()
+    ws = q._workspace(B, x.device)
+    st = torch.cuda.current_stream().cuda_stream
+    lg1 = torch.empty((B, N * K), device="cuda")
+    lg2 = torch.empty_like(lg1)
+    a1 = torch.empty((B, N), dtype=torch.int64, device="cuda")
+    i1 = torch.empty_like(a1)
+    i2 = torch.empty_like(a1)
+    for iters in (0, 1, 3):
+        assert L.mcq_logits_argmax(x.data_ptr(), B, blob.data_ptr(), q._lscale_exp, N, K, D, lg1.data_ptr(), a1.data_ptr(),
+                                   ws.data_ptr(), ws.numel(), st, 0) == 0
+        assert L.mcq_refine_indexes(x.data_ptr(), B, blob.data_ptr(), N, K, D, iters, a1.data_ptr(), i1.data_ptr(),
+                                    ws.data_ptr(), ws.numel(), st) == 0
+        assert L.mcq_logits_refine(x.data_ptr(), B, blob.data_ptr(), q._lscale_exp, N, K, D, iters, lg2.data_ptr(),
+                                   i2.data_ptr(), ws.data_ptr(), ws.numel(), st, 0) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(lg1, lg2) and torch.equal(i1, i2), iters
+        assert torch.equal(i2, q._compute_indexes(x, iters))
