@@ -249,6 +249,11 @@ size_t mcq_logits_workspace_bytes(long B, int N, int D);   /* also what mcq_logi
 int mcq_logits(const float *x, long B, const void *prepared, float lscale_exp, int N, int K, int D,
                float *out, void *workspace, size_t workspace_bytes, void *stream);
 
+/* The wave-level selection of the search on its own: `cases` independent problems of 64 * per_lane scores each
+ * (per_lane 1, 4 or 16; position = index); out_v / out_p [cases][64] receive the cnt smallest in (value, position) order.
+ * Test hook for the selection's paths (ties, clustered survivors).                                                       */
+int mcq_test_select(const float *scores, int cases, int per_lane, int cnt, float *out_v, int *out_p, void *stream);
+
 /* Name and launch count of the kernels enqueued by the last mcq_encode on this
  * thread (for bench.py's per-kernel HIP-event timing); returns the count.      */
 int mcq_last_encode_launches(void);

@@ -359,8 +359,8 @@ int run_tf_combines(const float *G, const uint8_t *idx_cur, uint8_t *idx_new, co
         MCQ_LAUNCH_CHECK();
         if (N == 16 && v == 3) {       // two groups of eight: levels 2 and 3 in one kernel, tables in LDS
             if (prof) { prof->end(CAT_TABLES + 2); prof->begin(); }
-            if (small) hipLaunchKernelGGL((k_tf_comb3<8, 16, 16>), dim3((unsigned)B), dim3(64), 0, st, idx_cur, w.E, L, B, N, w.tabs[0], idx_new, nact);
-            else hipLaunchKernelGGL((k_tf_comb3<16, 32, 32>), dim3((unsigned)B), dim3(64), 0, st, idx_cur, w.E, L, B, N, w.tabs[0], idx_new, nact);
+            if (small) hipLaunchKernelGGL((k_tf_comb3<8, 16, 16>), dim3((unsigned)B), dim3(256), 0, st, idx_cur, w.E, L, B, N, w.tabs[0], idx_new, nact);
+            else hipLaunchKernelGGL((k_tf_comb3<16, 32, 32>), dim3((unsigned)B), dim3(256), 0, st, idx_cur, w.E, L, B, N, w.tabs[0], idx_new, nact);
             MCQ_LAUNCH_CHECK();
             if (prof) prof->end(CAT_COMBINE + 2);
             continue;
@@ -1022,6 +1022,19 @@ int mcq_grad_tail(const float *part_c, long n_c, const float *sa, const float *s
 }
 
 int mcq_last_encode_launches(void) { return g_last_launches; }
+
+int mcq_test_select(const float *scores, int cases, int per_lane, int cnt, float *out_v, int *out_p, void *stream) {
+    if (!scores || !out_v || !out_p || cases <= 0 || cnt < 1 || cnt > 64) return MCQ_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (per_lane) {
+        case 1: hipLaunchKernelGGL((k_test_select<1>), dim3(cases), dim3(64), 0, st, scores, cnt, out_v, out_p); break;
+        case 4: hipLaunchKernelGGL((k_test_select<4>), dim3(cases), dim3(64), 0, st, scores, cnt, out_v, out_p); break;
+        case 16: hipLaunchKernelGGL((k_test_select<16>), dim3(cases), dim3(64), 0, st, scores, cnt, out_v, out_p); break;
+        default: return MCQ_EINVAL;
+    }
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
 
 int mcq_profile_encode(const float *x, long B, const void *prepared, float lscale_exp, int N, int K, int D,
                        int refine_iters, void *workspace, size_t workspace_bytes, void *stream, float *ms_out,

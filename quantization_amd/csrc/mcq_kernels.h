@@ -204,10 +204,12 @@ __device__ __forceinline__ void wave_select_fast(const float (&v)[VPL], const in
         wave_lds_fence();
         return;
     }
-    if (VPL > 1 && cnt * VPL <= 128 && cnt <= 64) {
+    if (VPL > 1 && cnt <= 64) {
         // Two-level variant with up to two survivors per lane (32 of 256 with four keys per lane): T0 as above bounds
-        // the answer, at most cnt lanes hold keys <= T0, so at most cnt * VPL <= 128 keys survive; lane l ranks the
-        // survivors l and l + 64 against all of them.
+        // the answer, at most cnt lanes hold keys <= T0, so at most cnt * VPL keys survive; lane l ranks the survivors
+        // l and l + 64 against all of them.  With more keys per lane (32 of 1,024: sixteen) cnt * VPL exceeds the 128
+        // slots, but the survivors rarely do (about 46 on the bench workload): they are counted first, and only a
+        // count above 128 falls through to the general quickselect below (sixteen ballots per round).
         u64 lmin = key[0];
 #pragma unroll
         for (int i = 1; i < VPL; ++i) lmin = key[i] < lmin ? key[i] : lmin;
@@ -221,6 +223,10 @@ __device__ __forceinline__ void wave_select_fast(const float (&v)[VPL], const in
             if (rr == target) { T0 = kp; break; }
             cm &= (rr > target) ? ltm : ~(ltm | (1ull << pl));
         }
+        int nsurv = 0;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) nsurv += __popcll(__ballot(key[i] <= T0));
+        if (nsurv <= 128) {
         u64 *ldsS = lds, *ldsO = lds + 144;        // survivors [0, 136), results [144, 208)
         int base = 0;
 #pragma unroll
@@ -258,6 +264,7 @@ __device__ __forceinline__ void wave_select_fast(const float (&v)[VPL], const in
         }
         wave_lds_fence();
         return;
+        }
     }
     // quickselect: find the key T with exactly cnt - 1 keys below it.  Candidate sets as wave-uniform masks, one
     // per key slot (see the two-level variant above); the pivot is the first candidate of the lowest slot that has one.
@@ -318,6 +325,30 @@ __device__ __forceinline__ void wave_select_fast(const float (&v)[VPL], const in
         out_v = unord32((uint32_t)(o >> 32));
     }
     wave_lds_fence();
+}
+
+// Test hook: one wave selects the `cnt` smallest of M = 64 * VPL scores (position = index) with wave_select_fast; lane j
+// writes the j-th.  Lets the tests drive every path of the selection with adversarial inputs (ties, all survivors in a few
+// lanes, more survivors than the two-per-lane path holds).
+template <int VPL>
+__global__ void __launch_bounds__(64)
+k_test_select(const float *__restrict__ scores, int cnt, float *__restrict__ out_v, int *__restrict__ out_p) {
+    __shared__ u64 scratch[kSelectLdsU64];
+    const float *sc = scores + (size_t)blockIdx.x * 64 * VPL;
+    float v[VPL];
+    int p[VPL];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        p[i] = VPL * lane_id() + i;
+        v[i] = sc[p[i]];
+    }
+    float ov;
+    int op;
+    wave_select_fast<VPL>(v, p, cnt, 64 * VPL, scratch, ov, op);
+    if (lane_id() < cnt) {
+        out_v[(size_t)blockIdx.x * 64 + lane_id()] = ov;
+        out_p[(size_t)blockIdx.x * 64 + lane_id()] = op;
+    }
 }
 
 // ------------------------------------------------------------------- prepare

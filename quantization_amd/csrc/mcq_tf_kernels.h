@@ -598,54 +598,66 @@ k_tf_comb(const float *__restrict__ E, TfLists L, long B, int N, int v, int keep
 
 // ------------------------------------------------------- combine of level 3
 // N = 16: the two groups of eight codebooks.  16 level-1 tables (tabs, quads layout) -> the four level-2 tables of
-// (groups 0 | 1) x (2 | 3) in LDS -> the KC3 x KC3 scores.  One wave per vector; always the last combine.
+// (groups 0 | 1) x (2 | 3) in LDS -> the KC3 x KC3 scores -> their arg min; always the last combine.  One workgroup of FOUR
+// waves per vector: the tables take 33 KB of LDS (16 + 16 KB at K >= 32), which leaves room for four workgroups per CU --
+// with a single wave each (the first version) a CU held four waves and the kernel took 1.0 ms at 65,536 vectors.  Wave w
+// loads four of the level-1 tables, builds level-2 table w and scores a quarter of the candidate pairs.
 template <int KC1, int KC2, int KC3>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(256)
 k_tf_comb3(const uint8_t *__restrict__ idx, const float *__restrict__ E, TfLists L, long B, int N,
            const float *__restrict__ tabs, uint8_t *__restrict__ idx_final, const int *__restrict__ nact) {
-    constexpr int VPL2 = KC2 * KC2 / 64, VPL = KC3 * KC3 / 64, M1 = KC1 * KC1, M2 = KC2 * KC2;
-    __shared__ u64 scratch[kSelectLdsU64];
+    constexpr int VPL2 = KC2 * KC2 / 64, M1 = KC1 * KC1, M2 = KC2 * KC2;
+    constexpr int PW = KC3 * KC3 / 4, VPLW = PW / 64;          // candidate pairs per wave, per lane
     __shared__ __attribute__((aligned(16))) float t1[16 * M1];
     __shared__ __attribute__((aligned(16))) float t2[4 * M2];
+    __shared__ float wv[4];
+    __shared__ int wp[4];
+    (void)idx;
     if (nact) B = *nact;
     const long b = blockIdx.x;
     if (b >= B) return;
-    const int lane = lane_id();
-    tf_load_tables<M1>(tabs + (size_t)b * 16 * M1, t1, 16);
-    const int i = (VPL * lane) / KC3, j0 = (VPL * lane) % KC3;
+    const int lane = lane_id(), w = threadIdx.x >> 6;
+    tf_load_tables<M1>(tabs + ((size_t)b * 16 + 4 * w) * M1, t1 + 4 * w * M1, 4);
     const float Eb = E[b];
-    const float se = L.S[3][(b * 2 + 0) * KC3 + i];
-    float so[VPL];
-#pragma unroll
-    for (int v = 0; v < VPL; ++v) so[v] = L.S[3][(b * 2 + 1) * KC3 + j0 + v];
-    wave_lds_fence();
+    __syncthreads();
     const int G2 = N >> 2;   // 4 level-2 groups
+    {
+        // level-2 groups xc and 2 + yc; their halves are the level-1 groups 2xc, 2xc+1 and 4+2yc, 4+2yc+1
+        const int xc = w >> 1, yc = w & 1;
+        const int X0 = 2 * xc, Y0 = 2 * yc;      // Y0 relative to 4
+        float tv[VPL2];
+        tf_up<KC1, KC2>(t1 + (4 * X0 + Y0) * M1, t1 + (4 * X0 + Y0 + 1) * M1, t1 + (4 * (X0 + 1) + Y0) * M1,
+                        t1 + (4 * (X0 + 1) + Y0 + 1) * M1, L.pos[2] + ((b * G2 + xc) * KC2) * 2,
+                        L.pos[2] + ((b * G2 + 2 + yc) * KC2) * 2, tv);
+        float *dst = t2 + w * M2 + VPL2 * lane;
 #pragma unroll
-    for (int xc = 0; xc < 2; ++xc)
-#pragma unroll
-        for (int yc = 0; yc < 2; ++yc) {
-            // level-2 groups xc and 2 + yc; their halves are the level-1 groups 2xc, 2xc+1 and 4+2yc, 4+2yc+1
-            const int X0 = 2 * xc, Y0 = 2 * yc;      // Y0 relative to 4
-            float tv[VPL2];
-            tf_up<KC1, KC2>(t1 + (4 * X0 + Y0) * M1, t1 + (4 * X0 + Y0 + 1) * M1, t1 + (4 * (X0 + 1) + Y0) * M1,
-                            t1 + (4 * (X0 + 1) + Y0 + 1) * M1, L.pos[2] + ((b * G2 + xc) * KC2) * 2,
-                            L.pos[2] + ((b * G2 + 2 + yc) * KC2) * 2, tv);
-            float *dst = t2 + (xc * 2 + yc) * M2 + VPL2 * lane;
-#pragma unroll
-            for (int v = 0; v < VPL2; ++v) dst[v] = tv[v];
-        }
-    wave_lds_fence();
-    float t[VPL];
-    tf_up<KC2, KC3>(t2, t2 + M2, t2 + 2 * M2, t2 + 3 * M2, L.pos[3] + ((b * 2 + 0) * KC3) * 2,
-                    L.pos[3] + ((b * 2 + 1) * KC3) * 2, t);
-    float sv[VPL];
-    int sp[VPL];
-#pragma unroll
-    for (int v = 0; v < VPL; ++v) {
-        sv[v] = ((se + so[v]) - Eb) + 2.0f * t[v];
-        sp[v] = VPL * lane + v;
+        for (int v = 0; v < VPL2; ++v) dst[v] = tv[v];
     }
-    tf_finish<VPL>(sv, sp, 1, KC3, scratch, L, 4, b, N, 0, idx_final);
+    __syncthreads();
+    // candidate pair p = i * KC3 + j of the two level-3 lists: wave w takes p in [w PW, (w + 1) PW), ascending per lane
+    const uint8_t *px = L.pos[3] + ((b * 2 + 0) * KC3) * 2, *py = L.pos[3] + ((b * 2 + 1) * KC3) * 2;
+    const float *Sx = L.S[3] + (b * 2 + 0) * KC3, *Sy = L.S[3] + (b * 2 + 1) * KC3;
+    float bv = INFINITY;
+    int bp = kBigPos;
+#pragma unroll
+    for (int v = 0; v < VPLW; ++v) {
+        const int p = w * PW + VPLW * lane + v;
+        const int i = p / KC3, j = p % KC3;
+        const int i0 = px[2 * i], i1 = px[2 * i + 1], jj0 = py[2 * j], jj1 = py[2 * j + 1];
+        const float t = ((t2[i0 * KC2 + jj0] + t2[M2 + i0 * KC2 + jj1]) + t2[2 * M2 + i1 * KC2 + jj0]) + t2[3 * M2 + i1 * KC2 + jj1];
+        lexmin(bv, bp, ((Sx[i] + Sy[j]) - Eb) + 2.0f * t, p);
+    }
+    wave_lexmin(bv, bp);
+    if (lane == 0) { wv[w] = bv; wp[w] = bp; }
+    __syncthreads();
+    if (w == 0) {
+        float rv = wv[0];
+        int rp = wp[0];
+#pragma unroll
+        for (int u = 1; u < 4; ++u) lexmin(rv, rp, wv[u], wp[u]);
+        if (rp > KC3 * KC3 - 1) rp = KC3 * KC3 - 1;              // only reachable with NaN keys
+        tf_emit(L, b, N, 4, rp, idx_final);
+    }
 }
 
 }  // namespace mcq

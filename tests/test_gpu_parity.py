@@ -517,3 +517,42 @@ def test_logits_refine_is_logits_argmax_then_refine_indexes():
         torch.cuda.synchronize()
         assert torch.equal(lg1, lg2) and torch.equal(i1, i2), iters
         assert torch.equal(i2, q._compute_indexes(x, iters))
+
+
+@pytest.mark.parametrize("per_lane,cnt", [(1, 8), (4, 8), (4, 16), (4, 32), (16, 16), (16, 32), (16, 64), (4, 1), (16, 1)])
+def test_wave_selection_paths(per_lane, cnt):
+    """wave_select_fast on its own (mcq_test_select): the cnt smallest of 64 * per_lane scores in (value, position) order,
+    for random scores, heavy ties, survivors clustered in a few lanes (more than the two-per-lane path holds: the general
+    quickselect takes over) and constant input"""
+    from quantization_amd import _lib
+    L = _lib.lib()
+    M = 64 * per_lane
+    rs = np.random.RandomState(per_lane * 100 + cnt)
+    cases = []
+    for c in range(40):
+        kind = c % 5
+        if kind == 0:
+            sc = rs.standard_normal(M) * 10 + 500
+        elif kind == 1:                                   # heavy ties: a handful of distinct values
+            sc = rs.randint(0, 6, size=M).astype(np.float64)
+        elif kind == 2:                                   # the small scores all sit in a few lanes
+            sc = rs.standard_normal(M) + 100
+            lanes = rs.choice(64, size=max(cnt, 12), replace=False)
+            for l in lanes:
+                sc[per_lane * l:per_lane * (l + 1)] = rs.standard_normal(per_lane)
+        elif kind == 3:
+            sc = np.full(M, 3.25)
+        else:                                             # negative and positive, zeros
+            sc = rs.standard_normal(M)
+            sc[rs.randint(0, M, size=M // 8)] = 0.0
+        cases.append(sc.astype(np.float32))
+    sc = np.stack(cases)
+    dsc = torch.from_numpy(sc).cuda()
+    ov = torch.zeros((len(cases), 64), dtype=torch.float32, device="cuda")
+    op = torch.zeros((len(cases), 64), dtype=torch.int32, device="cuda")
+    assert L.mcq_test_select(dsc.data_ptr(), len(cases), per_lane, cnt, ov.data_ptr(), op.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    for c in range(len(cases)):
+        order = np.lexsort((np.arange(M), sc[c]))[:cnt]          # by value, then position
+        assert np.array_equal(op[c, :cnt].cpu().numpy(), order), (c, per_lane, cnt)
+        assert np.array_equal(ov[c, :cnt].cpu().numpy(), sc[c][order])
