@@ -316,6 +316,14 @@ k_fgemm(const FixGemm g) {
         // lane-dependent offsets are formed anew for every tile (hoisted out of the tile loop they would cost 128 registers)
         int rbase = 64 * wm + 4 * kh, cbase = 64 * wn + r32;
         asm volatile("" : "+v"(rbase), "+v"(cbase));
+        // the exponents (and biases) of this lane's 32 rows: eight 16-byte LDS reads up front -- read one by one next to
+        // their use, every output waited out an LDS round trip of its own (the epilogue was 0.13 ms of a 0.73 ms launch)
+        i32x4 er[2][4];
+#pragma unroll
+        for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) er[ta][q] = *reinterpret_cast<const i32x4 *>(&info[rbase + 32 * ta + 8 * q]);
+        const bool full = (m0 + kFixTile <= g.M) && (n0 + kFixTile <= g.N);      // whole tile inside: no per-element guards
         if (MODE == FG_STORE) {
             const int rows_left = (int)((g.M - m0 - rbase) > 128 ? 128 : (g.M - m0 - rbase));
             float *orow = g.out + (m0 + rbase) * g.ldo + n0 + cbase;
@@ -323,14 +331,24 @@ k_fgemm(const FixGemm g) {
             for (int tb = 0; tb < 2; ++tb) {
                 const bool col_ok = n0 + cbase + 32 * tb < g.N;
                 const int ecol = info[128 + cbase + 32 * tb] - 36;
+                if (full) {
 #pragma unroll
-                for (int ta = 0; ta < 2; ++ta)
+                    for (int ta = 0; ta < 2; ++ta)
 #pragma unroll
-                    for (int v = 0; v < 16; ++v) {
-                        const int ro = 32 * ta + 8 * (v >> 2) + (v & 3);          // row of the lane's block
-                        const float val = value(ta, tb, v, info[rbase + ro] + ecol);
-                        if (col_ok && ro < rows_left) orow[(long)ro * g.ldo + 32 * tb] = val;
-                    }
+                        for (int v = 0; v < 16; ++v) {
+                            const int ro = 32 * ta + 8 * (v >> 2) + (v & 3);          // row of the lane's block
+                            orow[(long)ro * g.ldo + 32 * tb] = value(ta, tb, v, er[ta][v >> 2][v & 3] + ecol);
+                        }
+                } else {
+#pragma unroll
+                    for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+                        for (int v = 0; v < 16; ++v) {
+                            const int ro = 32 * ta + 8 * (v >> 2) + (v & 3);
+                            const float val = value(ta, tb, v, er[ta][v >> 2][v & 3] + ecol);
+                            if (col_ok && ro < rows_left) orow[(long)ro * g.ldo + 32 * tb] = val;
+                        }
+                }
             }
         } else {
             const float ls = g.lscale_ptr ? *g.lscale_ptr : g.lscale;
@@ -338,6 +356,11 @@ k_fgemm(const FixGemm g) {
             float bv[2][4];       // best of the 16-row group (ta, v >> 3), this lane's 8 rows of it
             int bk[2][4];
             const int rows_left = (int)((g.M - m0 - rbase) > 128 ? 128 : (g.M - m0 - rbase));
+            f32x4 br[2][4];
+#pragma unroll
+            for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) br[ta][q] = *reinterpret_cast<const f32x4 *>(&infof[256 + rbase + 32 * ta + 8 * q]);
 #pragma unroll
             for (int tb = 0; tb < 2; ++tb) {
                 const long col = n0 + cbase + 32 * tb;
@@ -352,13 +375,13 @@ k_fgemm(const FixGemm g) {
                         for (int c = 0; c < 4; ++c) {
                             const int v = 4 * v4 + c;
                             const int rl = rbase + 32 * ta + 8 * v4 + c;
-                            const float val = __fadd_rn(__fmul_rn(value(ta, tb, v, info[rl] + ecol), ls), infof[256 + rl]);
+                            const float val = __fadd_rn(__fmul_rn(value(ta, tb, v, er[ta][v4][c] + ecol), ls), br[ta][v4][c]);
                             q4[c] = val;
                             const int gi = 2 * ta + (v4 >> 1);
                             if ((v4 & 1) == 0 && c == 0) { bv[tb][gi] = val; bk[tb][gi] = rl; }
                             else if (val > bv[tb][gi]) { bv[tb][gi] = val; bk[tb][gi] = rl; }
                         }
-                        if (g.logits && col < g.N && 32 * ta + 8 * v4 < rows_left)
+                        if (g.logits && (full || (col < g.N && 32 * ta + 8 * v4 < rows_left)))
                             *reinterpret_cast<f32x4 *>(lrow + 32 * ta + 8 * v4) = q4;
                     }
             }
