@@ -475,15 +475,34 @@ k_tf_table1(const float *__restrict__ G, const uint8_t *__restrict__ idx, TfList
     }
 }
 
-// copy `count` tables of M floats each from global memory to LDS (wave-cooperative)
-template <int M>
-__device__ __forceinline__ void tf_load_tables(const float *__restrict__ src, float *dst, int count) {
+// copy COUNT tables of M floats each from global memory to LDS (wave-cooperative).  The loads go out in batches of up to
+// eight per lane before the first LDS write: written as a plain loop the compiler issued load, wait, write per
+// iteration -- a memory round trip per 1 KB.
+template <int M, int COUNT>
+__device__ __forceinline__ void tf_load_tables(const float *__restrict__ src, float *dst) {
     const int lane = lane_id();
-    if constexpr (M % 256 == 0) {
-        for (int u = lane; u < count * (M / 4); u += 64)
-            reinterpret_cast<f32x4 *>(dst)[u] = reinterpret_cast<const f32x4 *>(src)[u];
+    if constexpr ((COUNT * M) % 256 == 0) {
+        constexpr int IT = COUNT * M / 256;               // float4 per lane
+        constexpr int BATCH = IT < 8 ? IT : 8;
+#pragma unroll
+        for (int i0 = 0; i0 < IT; i0 += BATCH) {
+            f32x4 r[BATCH];
+#pragma unroll
+            for (int i = 0; i < BATCH; ++i)
+                if (i0 + i < IT) r[i] = reinterpret_cast<const f32x4 *>(src)[lane + 64 * (i0 + i)];
+#pragma unroll
+            for (int i = 0; i < BATCH; ++i)
+                if (i0 + i < IT) reinterpret_cast<f32x4 *>(dst)[lane + 64 * (i0 + i)] = r[i];
+        }
     } else {
-        for (int u = lane; u < count * M; u += 64) dst[u] = src[u];
+        constexpr int TOT = COUNT * M;                    // (64-entry tables: K == 16)
+        constexpr int IT = (TOT + 63) / 64;
+        float r[IT];
+#pragma unroll
+        for (int i = 0; i < IT; ++i) r[i] = (lane + 64 * i < TOT) ? src[lane + 64 * i] : 0.f;
+#pragma unroll
+        for (int i = 0; i < IT; ++i)
+            if (lane + 64 * i < TOT) dst[lane + 64 * i] = r[i];
     }
 }
 
@@ -528,7 +547,7 @@ k_tf_up(TfLists L, long B, int N, int u, int ntab, int per, const float *__restr
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-            tf_load_tables<MH>(tabs_in + (cbase + (size_t)(2 * a + i) * (2 * per) + (2 * c + j)) * MH, th + (2 * i + j) * MH, 1);
+            tf_load_tables<MH, 1>(tabs_in + (cbase + (size_t)(2 * a + i) * (2 * per) + (2 * c + j)) * MH, th + (2 * i + j) * MH);
     wave_lds_fence();
     float tv[VPL];
     tf_up<KH, KC>(th, th + MH, th + 2 * MH, th + 3 * MH, L.pos[u] + ((b * Gu + X) * KC) * 2, L.pos[u] + ((b * Gu + Y) * KC) * 2, tv);
@@ -557,7 +576,7 @@ k_tf_comb(const float *__restrict__ E, TfLists L, long B, int N, int v, int keep
     if (b >= B) return;
     const int lane = lane_id();
     const int P = 2 * h, Q = P + 1, Gv = N >> v;
-    tf_load_tables<MH>(tabs + ((size_t)b * Gout + h) * 4 * MH, th, 4);
+    tf_load_tables<MH, 4>(tabs + ((size_t)b * Gout + h) * 4 * MH, th);
     const float Eb = E[b];
     const uint8_t *px = L.pos[v] + ((b * Gv + P) * KC) * 2, *py = L.pos[v] + ((b * Gv + Q) * KC) * 2;
     const float *Sx = L.S[v] + (b * Gv + P) * KC, *Sy = L.S[v] + (b * Gv + Q) * KC;
@@ -617,7 +636,7 @@ k_tf_comb3(const uint8_t *__restrict__ idx, const float *__restrict__ E, TfLists
     const long b = blockIdx.x;
     if (b >= B) return;
     const int lane = lane_id(), w = threadIdx.x >> 6;
-    tf_load_tables<M1>(tabs + ((size_t)b * 16 + 4 * w) * M1, t1 + 4 * w * M1, 4);
+    tf_load_tables<M1, 4>(tabs + ((size_t)b * 16 + 4 * w) * M1, t1 + 4 * w * M1);
     const float Eb = E[b];
     __syncthreads();
     const int G2 = N >> 2;   // 4 level-2 groups
