@@ -186,19 +186,33 @@ __device__ __forceinline__ void tf_leaf(const float *__restrict__ G, int NK, int
     const int lane = lane_id();
     const int i = (VPL * lane) / KC, j0 = (VPL * lane) % KC;
     const uint32_t rown = (uint32_t)(n * K), colm = (uint32_t)(m * K);
-    const uint32_t si = rown + en[i];
+    // every list byte this lane needs (its row entry, its VPL column entries, its border entry) is requested before the first
+    // use: left to the compiler the border bytes were loaded one after the other BEHIND the first wait, and the Gram reads
+    // started four memory round trips into the kernel instead of two
+    const int bl = lane < 2 * KC ? lane : 2 * KC;
+    const uint8_t *bp = bl < KC ? en + bl : em + (bl < 2 * KC ? bl - KC : 0);
+    int e_i = en[i], e_b = *bp;
+    uint32_t w4 = 0;
+    int ej[VPL];
+    if constexpr (VPL == 4) {
+        w4 = *reinterpret_cast<const uint32_t *>(em + j0);
+        asm volatile("" : "+v"(e_i), "+v"(e_b), "+v"(w4));
+    } else {
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) ej[v] = em[j0 + v];
+        asm volatile("" : "+v"(e_i), "+v"(e_b), "+v"(ej[0]));
+    }
+    const uint32_t si = rown + (uint32_t)e_i;
+    const uint32_t br = bl < KC ? rown + (uint32_t)e_b : rown + (uint32_t)old_n;
+    const uint32_t bc = (bl >= KC && bl < 2 * KC) ? colm + (uint32_t)e_b : colm + (uint32_t)old_m;
     float g[VPL];
     if constexpr (VPL == 4) {
-        const uint32_t w4 = *reinterpret_cast<const uint32_t *>(em + j0);
 #pragma unroll
         for (int v = 0; v < 4; ++v) g[v] = G[si * (uint32_t)NK + colm + ((w4 >> (8 * v)) & 0xffu)];
     } else {
 #pragma unroll
-        for (int v = 0; v < VPL; ++v) g[v] = G[si * (uint32_t)NK + colm + em[j0 + v]];
+        for (int v = 0; v < VPL; ++v) g[v] = G[si * (uint32_t)NK + colm + (uint32_t)ej[v]];
     }
-    const int bl = lane < 2 * KC ? lane : 2 * KC;
-    const uint32_t br = bl < KC ? rown + en[bl < KC ? bl : 0] : rown + (uint32_t)old_n;
-    const uint32_t bc = (bl >= KC && bl < 2 * KC) ? colm + em[(bl >= KC && bl < 2 * KC) ? bl - KC : 0] : colm + (uint32_t)old_m;
     const float bv = G[br * (uint32_t)NK + bc];
     const float u = shfl_f(bv, i), w = shfl_f(bv, 2 * KC);
 #pragma unroll
@@ -306,9 +320,17 @@ __device__ __forceinline__ void tf_table1(const float *__restrict__ G, const uin
         const int NK = N * K;
         // quarter w of the wave = one of the four halves' lists: 0, 1 = the halves of X, 2, 3 = those of Y
         const int w = lane >> 4, c = lane & 15;
-        const int mypos = (w < 2 ? px : py)[2 * c + (w & 1)];
         const int cb = (w < 2) ? 2 * X + w : 2 * Y + (w - 2);      // this quarter's codebook
-        const int myent = L.ent[(b * N + cb) * KCH + c];            // entry at level-0 position c of that codebook
+        // every byte of the lists and of the current indexes this wave needs is requested here, together: left to the
+        // compiler they were loaded one at a time, each behind a full wait, and the four border reads below (which only
+        // need the current entries of their codebooks) were serialised behind them -- eleven round trips instead of three
+        int mypos = (w < 2 ? px : py)[2 * c + (w & 1)];
+        int myent = L.ent[(b * N + cb) * KCH + c];                  // entry at level-0 position c of that codebook
+        int oldv = id[cb];                                          // current entry of this quarter's codebook
+        asm volatile("" : "+v"(mypos), "+v"(myent), "+v"(oldv));
+        int oldq[4];                                                // current entries of codebooks 2X, 2X+1, 2Y, 2Y+1
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) oldq[qq] = __builtin_amdgcn_readlane(oldv, 16 * qq);
         uint32_t m = 1u << mypos;
         m |= (uint32_t)dpp_i<0x121>((int)m);     // row_ror 1, 2, 4, 8: OR over the 16 lanes of the quarter
         m |= (uint32_t)dpp_i<0x122>((int)m);
@@ -337,8 +359,8 @@ __device__ __forceinline__ void tf_table1(const float *__restrict__ G, const uin
             colm_[tb] = (uint32_t)(mcb * K);
             // border: lanes [0, na) G[s_i][o_m], [na, na + nc) G[o_n][s_j], the others G[o_n][o_m]
             const bool isu = lane < na_[tb], isv = lane >= na_[tb] && lane < na_[tb] + nc_[tb];
-            const uint32_t br = rown_[tb] + (uint32_t)(isu ? cent[a * 16 + lane] : id[n]);
-            const uint32_t bc = colm_[tb] + (uint32_t)(isv ? cent[(2 + cc) * 16 + (lane - na_[tb])] : id[mcb]);
+            const uint32_t br = rown_[tb] + (uint32_t)(isu ? cent[a * 16 + lane] : oldq[a]);
+            const uint32_t bc = colm_[tb] + (uint32_t)(isv ? cent[(2 + cc) * 16 + (lane - na_[tb])] : oldq[2 + cc]);
             bv[tb] = G[br * (uint32_t)NK + bc];
         }
         float g[4][4];
