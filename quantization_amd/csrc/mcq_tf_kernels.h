@@ -123,6 +123,34 @@ k_tf_stage0(const float *__restrict__ G, const float *__restrict__ XC, const uin
     const bool act = VPL * lane < K;
     const int k0 = act ? VPL * lane : 0;
     const uint8_t *id = idx + b * N;
+    // the vector's own inputs (its x.C segment comes from HBM: the longest latency of the kernel) are requested first,
+    // beside the index bytes, not after the Gram rows that depend on those bytes
+    const float *xc = XC + ((size_t)(map ? (long)map[b] : b) * NK + n * K + k0);
+    const float *q = Q + n * K + k0;
+    float xcv[VPL], qv[VPL];
+    if constexpr (VPL == 4) {
+        const f32x4 x4 = *reinterpret_cast<const f32x4 *>(xc), q4 = *reinterpret_cast<const f32x4 *>(q);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { xcv[i] = x4[i]; qv[i] = q4[i]; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) { xcv[i] = xc[i]; qv[i] = q[i]; }
+    }
+    const float Rv = R[b * N + n];
+    __builtin_amdgcn_sched_barrier(0);                      // (the scheduler otherwise sinks the x.C read below the Gram reads)
+    // the vector's N index bytes: one scalar load per 8 of them (the vector is the same for the whole wave) instead of N - 1
+    // byte loads per lane; the Gram row addresses are then scalar too
+    unsigned long long iw[N >= 8 ? N / 8 : 1];
+    if constexpr (N >= 8) {
+        const unsigned long long *ip =
+            reinterpret_cast<const unsigned long long *>(idx) + (size_t)__builtin_amdgcn_readfirstlane((int)b) * (N / 8);
+#pragma unroll
+        for (int q8 = 0; q8 < N / 8; ++q8) iw[q8] = ip[q8];
+    }
+    auto code = [&](int m) -> int {
+        if constexpr (N >= 8) return (int)((iw[m >> 3] >> (8 * (m & 7))) & 0xffull);
+        else return (int)id[m];
+    };
     float t[VPL];
 #pragma unroll
     for (int i = 0; i < VPL; ++i) t[i] = 0.f;               // N == 1: no other codebook, X = 0 - XC
@@ -133,7 +161,7 @@ k_tf_stage0(const float *__restrict__ G, const float *__restrict__ XC, const uin
         for (int u = 0; u < CH; ++u) {
             const int j = j0 + u < N - 1 ? j0 + u : N - 2;
             const int m = j < n ? j : j + 1;                    // m ascending over the codebooks other than n
-            const float *p = G + ((size_t)(m * K + id[m]) * NK + n * K + k0);
+            const float *p = G + ((size_t)(m * K + code(m)) * NK + n * K + k0);
             if constexpr (VPL == 4) {
                 const f32x4 t4 = *reinterpret_cast<const f32x4 *>(p);
 #pragma unroll
@@ -150,15 +178,12 @@ k_tf_stage0(const float *__restrict__ G, const float *__restrict__ XC, const uin
                 for (int i = 0; i < VPL; ++i) t[i] = (j0 + u == 0) ? gv[u][i] : t[i] + gv[u][i];
             }
     }
-    const float *xc = XC + ((size_t)(map ? (long)map[b] : b) * NK + n * K + k0);
-    const float *q = Q + n * K + k0;
-    const float Rv = R[b * N + n];
     float sv[VPL];
     int sp[VPL];
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
-        const float X = t[i] - xc[i];
-        sv[i] = act ? (Rv + q[i]) + 2.0f * X : INFINITY;
+        const float X = t[i] - xcv[i];
+        sv[i] = act ? (Rv + qv[i]) + 2.0f * X : INFINITY;
         sp[i] = act ? k0 + i : kBigPos;
     }
     float ov;
