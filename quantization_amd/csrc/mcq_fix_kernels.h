@@ -42,7 +42,7 @@ __device__ __forceinline__ int fix_q(float v, int e) {
     return (int)rintf(s);
 }
 
-// Workgroup = RW rows (16, or 4 when there are few rows: more workgroups), wave w takes RW / 4 of them.  Pass 1: the row
+// Workgroup = RW rows (4 is what ships: one row per wave), wave w takes RW / 4 of them.  Pass 1: the row
 // exponent (and, for frames, |x|^2 as the sum of squares of the path is formed: lane l adds the float4 groups l, l + 64,
 // ... then the butterfly); rows of up to 1,024 columns stay in registers for pass 2.  Pass 2, per block of 512 columns:
 // limbs to LDS as [plane][row][16 bytes], then runs of RW x 16 bytes (RW rows of one plane) to the planes.
@@ -69,7 +69,7 @@ k_fix_rows(const float *__restrict__ src, int xh, long R, long Rp, int D, long l
             if (4 * q + c < D) v[c] = xh ? (float)srch[row * ld + 4 * q + c] : src[row * ld + 4 * q + c];
         return v;
     };
-    const bool cached = (RW == 4) && D <= 1024;      // (16-row workgroups: measured slower with the rows held, 0.126 vs 0.083 ms)
+    const bool cached = (RW == 4) && D <= 1024;      // (16-row workgroups measured slower with the rows held, 0.126 vs 0.083 ms, and slower than 4-row ones either way)
     f32x4 cache[RW == 4 ? RPW : 1][4];
 #pragma unroll
     for (int rr = 0; rr < RPW; ++rr) {

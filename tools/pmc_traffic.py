@@ -3,7 +3,7 @@
 usage: pmc_traffic.py gpurun_out/<pmc dir> > profiles/r02_pmc_traffic.json   (keys = bench.py's kernel categories)"""
 import collections, csv, glob, json, os, re, sys
 root = sys.argv[1]
-KERNELS = {"logits_product_argmax": "k_fgemm<1>", "xc_product": "k_fgemm<0>", "frames_to_limbs": "k_fix_rows<16>",
+KERNELS = {"logits_product_argmax": "k_fgemm<1>", "xc_product": "k_fgemm<0>", "frames_to_limbs": "k_fix_rows<4>",
            "residual_energies": "k_tf_er<8>", "stage0_tables": "k_tf_stage0<256, 8>", "combine_level0": "k_tf_pair0<16>",
            "combine_level1": "k_tf_pair1<16, 16>", "tables_level1": "k_tf_table1<16, 16>", "combine_level2": "k_tf_comb<16, 32>"}
 vals = collections.defaultdict(lambda: collections.defaultdict(list))
