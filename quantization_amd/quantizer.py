@@ -207,6 +207,7 @@ class Quantizer(nn.Module):
             "quantization.py:506, and needs <= 256 for byte codes, :271)")
         assert self.num_codebooks <= (64 if self.codebook_size == 16 else 32), (
             "num_codebooks <= 64 for codebook_size 16, <= 32 otherwise (bytes_per_frame <= 32, quantization.py:614)")
+        assert self.dim <= 16384, "dim <= 16384 (the i32 accumulators of the fixed-point products, include/mcq.h)"
 
     def _workspace(self, B: int, dev) -> Tensor:
         """Scratch of the search, one buffer per (device, stream): encodes issued on different streams never share it."""
