@@ -683,35 +683,61 @@ k_tf_comb3(const uint8_t *__restrict__ idx, const float *__restrict__ E, TfLists
     const long b = blockIdx.x;
     if (b >= B) return;
     const int lane = lane_id(), w = threadIdx.x >> 6;
-    tf_load_tables<M1, 4>(tabs + ((size_t)b * 16 + 4 * w) * M1, t1 + 4 * w * M1);
-    const float Eb = E[b];
-    __syncthreads();
     const int G2 = N >> 2;   // 4 level-2 groups
-    {
-        // level-2 groups xc and 2 + yc; their halves are the level-1 groups 2xc, 2xc+1 and 4+2yc, 4+2yc+1
-        const int xc = w >> 1, yc = w & 1;
-        const int X0 = 2 * xc, Y0 = 2 * yc;      // Y0 relative to 4
-        float tv[VPL2];
-        tf_up<KC1, KC2>(t1 + (4 * X0 + Y0) * M1, t1 + (4 * X0 + Y0 + 1) * M1, t1 + (4 * (X0 + 1) + Y0) * M1,
-                        t1 + (4 * (X0 + 1) + Y0 + 1) * M1, L.pos[2] + ((b * G2 + xc) * KC2) * 2,
-                        L.pos[2] + ((b * G2 + 2 + yc) * KC2) * 2, tv);
-        float *dst = t2 + w * M2 + VPL2 * lane;
+    // level-2 groups xc and 2 + yc (this wave's table); their halves are the level-1 groups 2xc, 2xc+1 and 4+2yc, 4+2yc+1
+    const int xc = w >> 1, yc = w & 1;
+    // Every list byte and score this wave will need -- for its level-2 table and for its quarter of the candidate pairs --
+    // is requested here, before the tables: read where they are used they were single-byte loads, each behind a full wait
+    constexpr int NB2 = 2 * VPL2;                                 // position bytes of the lane's VPL2 columns (8 or 32)
+    const int i2 = (VPL2 * lane) / KC2, j2 = (VPL2 * lane) % KC2;
+    const uint8_t *px2 = L.pos[2] + ((b * G2 + xc) * KC2) * 2, *py2 = L.pos[2] + ((b * G2 + 2 + yc) * KC2) * 2;
+    const unsigned pxw2 = *reinterpret_cast<const uint16_t *>(px2 + 2 * i2);
+    uint32_t pyw2[NB2 / 4];
 #pragma unroll
-        for (int v = 0; v < VPL2; ++v) dst[v] = tv[v];
-    }
-    __syncthreads();
-    // candidate pair p = i * KC3 + j of the two level-3 lists: wave w takes p in [w PW, (w + 1) PW), ascending per lane
+    for (int u = 0; u < NB2 / 4; ++u) pyw2[u] = reinterpret_cast<const uint32_t *>(py2 + 2 * j2)[u];
     const uint8_t *px = L.pos[3] + ((b * 2 + 0) * KC3) * 2, *py = L.pos[3] + ((b * 2 + 1) * KC3) * 2;
     const float *Sx = L.S[3] + (b * 2 + 0) * KC3, *Sy = L.S[3] + (b * 2 + 1) * KC3;
-    float bv = INFINITY;
-    int bp = kBigPos;
+    // candidate pair p = i * KC3 + j of the two level-3 lists: wave w takes p in [w PW, (w + 1) PW), ascending per lane;
+    // a lane's VPLW pairs share the row i (VPLW divides KC3)
+    const int p0 = w * PW + VPLW * lane;
+    const int i3 = p0 / KC3, j3 = p0 % KC3;
+    const unsigned pxw3 = *reinterpret_cast<const uint16_t *>(px + 2 * i3);
+    unsigned pyw3[VPLW];
+    float sy3[VPLW];
 #pragma unroll
     for (int v = 0; v < VPLW; ++v) {
-        const int p = w * PW + VPLW * lane + v;
-        const int i = p / KC3, j = p % KC3;
-        const int i0 = px[2 * i], i1 = px[2 * i + 1], jj0 = py[2 * j], jj1 = py[2 * j + 1];
-        const float t = ((t2[i0 * KC2 + jj0] + t2[M2 + i0 * KC2 + jj1]) + t2[2 * M2 + i1 * KC2 + jj0]) + t2[3 * M2 + i1 * KC2 + jj1];
-        lexmin(bv, bp, ((Sx[i] + Sy[j]) - Eb) + 2.0f * t, p);
+        pyw3[v] = *reinterpret_cast<const uint16_t *>(py + 2 * (j3 + v));
+        sy3[v] = Sy[j3 + v];
+    }
+    const float sx3 = Sx[i3];
+    const float Eb = E[b];
+    tf_load_tables<M1, 4>(tabs + ((size_t)b * 16 + 4 * w) * M1, t1 + 4 * w * M1);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    {
+        const int X0 = 2 * xc, Y0 = 2 * yc;      // Y0 relative to 4
+        const float *t00 = t1 + (4 * X0 + Y0) * M1, *t01 = t1 + (4 * X0 + Y0 + 1) * M1, *t10 = t1 + (4 * (X0 + 1) + Y0) * M1,
+                    *t11 = t1 + (4 * (X0 + 1) + Y0 + 1) * M1;
+        const int i0 = (int)(pxw2 & 0xffu), i1 = (int)(pxw2 >> 8);
+        float *dst = t2 + w * M2 + VPL2 * lane;
+#pragma unroll
+        for (int v = 0; v < VPL2; ++v) {
+            const uint32_t wj = pyw2[v >> 1] >> (16 * (v & 1));
+            const int jj0 = (int)(wj & 0xffu), jj1 = (int)((wj >> 8) & 0xffu);
+            dst[v] = ((t00[i0 * KC1 + jj0] + t01[i0 * KC1 + jj1]) + t10[i1 * KC1 + jj0]) + t11[i1 * KC1 + jj1];
+        }
+    }
+    __syncthreads();
+    float bv = INFINITY;
+    int bp = kBigPos;
+    {
+        const int i0 = (int)(pxw3 & 0xffu), i1 = (int)(pxw3 >> 8);
+#pragma unroll
+        for (int v = 0; v < VPLW; ++v) {
+            const int jj0 = (int)(pyw3[v] & 0xffu), jj1 = (int)(pyw3[v] >> 8);
+            const float t = ((t2[i0 * KC2 + jj0] + t2[M2 + i0 * KC2 + jj1]) + t2[2 * M2 + i1 * KC2 + jj0]) + t2[3 * M2 + i1 * KC2 + jj1];
+            lexmin(bv, bp, ((sx3 + sy3[v]) - Eb) + 2.0f * t, p0 + v);
+        }
     }
     wave_lexmin(bv, bp);
     if (lane == 0) { wv[w] = bv; wp[w] = bp; }
