@@ -253,3 +253,22 @@ def test_weight_grad_kernel_matches_matmul(B, N, K, D):
                              ws.numel(), st) == 0
     torch.cuda.synchronize()
     assert torch.equal(gW, gW2) and torch.equal(gb, gb2)        # fixed summation order
+
+
+@pytest.mark.parametrize("D,K,N", [(64, 16, 8), (100, 256, 2), (512, 256, 8), (40, 32, 64 // 4)])
+def test_data_mean_in_the_prepared_state(D, K, N):
+    """get_data_mean() (quantization.py:67-75) of the scaled centers is formed by mcq_prepare inside the prepared blob
+    (k_centers_mean): equal to centers.mean(dim=1).sum(dim=0) up to fp32 summation order"""
+    from quantization_amd import Quantizer, _lib
+    torch.manual_seed(D + K)
+    q = Quantizer(D, K, N).cuda()
+    with torch.no_grad():
+        q.centers.copy_(torch.randn_like(q.centers))
+        q.centers_scale.fill_(0.03)
+        blob = q._prepared()
+        L = _lib.lib()
+        off = L.mcq_prepared_mean_offset(N, K, D)
+        Dp = L.mcq_padded_dim(D)
+        got = blob[off:off + 4 * Dp].view(torch.float32)[:D].cpu()
+        want = q.get_centers().mean(dim=1).sum(dim=0).cpu()
+    assert torch.allclose(got, want, rtol=1e-5, atol=1e-6), (got - want).abs().max()
