@@ -271,7 +271,13 @@ k_centers_mean(const float *__restrict__ C /*[N][K][Dp]*/, int N, int K, int Dp,
     for (int n = wave; n < N; n += 16) {
         const float *p = C + ((size_t)n * K + (size_t)kq * kn) * Dp + d;
         float s = 0.f;
-        for (int k = 0; k < kn; ++k) s = s + p[(size_t)k * Dp];
+        for (int k0 = 0; k0 < kn; k0 += 4) {          // kn is a multiple of 4 (K >= 16): four loads in flight, added in order
+            float r[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) r[u] = p[(size_t)(k0 + u) * Dp];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s = s + r[u];
+        }
         s = s + __shfl_xor(s, 16, 64);
         s = s + __shfl_xor(s, 32, 64);
         if (kq == 0) part[n][c] = s / (float)K;
