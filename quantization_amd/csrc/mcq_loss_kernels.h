@@ -54,33 +54,46 @@ k_loss_fwd(const float *__restrict__ logits, const int64_t *__restrict__ idx, lo
 #pragma unroll
     for (int i = 0; i < VPL; ++i) acc[i] = 0.f;
     float chosen = 0.f;
-    for (long b0 = b_lo + (long)wave * RPW; b0 < b_hi; b0 += (long)kLossWaves * RPW) {
-        const long b = b0 + sub;
-        const bool ok = b < b_hi;
-        const long bc = ok ? b : b_hi - 1;
-        const float *z = logits + (bc * N + n) * (long)K;
-        float v[VPL];
+    // four rows per trip: their logits (and targets) are requested together, then taken in row order -- one row per trip
+    // was a memory round trip per row (16 per wave at 64 rows per chunk)
+    constexpr int UR = 4;
+    for (long b0 = b_lo + (long)wave * RPW; b0 < b_hi; b0 += (long)UR * kLossWaves * RPW) {
+        float vv[UR][VPL];
+        int kiv[UR];
 #pragma unroll
-        for (int i = 0; i < VPL; ++i) v[i] = z[kl + KL * i];
-        float mx = v[0];
+        for (int u = 0; u < UR; ++u) {
+            const long b = b0 + (long)u * kLossWaves * RPW + sub;
+            const long bc = b < b_hi ? b : b_hi - 1;
+            const float *z = logits + (bc * N + n) * (long)K;
 #pragma unroll
-        for (int i = 1; i < VPL; ++i) mx = fmaxf(mx, v[i]);
-        mx = row_max<KL>(mx);
-        float se = 0.f;
+            for (int i = 0; i < VPL; ++i) vv[u][i] = z[kl + KL * i];
+            kiv[u] = (int)idx[bc * N + n];
+        }
 #pragma unroll
-        for (int i = 0; i < VPL; ++i) se += expf(v[i] - mx);
-        se = row_sum<KL>(se);
-        const float lse = mx + logf(se);
-        const int ki = (int)idx[bc * N + n];
-        if (ok && kl == 0) lse_out[b * N + n] = lse;
-        if (ok && ki >= 0) {   // negative target = "no index here" (padding frames of JointCodebookLoss): contributes nothing
+        for (int u = 0; u < UR; ++u) {
+            const long b = b0 + (long)u * kLossWaves * RPW + sub;
+            const bool ok = b < b_hi;
+            float (&v)[VPL] = vv[u];
+            float mx = v[0];
 #pragma unroll
-            for (int i = 0; i < VPL; ++i) {
-                const float lp = v[i] - lse;
-                acc[i] += expf(lp);
-                if (kl + KL * i == ki) chosen += lp;
+            for (int i = 1; i < VPL; ++i) mx = fmaxf(mx, v[i]);
+            mx = row_max<KL>(mx);
+            float se = 0.f;
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) se += expf(v[i] - mx);
+            se = row_sum<KL>(se);
+            const float lse = mx + logf(se);
+            const int ki = kiv[u];
+            if (ok && kl == 0) lse_out[b * N + n] = lse;
+            if (ok && ki >= 0) {   // negative target = "no index here" (padding frames of JointCodebookLoss): contributes nothing
+#pragma unroll
+                for (int i = 0; i < VPL; ++i) {
+                    const float lp = v[i] - lse;
+                    acc[i] += expf(lp);
+                    if (kl + KL * i == ki) chosen += lp;
+                }
+                if (kl == 0) atomicAdd(&s_count[ki & (K - 1)], 1);   // integer: order-independent
             }
-            if (kl == 0) atomicAdd(&s_count[ki & (K - 1)], 1);   // integer: order-independent
         }
     }
 #pragma unroll
