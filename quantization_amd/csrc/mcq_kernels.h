@@ -477,7 +477,7 @@ __global__ void k_decode(const CodeT *__restrict__ codes, int per_row, long B, c
 // every XCD's L2 only ever holds its own slice of the codebooks (N*K*Dp/8 floats: 0.5 MB at dim 512 / 8
 // codebooks instead of 4 MB, which is the whole L2).  A wave covers 64 / LPV vectors, LPV lanes x float4
 // per vector slice; rows are added n ascending in chunks of CH gathers in flight.  Unpacked codes only.
-template <typename CodeT, int CH, int LPV>
+template <typename CodeT, int CH, int LPV, bool NT>
 __global__ void __launch_bounds__(256)
 k_decode_sliced(const CodeT *__restrict__ codes, long B, const float *__restrict__ C, int N, int K, int D, int Dp,
                 float *__restrict__ out) {
@@ -506,7 +506,8 @@ k_decode_sliced(const CodeT *__restrict__ codes, long B, const float *__restrict
     }
     float *ob = out + b * D + off;
     if (((D & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0) && off + 3 < D) {
-        __builtin_nontemporal_store(t, reinterpret_cast<f32x4 *>(ob));   // streamed: keep the L2 for the codebooks
+        if (NT) __builtin_nontemporal_store(t, reinterpret_cast<f32x4 *>(ob));
+        else *reinterpret_cast<f32x4 *>(ob) = t;
     } else {
 #pragma unroll
         for (int c = 0; c < 4; ++c)
@@ -610,7 +611,7 @@ k_decode_lds(const CodeT *__restrict__ codes, long B, const float *__restrict__ 
 // against 36.9-40 us for k_decode_lds (whose codes are requested one trip ahead, four vectors at a time) -- the time of a
 // plain fill of the same 134 MB (29 us); larger batches prefer UNR = 2 (681 vs 729 us at 1,048,576 vectors) and settle at
 // 3.0-3.2 TB/s, bound by the LDS bank conflicts of random 64-byte rows and the 64-byte output pieces.
-template <int NL, int NGT, int UNR>
+template <int NL, int NGT, int UNR, bool NT>
 __global__ void __launch_bounds__(1024)
 k_decode_hyb(const uint8_t *__restrict__ codes, long B, const float *__restrict__ C, int N, int K, int D, int Dp,
              int groups /* workgroups per slice */, float *__restrict__ out) {
@@ -670,7 +671,10 @@ k_decode_hyb(const uint8_t *__restrict__ codes, long B, const float *__restrict_
             for (int j = 0; j < NGMAX; ++j)
                 if (j < NG) t = t + g0[u][j];
             const long bb = b + u * stride;
-            if (bb < b_hi && off < D) __builtin_nontemporal_store(t, reinterpret_cast<f32x4 *>(out + bb * D + off));      // (D % 4 == 0; the last slice may reach into the padding.  Plain stores: no better)
+            if (bb < b_hi && off < D) {                          // (D % 4 == 0; the last slice may reach into the padding)
+                if (NT) __builtin_nontemporal_store(t, reinterpret_cast<f32x4 *>(out + bb * D + off));
+                else *reinterpret_cast<f32x4 *>(out + bb * D + off) = t;
+            }
         }
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
@@ -678,6 +682,100 @@ k_decode_hyb(const uint8_t *__restrict__ codes, long B, const float *__restrict_
             c1[u][0] = c2[u][0]; c1[u][1] = c2[u][1];
 #pragma unroll
             for (int j = 0; j < NGMAX; ++j) g0[u][j] = g1[u][j];
+        }
+    }
+}
+
+// Block-staged LDS-resident decode for packed byte codes (N = 8 or 16 per vector) whose row slices fit the LDS.
+// What bounded k_decode_hyb was not the gather-sums (23 us at dim 512 / 8 x 256 / 65,536 vectors with the stores removed) nor
+// the write pattern (tools/micro/write_patterns.hip: the same 64-byte pieces written with PLAIN stores leave the chip at
+// the rate of a contiguous fill, 21 us; nontemporal ones take 34 us) but the wait between them: on gfx9 loads and stores
+// share one in-order counter (vmcnt), so waiting for the codes of a later trip also waits for every store issued before
+// their load, and the compiler's register copies at the end of a trip made that a full drain per trip (s_waitcnt vmcnt(0)).
+// Here no vector load is waited for inside the trips: the codes of a block of VB vectors (16 KB) go from global memory
+// straight into LDS (global_load_lds_dwordx4, one 1 KB piece per wave, requested a whole block ahead) and the trips read
+// them with ds_read; the one wait per block is s_waitcnt vmcnt(TRIPS) -- the piece was requested before the block's TRIPS
+// stores, which stay in flight.  W = 4 * LPV floats per slice: 64-byte slices (LPV = 4), or 32-byte slices (LPV = 2) for
+// 16 x 256 codebooks, whose 64-byte slices (256 KB) do not fit; XCD x owns a run of adjacent slices, so the pieces of an
+// output cache line meet in one L2 and leave it as whole lines (plain stores).  Sums n ascending as in k_decode.
+// A workgroup's last, partial block takes the guarded path (compiler-managed loads, per-vector clamps).
+template <int N, int LPV>
+__global__ void __launch_bounds__(1024)
+k_decode_blk(const uint8_t *__restrict__ codes, long B, const float *__restrict__ C, int K, int D, int Dp,
+             int groups /* workgroups per slice */, long per /* vectors per workgroup, a multiple of 256 */, float *__restrict__ out) {
+    static_assert(N == 8 || N == 16, "packed codes: 8 or 16 per vector");
+    constexpr int W = 4 * LPV;
+    constexpr int VPT = 1024 / LPV;                 // vectors per trip
+    constexpr int VB = 1024 * 16 / N;               // vectors per block: 16 bytes of codes per thread
+    constexpr int TRIPS = VB / VPT;
+    static_assert(TRIPS >= 1 && TRIPS < 32, "");
+    typedef unsigned cw_t __attribute__((ext_vector_type(N / 4)));      // the N code bytes of a vector
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4 *rows = reinterpret_cast<f32x4 *>(smem);                     // [N*K][LPV]
+    char *cbuf = smem + (size_t)N * K * W * 4;                         // 2 x 16 KB of codes
+    const int ns = Dp / W;
+    const int xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
+    const int per_xcd = (ns + 7) / 8;
+    const int slice = xcd * per_xcd + within % per_xcd;
+    const int grp = within / per_xcd;
+    if (slice >= ns) return;
+    const int tid = threadIdx.x;
+    const long b_lo = grp * per, b_hi = (b_lo + per < B) ? b_lo + per : B;
+    if (b_lo >= b_hi) return;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned voff = (unsigned)(tid & 63) * 16;
+    // (m0 is written without being declared clobbered -- the compiler rejects it as a reserved register; nothing else in this
+    // kernel uses m0: LDS instructions need no m0 on gfx9+)
+    auto dma = [&](long b0, int buf) {              // this wave's 1 KB of the codes of block b0 -> cbuf[buf]
+        const uint8_t *pg = codes + b0 * N + wave * 1024;
+        const unsigned d = (unsigned)(size_t)cbuf + buf * 16384 + wave * 1024;
+        asm volatile("s_mov_b32 m0, %[d]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[vo], %[p]" : : [vo] "v"(voff), [p] "s"(pg), [d] "s"(d) : "memory");
+    };
+    const bool first_full = b_lo + VB <= b_hi;
+    if (first_full) dma(b_lo, 0);
+    // the slice of every row, global -> LDS without passing through registers, all pieces of a wave in flight together
+    // (a load / wait / ds_write loop costs one round trip per KB and thread: 8 of them at 8 x 256)
+    for (int u0 = 0; u0 < N * K * LPV; u0 += 1024) {
+        const int u = u0 + tid;
+        if (u < N * K * LPV) {
+            const unsigned go = (unsigned)(((long)(u / LPV) * Dp + slice * W + 4 * (u % LPV)) * 4);
+            const unsigned d = (unsigned)(size_t)smem + (unsigned)(u0 + wave * 64) * 16;
+            asm volatile("s_mov_b32 m0, %[d]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[vo], %[p]" : : [vo] "v"(go), [p] "s"(C), [d] "s"(d) : "memory");
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                 // (the first block's codes are in as well)
+    const int q = tid % LPV, v0 = tid / LPV;
+    const int off = slice * W + 4 * q;
+    const bool lane_on = off < D;                    // (D % 4 == 0; the last slice may reach into the padding.  q = 0 is always inside)
+    auto code_of = [&](const cw_t &w, int n) { return (int)((w[n >> 2] >> (8 * (n & 3))) & 0xffu) & (K - 1); };
+    auto sum_rows = [&](const cw_t &w) {
+        f32x4 t = rows[code_of(w, 0) * LPV + q];
+#pragma unroll
+        for (int n = 1; n < N; ++n) t = t + rows[(n * K + code_of(w, n)) * LPV + q];
+        return t;
+    };
+    long b0 = b_lo;
+    int buf = 0;
+    for (; b0 + VB <= b_hi; b0 += VB, buf ^= 1) {
+        // every wave has left the previous block (its reads of cbuf[buf ^ 1] are done) once all have arrived here
+        if (b0 + 2 * VB <= b_hi) dma(b0 + VB, buf ^ 1);
+        const char *cb = cbuf + buf * 16384;
+        float *ob = out + (b0 + v0) * D + off;
+#pragma unroll
+        for (int t = 0; t < TRIPS; ++t) {
+            const cw_t w = *reinterpret_cast<const cw_t *>(cb + (size_t)(t * VPT + v0) * N);
+            const f32x4 r = sum_rows(w);
+            if (lane_on) *reinterpret_cast<f32x4 *>(ob + (long)t * VPT * D) = r;
+        }
+        // the next block's piece was requested before these TRIPS stores: they stay in flight
+        if (b0 + 2 * VB <= b_hi) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" : : "n"(TRIPS) : "memory");
+    }
+    if (b0 < b_hi) {                                 // partial block
+        for (long b = b0 + v0; b < b_hi; b += VPT) {
+            const cw_t w = *reinterpret_cast<const cw_t *>(codes + b * N);
+            const f32x4 r = sum_rows(w);
+            if (lane_on) *reinterpret_cast<f32x4 *>(out + b * D + off) = r;
         }
     }
 }
