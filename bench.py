@@ -397,7 +397,7 @@ def main():
             dblob = qq._prepared(any_flavour=True)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            for _ in range(reps):      # untimed: a burst this short otherwise runs before the clocks have come up
+            for _ in range(4 * reps):  # untimed: a burst this short otherwise runs before the clocks have come up
                 L.mcq_decode(cc.data_ptr(), 1, n_, cc.shape[0], dblob.data_ptr(), n_, 256, d_, y.data_ptr(), st)
             e0.record()
             for _ in range(reps):
@@ -412,7 +412,7 @@ def main():
     dec_gbps = B * (N + 4 * D) / (dec_ms * 1e-3) / 1e9
     out["decode"] = {"vectors_per_s": round(B / (dec_ms * 1e-3), 1), "ms": round(dec_ms, 4),
                      "hbm_gb_per_s": round(dec_gbps, 1), "peak_gb_per_s": PEAK_HBM_GBPS, "frac": round(dec_gbps / PEAK_HBM_GBPS, 4),
-                     "note": "50 back-to-back mcq_decode launches (after 50 untimed ones), HIP events on the launch stream; algorithmic bytes = N + 4*D per vector"}
+                     "note": "50 back-to-back mcq_decode launches (after 200 untimed ones), HIP events on the launch stream; algorithmic bytes = N + 4*D per vector"}
 
     # ---- the other BASELINE shapes on one GPU (same code path; parity for them is in tests/ -m gpu)
     if world == 1:

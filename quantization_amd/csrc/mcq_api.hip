@@ -607,8 +607,8 @@ int mcq_decode(const void *codes, int code_bytes, int codes_per_row, long B, con
     // (N >= 8: with fewer rows per vector the L2 gathers of the sliced kernel measured faster; 36.9 vs 52.2 us at 8 x 256, 65,536 vectors)
     const char *lds_env = getenv("MCQ_DECODE_LDS_MIN");   // test / tuning hook, read per call
     const long lds_min_b = lds_env ? atol(lds_env) : 16384;
-    // block-staged LDS-resident kernel (k_decode_blk): packed byte codes, 8 or 16 per vector, 64-byte slices when they fit the
-    // LDS beside the two code buffers, 32-byte slices otherwise (16 x 256).  MCQ_DECODE_BLK=0: the older kernels (tuning hook)
+    // block-staged LDS-resident kernel (k_decode_blk): packed byte codes, 4, 8 or 16 per vector, 64-byte slices when they fit the
+    // LDS beside the two code buffers, 32-byte slices otherwise (16 x 256).  MCQ_DECODE_BLK=0: the other kernels (tuning hook)
     {
         const char *blk_env = getenv("MCQ_DECODE_BLK");
         const int blk_mode = blk_env ? atoi(blk_env) : 1;
@@ -616,9 +616,8 @@ int mcq_decode(const void *codes, int code_bytes, int codes_per_row, long B, con
         int lpv = 0;
         if ((size_t)N * K * 64 + cbytes <= lds_max) lpv = 4;
         else if ((size_t)N * K * 32 + cbytes <= lds_max) lpv = 2;
-        if (blk_mode == 2 && (size_t)N * K * 32 + cbytes <= lds_max) lpv = 2;      // (measurement: 32-byte slices everywhere)
         if (blk_mode != 0 && sliced_ok && rep == 1 && code_bytes == 1 && B >= lds_min_b && K >= 32 && (D & 3) == 0 && lpv != 0 &&
-            (N == 8 || N == 16) && ((reinterpret_cast<uintptr_t>(codes) & 15) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0)) {
+            (N == 4 || N == 8 || N == 16) && ((reinterpret_cast<uintptr_t>(codes) & 15) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0)) {
             const int W = 4 * lpv, ns = Dp / W, per_xcd = (ns + 7) / 8;
             int groups = 256 / (8 * per_xcd);            // one workgroup per CU
             groups = groups < 1 ? 1 : groups;
@@ -639,40 +638,12 @@ int mcq_decode(const void *codes, int code_bytes, int codes_per_row, long B, con
         }                                                                                                                   \
         hipLaunchKernelGGL((k_decode_blk<NN, LL>), dim3(g), dim3(1024), lds, st, cp, B, P.C, K, D, Dp, groups, per, out);   \
     } while (0)
-            if (N == 8) { if (lpv == 4) MCQ_DECB(8, 4); else MCQ_DECB(8, 2); }
+            if (N == 4) { if (lpv == 4) MCQ_DECB(4, 4); else MCQ_DECB(4, 2); }
+            else if (N == 8) { if (lpv == 4) MCQ_DECB(8, 4); else MCQ_DECB(8, 2); }
             else { if (lpv == 4) MCQ_DECB(16, 4); else MCQ_DECB(16, 2); }
 #undef MCQ_DECB
             hipError_t e6 = hipGetLastError();
             return e6 == hipSuccess ? 0 : (int)e6;
-        }
-    }
-    // pipelined LDS-resident kernel for packed byte codes, 8 or 16 per vector; 16 x 256 (slice too large for the LDS) as 8 + 8
-    {
-        const bool fits = (size_t)N * K * 64 <= 144 * 1024;
-        if (sliced_ok && rep == 1 && code_bytes == 1 && B >= lds_min_b && K >= 32 && (D & 3) == 0 &&
-            ((reinterpret_cast<uintptr_t>(codes) & 15) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0) &&
-            ((N == 8 && fits) || (N == 16 && (fits || (K == 256 && B >= 32768))))) {      // (8 + 8 below 32,768 vectors: sliced wins, 54 vs 57 us)
-            const int ns = Dp / 16, per_xcd = (ns + 7) / 8;
-            int groups = 256 / (8 * per_xcd);            // one workgroup per CU
-            groups = groups < 1 ? 1 : groups;
-            const unsigned g = (unsigned)(8 * per_xcd * groups);
-            const int nl = fits ? N : 8;
-            const size_t lds = (size_t)nl * K * 64;
-            const uint8_t *cp = static_cast<const uint8_t *>(codes);
-            const bool two = B > 200000;                 // vectors per lane and trip: 1, or 2 for large batches (measured)
-            const char *nt_env = getenv("MCQ_DECODE_NT");
-            const bool nt = nt_env ? atoi(nt_env) != 0 : true;
-#define MCQ_DECP(NLL, NGG, UU)                                                                                                          \
-    do {                                                                                                                                \
-        if (nt) hipLaunchKernelGGL((k_decode_hyb<NLL, NGG, UU, true>), dim3(g), dim3(1024), lds, st, cp, B, P.C, N, K, D, Dp, groups, out); \
-        else hipLaunchKernelGGL((k_decode_hyb<NLL, NGG, UU, false>), dim3(g), dim3(1024), lds, st, cp, B, P.C, N, K, D, Dp, groups, out);   \
-    } while (0)
-            if (N == 8) { if (two) MCQ_DECP(8, 0, 2); else MCQ_DECP(8, 0, 1); }
-            else if (fits) { if (two) MCQ_DECP(16, 0, 2); else MCQ_DECP(16, 0, 1); }
-            else MCQ_DECP(8, 8, 1);
-#undef MCQ_DECP
-            hipError_t e5 = hipGetLastError();
-            return e5 == hipSuccess ? 0 : (int)e5;
         }
     }
     if (sliced_ok && rep == 1 && B >= lds_min_b && (size_t)N * K * 64 <= 144 * 1024 && K >= 32 && N >= 8) {
@@ -696,13 +667,9 @@ int mcq_decode(const void *codes, int code_bytes, int codes_per_row, long B, con
         if (lpv <= 64) {
             const int vpw = 64 / lpv;
             const unsigned g = (unsigned)(((B + 4 * vpw - 1) / (4 * vpw)) * 8);
-            const char *nt_env = getenv("MCQ_DECODE_NT");
-            const bool nt = nt_env ? atoi(nt_env) != 0 : true;
 #define MCQ_DECS_LAUNCH(T, CHH, LL)                                                                              \
-    do {                                                                                                         \
-        if (nt) hipLaunchKernelGGL((k_decode_sliced<T, CHH, LL, true>), dim3(g), dim3(256), 0, st, static_cast<const T *>(codes), B, P.C, N, K, D, Dp, out); \
-        else hipLaunchKernelGGL((k_decode_sliced<T, CHH, LL, false>), dim3(g), dim3(256), 0, st, static_cast<const T *>(codes), B, P.C, N, K, D, Dp, out);   \
-    } while (0)
+    hipLaunchKernelGGL((k_decode_sliced<T, CHH, LL>), dim3(g), dim3(256), 0, st, static_cast<const T *>(codes), B, P.C, N, \
+                       K, D, Dp, out)
 #define MCQ_DECS_LPV(T, CHH)                                                                                     \
     switch (lpv) {                                                                                               \
         case 4: MCQ_DECS_LAUNCH(T, CHH, 4); break;                                                               \

@@ -477,7 +477,7 @@ __global__ void k_decode(const CodeT *__restrict__ codes, int per_row, long B, c
 // every XCD's L2 only ever holds its own slice of the codebooks (N*K*Dp/8 floats: 0.5 MB at dim 512 / 8
 // codebooks instead of 4 MB, which is the whole L2).  A wave covers 64 / LPV vectors, LPV lanes x float4
 // per vector slice; rows are added n ascending in chunks of CH gathers in flight.  Unpacked codes only.
-template <typename CodeT, int CH, int LPV, bool NT>
+template <typename CodeT, int CH, int LPV>
 __global__ void __launch_bounds__(256)
 k_decode_sliced(const CodeT *__restrict__ codes, long B, const float *__restrict__ C, int N, int K, int D, int Dp,
                 float *__restrict__ out) {
@@ -506,8 +506,7 @@ k_decode_sliced(const CodeT *__restrict__ codes, long B, const float *__restrict
     }
     float *ob = out + b * D + off;
     if (((D & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0) && off + 3 < D) {
-        if (NT) __builtin_nontemporal_store(t, reinterpret_cast<f32x4 *>(ob));
-        else *reinterpret_cast<f32x4 *>(ob) = t;
+        __builtin_nontemporal_store(t, reinterpret_cast<f32x4 *>(ob));   // streamed: keep the L2 for the codebooks (plain stores measured slower here: 22.8 vs 18.0 us at dim 256 / 4 codebooks)
     } else {
 #pragma unroll
         for (int c = 0; c < 4; ++c)
@@ -602,92 +601,8 @@ k_decode_lds(const CodeT *__restrict__ codes, long B, const float *__restrict__ 
     }
 }
 
-// Pipelined LDS-resident decode for packed byte codes (N = 8 or 16), optionally hybrid: the slice of the first NL
-// codebooks' rows sits in LDS (as in k_decode_lds), the rows of the other NGT come from the XCD's L2 as 64-byte pieces --
-// for 16 x 256 codebooks, whose slice (256 KB) does not fit the LDS: 8 + 8 (194 vs 219 us for the sliced kernel at dim 1024,
-// 65,536 vectors).  Sums in the same order (n ascending: the LDS rows first, the gathered ones after them).  Three trips are
-// in flight per lane: the codes of the vectors two trips ahead, the gathered rows of the next trip, the sums of this one.
-// With NGT = 0 and one vector per lane and trip (UNR = 1) this is the fastest decode of 8 x 256 at 65,536 vectors: 30.7-31.9 us
-// against 36.9-40 us for k_decode_lds (whose codes are requested one trip ahead, four vectors at a time) -- the time of a
-// plain fill of the same 134 MB (29 us); larger batches prefer UNR = 2 (681 vs 729 us at 1,048,576 vectors) and settle at
-// 3.0-3.2 TB/s, bound by the LDS bank conflicts of random 64-byte rows and the 64-byte output pieces.
-template <int NL, int NGT, int UNR, bool NT>
-__global__ void __launch_bounds__(1024)
-k_decode_hyb(const uint8_t *__restrict__ codes, long B, const float *__restrict__ C, int N, int K, int D, int Dp,
-             int groups /* workgroups per slice */, float *__restrict__ out) {
-    constexpr int W = 16, LPV = W / 4;
-    constexpr int NGMAX = NGT > 0 ? NGT : 1;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    f32x4 *rows = reinterpret_cast<f32x4 *>(smem);            // [NL*K][LPV]
-    const int ns = Dp / W;
-    const int xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
-    const int per_xcd = (ns + 7) / 8;
-    const int slice = xcd * per_xcd + within % per_xcd;
-    const int grp = within / per_xcd;
-    if (slice >= ns) return;
-    const int tid = threadIdx.x;
-    for (int u = tid; u < NL * K * LPV; u += blockDim.x)
-        rows[u] = *reinterpret_cast<const f32x4 *>(C + (long)(u / LPV) * Dp + slice * W + 4 * (u % LPV));
-    __syncthreads();
-    const long per = (B + groups - 1) / groups;
-    const long b_lo = grp * per, b_hi = (b_lo + per < B) ? b_lo + per : B;
-    if (b_lo >= b_hi) return;
-    const int q = tid % LPV;
-    const int off = slice * W + 4 * q;
-    const long stride = blockDim.x / LPV;
-    const int NG = N - NL;
-    const float *Cg = C + off;
-    auto fetch = [&](long b, unsigned long long (&w)[2]) {
-        const long bc = b < b_hi ? b : b_hi - 1;
-        const unsigned long long *p = reinterpret_cast<const unsigned long long *>(codes + bc * N);
-        w[0] = p[0];
-        w[1] = (N == 16) ? p[1] : 0ull;
-    };
-    auto code_of = [&](const unsigned long long (&w)[2], int n) { return (int)((w[n >> 3] >> (8 * (n & 7))) & 0xffull) & (K - 1); };
-    static_assert(NL + NGT == 8 || NL + NGT == 16, "packed codes: 8 or 16 per vector");
-    auto gather = [&](const unsigned long long (&w)[2], f32x4 (&g)[NGMAX]) {
-#pragma unroll
-        for (int j = 0; j < NGMAX; ++j)
-            if (j < NG) g[j] = *reinterpret_cast<const f32x4 *>(Cg + ((long)(NL + j) * K + code_of(w, NL + j)) * Dp);
-    };
-    unsigned long long c0[UNR][2], c1[UNR][2], c2[UNR][2];      // codes of this trip, the next, the one after
-    f32x4 g0[UNR][NGMAX], g1[UNR][NGMAX];                        // gathered rows of this trip, the next
-    long b = b_lo + tid / LPV;
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) { fetch(b + u * stride, c0[u]); fetch(b + (UNR + u) * stride, c1[u]); }
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) gather(c0[u], g0[u]);
-    for (; b < b_hi; b += UNR * stride) {
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) fetch(b + (2 * UNR + u) * stride, c2[u]);
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) gather(c1[u], g1[u]);
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            f32x4 t = rows[code_of(c0[u], 0) * LPV + q];
-#pragma unroll
-            for (int n = 1; n < NL; ++n) t = t + rows[(n * K + code_of(c0[u], n)) * LPV + q];
-#pragma unroll
-            for (int j = 0; j < NGMAX; ++j)
-                if (j < NG) t = t + g0[u][j];
-            const long bb = b + u * stride;
-            if (bb < b_hi && off < D) {                          // (D % 4 == 0; the last slice may reach into the padding)
-                if (NT) __builtin_nontemporal_store(t, reinterpret_cast<f32x4 *>(out + bb * D + off));
-                else *reinterpret_cast<f32x4 *>(out + bb * D + off) = t;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            c0[u][0] = c1[u][0]; c0[u][1] = c1[u][1];
-            c1[u][0] = c2[u][0]; c1[u][1] = c2[u][1];
-#pragma unroll
-            for (int j = 0; j < NGMAX; ++j) g0[u][j] = g1[u][j];
-        }
-    }
-}
-
-// Block-staged LDS-resident decode for packed byte codes (N = 8 or 16 per vector) whose row slices fit the LDS.
-// What bounded k_decode_hyb was not the gather-sums (23 us at dim 512 / 8 x 256 / 65,536 vectors with the stores removed) nor
+// Block-staged LDS-resident decode for packed byte codes (N = 4, 8 or 16 per vector) whose row slices fit the LDS.
+// What bounded its predecessor (a per-lane software pipeline: codes two trips ahead in registers) was not the gather-sums (23 us at dim 512 / 8 x 256 / 65,536 vectors with the stores removed) nor
 // the write pattern (tools/micro/write_patterns.hip: the same 64-byte pieces written with PLAIN stores leave the chip at
 // the rate of a contiguous fill, 21 us; nontemporal ones take 34 us) but the wait between them: on gfx9 loads and stores
 // share one in-order counter (vmcnt), so waiting for the codes of a later trip also waits for every store issued before
@@ -703,13 +618,13 @@ template <int N, int LPV>
 __global__ void __launch_bounds__(1024)
 k_decode_blk(const uint8_t *__restrict__ codes, long B, const float *__restrict__ C, int K, int D, int Dp,
              int groups /* workgroups per slice */, long per /* vectors per workgroup, a multiple of 256 */, float *__restrict__ out) {
-    static_assert(N == 8 || N == 16, "packed codes: 8 or 16 per vector");
+    static_assert(N == 4 || N == 8 || N == 16, "packed codes: 4, 8 or 16 per vector");
     constexpr int W = 4 * LPV;
     constexpr int VPT = 1024 / LPV;                 // vectors per trip
     constexpr int VB = 1024 * 16 / N;               // vectors per block: 16 bytes of codes per thread
     constexpr int TRIPS = VB / VPT;
     static_assert(TRIPS >= 1 && TRIPS < 32, "");
-    typedef unsigned cw_t __attribute__((ext_vector_type(N / 4)));      // the N code bytes of a vector
+    struct __attribute__((aligned(N))) cw_t { unsigned w[N / 4]; __device__ unsigned operator[](int i) const { return w[i]; } };      // the N code bytes of a vector
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4 *rows = reinterpret_cast<f32x4 *>(smem);                     // [N*K][LPV]
     char *cbuf = smem + (size_t)N * K * W * 4;                         // 2 x 16 KB of codes

@@ -420,9 +420,9 @@ def test_decode_of_big_batches_takes_the_xcd_sliced_kernel_and_stays_bit_exact(D
     got64 = q.decode(torch.from_numpy(codes).cuda())
     assert np.array_equal(got8.cpu().numpy().view(np.uint32), want.view(np.uint32))
     assert torch.equal(got8, got64)
-    # the LDS-resident kernels of large batches (threshold lowered through its test hook): the pipelined one for packed byte
-    # codes of 8 / 16 codebooks (8 + 8 hybrid for 16 x 256), k_decode_lds for the rest; dims whose last 16-float slice reaches
-    # into the padding must not write past a row
+    # the LDS-resident kernels of large batches (threshold lowered through its test hook): the block-staged one for packed byte
+    # codes of 4 / 8 / 16 codebooks (here only its partial-block path: 5,003 vectors), k_decode_lds for the rest; dims whose last
+    # slice reaches into the padding must not write past a row
     os.environ["MCQ_DECODE_LDS_MIN"] = "4096"
     try:
         lds8 = q.decode(torch.from_numpy(codes.astype(np.uint8)).cuda())
@@ -433,9 +433,9 @@ def test_decode_of_big_batches_takes_the_xcd_sliced_kernel_and_stays_bit_exact(D
 
 
 @pytest.mark.parametrize("D", [72, 256])
-def test_decode_hybrid_kernel_for_sixteen_big_codebooks(D):
-    """16 x 256 codebooks: the 64-byte slices of all rows (256 KB) do not fit the LDS; from 32,768 vectors mcq_decode keeps the
-    first eight codebooks' slices there and gathers the other eight rows from L2 -- same sums, n ascending"""
+def test_decode_of_sixteen_big_codebooks_uses_32_byte_slices(D):
+    """16 x 256 codebooks: the 64-byte slices of all rows (256 KB) do not fit the LDS; k_decode_blk keeps 32-byte slices there
+    instead (whole code blocks and a partial one per workgroup at this size) -- same sums, n ascending"""
     state = gen.synthetic_state(33, D, 256, 16)
     q = load_quantizer(state, D, 256, 16)
     oq = OracleQuantizer.from_state_dict(state)
@@ -443,6 +443,30 @@ def test_decode_hybrid_kernel_for_sixteen_big_codebooks(D):
     codes = np.random.default_rng(6).integers(0, 256, size=(B, 16), dtype=np.uint8)
     got = q.decode(torch.from_numpy(codes).cuda()).cpu().numpy()
     assert np.array_equal(got.view(np.uint32), oq.decode(codes).view(np.uint32))
+
+
+@pytest.mark.parametrize("D,K,N,B", [(40, 64, 8, 70001), (512, 256, 8, 65536), (256, 256, 4, 140003), (36, 256, 8, 33333), (100, 128, 16, 40001),
+                                     (512, 32, 4, 16384)])
+def test_block_staged_decode_whole_and_partial_blocks(D, K, N, B):
+    """k_decode_blk (packed byte codes of 4 / 8 / 16 codebooks, >= 16,384 vectors): the codes of a block reach the LDS by LDS-DMA
+    a block ahead and the wait for them is a counted one (the block's stores stay in flight).  Batches that give a workgroup
+    several whole blocks and a partial one, ragged dims, every row against the oracle; the other kernels must agree"""
+    state = gen.synthetic_state(35, D, K, N)
+    q = load_quantizer(state, D, K, N)
+    oq = OracleQuantizer.from_state_dict(state)
+    codes = np.random.default_rng(8).integers(0, K, size=(B, N), dtype=np.uint8)
+    cd = torch.from_numpy(codes).cuda()
+    got = q.decode(cd)
+    assert np.array_equal(got.cpu().numpy().view(np.uint32), oq.decode(codes).view(np.uint32))
+    for _ in range(3):                                   # back to back into fresh buffers: no stale block of codes
+        assert torch.equal(q.decode(cd), got)
+    os.environ["MCQ_DECODE_BLK"] = "0"
+    try:
+        other = q.decode(cd)
+    finally:
+        del os.environ["MCQ_DECODE_BLK"]
+    assert torch.equal(other, got)
+    assert torch.equal(q.decode(cd[1:]), got[1:])        # codes at an odd offset: not 16-byte aligned, another kernel
 
 
 def test_derived_state_follows_fused_optimizer_steps():

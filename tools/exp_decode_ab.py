@@ -6,9 +6,9 @@ from quantization_amd import synthetic as gen
 from quantization_amd import Quantizer
 from quantization_amd._lib import lib
 L = lib()
-name, vals = (sys.argv[1].split("=") + [""])[:2] if len(sys.argv) > 1 else ("MCQ_DECODE_NT", "1,0")
+name, vals = (sys.argv[1].split("=") + [""])[:2] if len(sys.argv) > 1 else ("MCQ_DECODE_BLK", "1,0")
 vals = vals.split(",")
-for (D, K, N, B) in [(512, 256, 8, 65536), (512, 256, 8, 1048576), (256, 256, 4, 65536), (1024, 256, 16, 65536), (1024, 256, 16, 262144), (512, 256, 16, 65536), (512, 64, 8, 65536)]:
+for (D, K, N, B) in [(512, 256, 8, 65536), (512, 256, 8, 1048576), (256, 256, 4, 65536), (256, 256, 4, 1048576), (512, 256, 4, 65536), (1024, 256, 16, 65536), (1024, 256, 16, 262144), (512, 256, 16, 65536), (512, 64, 8, 65536)]:
     q = Quantizer(D, K, N)
     sd = q.state_dict()
     for k, v in gen.synthetic_state(7, D, K, N).items():
@@ -21,6 +21,7 @@ for (D, K, N, B) in [(512, 256, 8, 65536), (512, 256, 8, 1048576), (256, 256, 4,
         blob = q._prepared(any_flavour=True)
         st = torch.cuda.current_stream().cuda_stream
         res = []
+        for _ in range(300): L.mcq_decode(codes.data_ptr(), 1, N, min(B, 65536), blob.data_ptr(), N, K, D, y0.data_ptr(), st)     # clocks up
         for v in vals:
             os.environ[name] = v
             y = torch.empty_like(y0)
