@@ -260,13 +260,16 @@ def main():
     dp = None
     if dist is not None and not args.no_secondary:
         dp = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend()}
-        for tag, per_gpu in (("global_batch_4096", max(4096 // world, 64)), ("per_gpu_batch_4096", 4096)):
-            ms, nparam = trainer_leg(dev, D, N, per_gpu, 40, data_parallel=True)
-            tt = torch.tensor([ms["phase1_ms_per_step"], ms["phase2_ms_per_step"]], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dp[tag] = {"per_gpu_batch": per_gpu, "global_batch": per_gpu * world,
-                       "phase1_ms_per_step": round(float(tt[0]), 3), "phase2_ms_per_step": round(float(tt[1]), 3),
-                       "all_reduce_bytes_per_step_phase2": 4 * nparam + 4 * (N * K * 2 + 4)}
+        try:      # (a failure here must not take the headline line with it)
+            for tag, per_gpu in (("global_batch_4096", max(4096 // world, 64)), ("per_gpu_batch_4096", 4096)):
+                ms, nparam = trainer_leg(dev, D, N, per_gpu, 40, data_parallel=True)
+                tt = torch.tensor([ms["phase1_ms_per_step"], ms["phase2_ms_per_step"]], device=dev, dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dp[tag] = {"per_gpu_batch": per_gpu, "global_batch": per_gpu * world,
+                           "phase1_ms_per_step": round(float(tt[0]), 3), "phase2_ms_per_step": round(float(tt[1]), 3),
+                           "all_reduce_bytes_per_step_phase2": 4 * nparam + 4 * (N * K * 2 + 4)}
+        except Exception as e:      # noqa: BLE001
+            dp["error"] = f"{type(e).__name__}: {e}"[:300]
         dp["note"] = ("QuantizerTrainer.step, data_parallel=True: one flat gradient all-reduce (RCCL) + one small "
                       "forward all-reduce of the batch sums per step; max over ranks")
 
