@@ -116,8 +116,20 @@ k_tf_stage0(const float *__restrict__ G, const float *__restrict__ XC, const uin
     constexpr int CH = (N - 1 < 8) ? (N > 1 ? N - 1 : 1) : 8;    // row segments in flight
     __shared__ u64 sel[4][kSelectLdsU64];
     if (nact) B = *nact;
-    const int n = blockIdx.x & (N - 1);
-    const long b = (long)(blockIdx.x / N) * 4 + (threadIdx.x >> 6);
+    // workgroup -> (vector quad, codebook): id mod 8 = the XCD.  Up to 8 codebooks: n = id mod N.  More: the launch runs
+    // in N / 8 phases, phase ph covering the codebooks 8 ph .. 8 ph + 7 for every vector, so that an XCD works on ONE column
+    // segment of G at a time (4 MB at 16 x 256: with n = id mod 16 its L2 was asked to hold two)
+    int n;
+    long b;
+    if constexpr (N > 8) {
+        const unsigned per_phase = gridDim.x / (N / 8);
+        const unsigned ph = blockIdx.x / per_phase, r = blockIdx.x - ph * per_phase;
+        n = (int)(r & 7u) + 8 * (int)ph;
+        b = (long)(r >> 3) * 4 + (threadIdx.x >> 6);
+    } else {
+        n = blockIdx.x & (N - 1);
+        b = (long)(blockIdx.x / N) * 4 + (threadIdx.x >> 6);
+    }
     if (b >= B) return;
     const int lane = lane_id();
     const bool act = VPL * lane < K;
@@ -467,8 +479,11 @@ __global__ void __launch_bounds__(64)
 k_tf_pair1(const float *__restrict__ G, const uint8_t *__restrict__ idx, const float *__restrict__ E, TfLists L, long B,
            int N, int K, int keep, uint8_t *__restrict__ idx_final, const int *__restrict__ nact) {
     constexpr int VPL = KC * KC / 64;
-    __shared__ u64 scratch[kSelectLdsU64];
+    // the selection's scratch reuses the leaf tables' LDS (dead once the level-1 table sits in registers): 5.6 instead of
+    // 7.3 KB per single-wave workgroup, i.e. 29 instead of 22 waves per CU -- the kernel is bound by latency, not by bytes
+    static_assert(tf_leaf_lds_floats(KCH) * 4 >= kSelectLdsU64 * 8, "");
     __shared__ __attribute__((aligned(16))) float leaf[tf_leaf_lds_floats(KCH)];
+    u64 *scratch = reinterpret_cast<u64 *>(leaf);
     if (nact) B = *nact;
     const int Gout = N >> 2;
     const int g = (int)(blockIdx.x & (unsigned)(Gout - 1));
@@ -491,6 +506,7 @@ k_tf_pair1(const float *__restrict__ G, const uint8_t *__restrict__ idx, const f
         sv[v] = ((se + so[v]) - Eb) + 2.0f * t[v];
         sp[v] = VPL * lane + v;
     }
+    wave_lds_fence();                                   // the table reads are done before the selection writes there
     tf_finish<VPL>(sv, sp, keep, KC, scratch, L, 2, b, N, g, idx_final);
 }
 
@@ -614,8 +630,10 @@ k_tf_comb(const float *__restrict__ E, TfLists L, long B, int N, int v, int keep
     constexpr int MH = KH * KH;
     constexpr int VPL = (KC * KC / 64 <= 16) ? KC * KC / 64 : 16;
     constexpr int CHUNKS = KC * KC / (64 * VPL);
-    __shared__ u64 scratch[kSelectLdsU64];
-    __shared__ __attribute__((aligned(16))) float th[4 * MH];
+    // (the selection's scratch reuses the tables' LDS: see k_tf_pair1)
+    constexpr int LDSF = (4 * MH * 4 >= kSelectLdsU64 * 8) ? 4 * MH : kSelectLdsU64 * 2;
+    __shared__ __attribute__((aligned(16))) float th[LDSF];
+    u64 *scratch = reinterpret_cast<u64 *>(th);
     if (nact) B = *nact;
     const int Gout = N >> (v + 1);
     const int h = (int)(blockIdx.x & (unsigned)(Gout - 1));
@@ -640,6 +658,7 @@ k_tf_comb(const float *__restrict__ E, TfLists L, long B, int N, int v, int keep
             sv[u] = ((se + Sy[j0 + u]) - Eb) + 2.0f * t[u];
             sp[u] = VPL * lane + u;
         }
+        wave_lds_fence();
         tf_finish<VPL>(sv, sp, keep, KC, scratch, L, v + 1, b, N, h, idx_final);
     } else {
         float bv = INFINITY;
