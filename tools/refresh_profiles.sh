@@ -1,0 +1,14 @@
+#!/bin/bash
+# copy the summaries of one tools/final_profiles.sh run (gpurun_out/<dir>) into profiles/ as the round's set
+# usage: tools/refresh_profiles.sh gpurun_out/final_r02 [r02]
+set -eu
+S=$1; R=${2:-r02}; P=$(dirname $0)/../profiles
+tail -1 $S/bench.json > $P/${R}_bench.json
+tail -1 $S/bench_under_rocprof.json > $P/${R}_bench_under_rocprof.json
+tail -1 $S/bench_dp2.json > $P/${R}_bench_dp2_dryrun.json
+cp $(ls $S/kt/*/*kernel_stats.csv | head -1) $P/${R}_kernel_stats.csv
+cp $(ls $S/tr1/*/*kernel_stats.csv | head -1) $P/${R}_trainer_phase1_kernel_stats.csv
+cp $(ls $S/tr2/*/*kernel_stats.csv | head -1) $P/${R}_trainer_phase2_kernel_stats.csv
+python $(dirname $0)/pmc_table.py $S/pmc > $P/${R}_pmc_counters.txt
+python $(dirname $0)/pmc_traffic.py $S/pmc > $P/${R}_pmc_traffic.json
+ls -la $P | grep ${R}_
