@@ -270,7 +270,8 @@ def main():
                            "all_reduce_bytes_per_step_phase2": 4 * nparam + 4 * (N * K * 2 + 4)}
         except Exception as e:      # noqa: BLE001
             dp["error"] = f"{type(e).__name__}: {e}"[:300]
-        dp["note"] = ("QuantizerTrainer.step, data_parallel=True: one flat gradient all-reduce (RCCL) + one small "
+        dp["note"] = ("QuantizerTrainer.step, data_parallel=True: the flat gradient bucket all-reduced (RCCL) in two parts -- "
+                      "the centers' gradient while the classifier's backward still runs, the rest after it -- + one small "
                       "forward all-reduce of the batch sums per step; max over ranks")
 
     if rank != 0:

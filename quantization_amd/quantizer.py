@@ -578,7 +578,7 @@ def _loss_forward_kernels(module, x, iters, blob, lscale_exp, flags, prob_sum=No
 
 
 def _loss_backward_kernels(module, st_: _LossState, g_num, g_chosen, g_prob, centers, centers_scale, bias, logits_scale,
-                           out=None, scales=None):
+                           out=None, scales=None, after_centers=None):
     """Gradients of  g_num * sum err^2 + g_chosen * sum chosen + <g_prob, prob_sum>  w.r.t. (centers, centers_scale,
     to_logits.weight, to_logits.bias, logits_scale); g_* are device tensors (or None).  Derivation:
       d sum err^2 / d(scaled centers) = 2 * scatter-add of err  (mcq_decode_backward_u8_ex: rows scaled by
@@ -587,7 +587,9 @@ def _loss_backward_kernels(module, st_: _LossState, g_num, g_chosen, g_prob, cen
       d logits_scale = speed * <G, logits - b>  (per-wave partials of mcq_loss_bwd_ex),  G = d/d logits;
       mcq_grad_tail reduces the two partial arrays in a fixed order.
     `out`: optional dict name -> preallocated tensor (the trainer's flat gradient bucket); `scales`: optional device
-    float[2] {exp(speed*centers_scale), exp(speed*logits_scale)} (the trainer's prepared state holds it)."""
+    float[2] {exp(speed*centers_scale), exp(speed*logits_scale)} (the trainer's prepared state holds it);
+    `after_centers`: optional callable, invoked once the centers' gradient is enqueued and before the classifier's
+    kernels (the data-parallel trainer starts that bucket's all-reduce there, so it overlaps the rest of the backward)."""
     L = _lib.lib()
     N, K, D = centers.shape
     B, dev = st_.xf.shape[0], st_.xf.device
@@ -619,6 +621,8 @@ def _loss_backward_kernels(module, st_: _LossState, g_num, g_chosen, g_prob, cen
             _lib.check(L.mcq_decode_backward_u8_ex(st_.err.data_ptr(), codes.data_ptr(), B, N, K, D, g_centers.data_ptr(),
                                                    scales.data_ptr(), gn.data_ptr(), 2.0, cw.data_ptr(), part_c.data_ptr(), st),
                        "mcq_decode_backward_u8_ex")
+            if after_centers is not None:
+                after_centers(g_centers)
         if g_chosen is not None or g_prob is not None:
             g_weight, g_bias, g_lscale = buf("to_logits.weight", (N * K, D)), buf("to_logits.bias", (N * K,)), buf("logits_scale", ())
             gc = (g_chosen if g_chosen is not None else torch.zeros((), **f32)).detach().to(torch.float32).reshape(1).contiguous()

@@ -72,6 +72,8 @@ class QuantizerTrainer(object):
         self.start_time = time.time()
         self.process_group = process_group
         self.data_parallel = data_parallel or process_group is not None
+        self.overlap_all_reduce = os.environ.get("MCQ_TRAINER_OVERLAP", "1") != "0"    # tuning hook: one collective per step
+        self._pending = None
         if self.data_parallel:
             self._broadcast_parameters()
         self._init_optimizer()
@@ -149,9 +151,15 @@ class QuantizerTrainer(object):
             tot_loss = reconstruction_loss + logprob_loss + logits_entropy_loss * self.entropy_scale   # quantization.py:682-683
             tot_loss.backward()
         if self._world() > 1:
-            if self._flat is not None:      # one collective on the bucket the gradients already live in
+            if self._flat is not None:      # collectives on the bucket the gradients already live in
                 dist = self._dist()
-                dist.all_reduce(self._flat[1], op=dist.ReduceOp.SUM, group=self.process_group)
+                pending, self._pending = self._pending, None
+                if pending is not None:     # the centers' part went out during the backward (see _fused_loss_and_grads)
+                    work, n_done = pending
+                    dist.all_reduce(self._flat[1][n_done:], op=dist.ReduceOp.SUM, group=self.process_group)
+                    work.wait()
+                else:
+                    dist.all_reduce(self._flat[1], op=dist.ReduceOp.SUM, group=self.process_group)
             else:
                 self._all_reduce_flat([p.grad for p in self.quantizer.parameters()])
         self.optim.step()
@@ -194,10 +202,21 @@ class QuantizerTrainer(object):
             names = ("centers", "centers_scale", "to_logits.weight", "to_logits.bias", "logits_scale")
             params = (q.centers, q.centers_scale, q.to_logits.weight, q.to_logits.bias, q.logits_scale)
             views = None
+            hook = None
             if self._flat is not None:
                 views = {n_: p_.grad for n_, p_ in zip(names, params)}
+                if self._world() > 1 and self.overlap_all_reduce:
+                    # two gradient buckets: the centers' (first in the flat bucket, complete after the scatter kernel) is
+                    # all-reduced while the classifier's backward (softmax backward, weight-gradient GEMM) still runs
+                    def hook(g_centers):
+                        assert g_centers.data_ptr() == self._flat[1].data_ptr()
+                        dist = self._dist()
+                        n = self._flat_offs[1]
+                        self._pending = (dist.all_reduce(self._flat[1][:n], op=dist.ReduceOp.SUM, group=self.process_group,
+                                                         async_op=True), n)
             grads = _loss_backward_kernels(q, st_, out[4], out[5], out[6:].view(N, K), q.centers, q.centers_scale,
-                                           q.to_logits.bias, q.logits_scale, out=views, scales=getattr(q, "_scales_dev", None))
+                                           q.to_logits.bias, q.logits_scale, out=views, scales=getattr(q, "_scales_dev", None),
+                                           after_centers=hook)
             if views is None:
                 for p_, g_ in zip(params, grads):
                     p_.grad = g_.reshape(p_.shape)
@@ -258,6 +277,8 @@ class QuantizerTrainer(object):
                 p.data = v
                 p.grad = flat_g[o:o + p.numel()].view(p.shape)
         self.quantizer.invalidate_cache()
+        self._flat_offs = offs + [off]
+        assert ps[0] is self.quantizer.centers and offs[0] == 0
         return flat_p, flat_g
 
     def _init_optimizer(self):
