@@ -447,6 +447,54 @@ __device__ __forceinline__ void tf_table1(const float *__restrict__ G, const uin
                    leaf[3 * LS + ri1 * 16 + rj1];
         }
         return;
+    } else if constexpr (KCH * KCH == 64) {
+        // lists of 8 (16-entry codebooks): a leaf table is one core entry and one border entry per lane.  The four tables
+        // move together -- all list / index bytes in one batch, all eight Gram reads in a second one -- instead of four
+        // tf_leaf calls in a row (eight dependent round trips: this path is the trainer's first phase)
+        const int NK = N * K;
+        const int i = lane / KCH, j = lane % KCH;
+        const int bl = lane < 2 * KCH ? lane : 2 * KCH;
+        int cbk[4] = {2 * X, 2 * X + 1, 2 * Y, 2 * Y + 1};
+        int e_row[2], e_col[2], e_brd[4], oldq[4];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            e_row[a] = L.ent[(b * N + cbk[a]) * KCH + i];
+            e_col[a] = L.ent[(b * N + cbk[2 + a]) * KCH + j];
+        }
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            oldq[q4] = id[cbk[q4]];
+            // border entry of this lane in a table whose row codebook is cbk[a] / column codebook cbk[2 + c]: lanes [0, KCH)
+            // need ent of the ROW codebook at position lane, lanes [KCH, 2 KCH) ent of the COLUMN codebook at lane - KCH
+            e_brd[q4] = L.ent[(b * N + cbk[q4]) * KCH + (q4 < 2 ? (bl < KCH ? bl : 0) : (bl >= KCH && bl < 2 * KCH ? bl - KCH : 0))];
+        }
+        asm volatile("" : "+v"(e_row[0]), "+v"(e_row[1]), "+v"(e_col[0]), "+v"(e_col[1]));
+        asm volatile("" : "+v"(e_brd[0]), "+v"(e_brd[1]), "+v"(e_brd[2]), "+v"(e_brd[3]));
+        float g[4], bv[4];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const uint32_t rown = (uint32_t)(cbk[a] * K), colm = (uint32_t)(cbk[2 + c] * K);
+                g[a * 2 + c] = G[(rown + (uint32_t)e_row[a]) * (uint32_t)NK + colm + (uint32_t)e_col[c]];
+                const uint32_t br = bl < KCH ? rown + (uint32_t)e_brd[a] : rown + (uint32_t)oldq[a];
+                const uint32_t bc = (bl >= KCH && bl < 2 * KCH) ? colm + (uint32_t)e_brd[2 + c] : colm + (uint32_t)oldq[2 + c];
+                bv[a * 2 + c] = G[br * (uint32_t)NK + bc];
+            }
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb) {
+            const float u = shfl_f(bv[tb], i), w = shfl_f(bv[tb], 2 * KCH), vj = shfl_f(bv[tb], KCH + j);
+            leaf[tb * MH + lane] = ((g[tb] - u) - vj) + w;          // the expression of tf_leaf
+        }
+        wave_lds_fence();
+        const int ii = (VPL * lane) / KC, j0 = (VPL * lane) % KC;
+        const int i0 = px[2 * ii], i1 = px[2 * ii + 1];
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+            const int jj0 = py[2 * (j0 + v)], jj1 = py[2 * (j0 + v) + 1];
+            t[v] = ((leaf[i0 * KCH + jj0] + leaf[MH + i0 * KCH + jj1]) + leaf[2 * MH + i1 * KCH + jj0]) +
+                   leaf[3 * MH + i1 * KCH + jj1];
+        }
     } else {
 #pragma unroll
         for (int a = 0; a < 2; ++a)
