@@ -264,6 +264,18 @@ int launch_tf_stage0_k(int N, const float *G, const float *XC, const uint8_t *id
 
 int launch_tf_stage0(int K, int N, const float *G, const float *XC, const uint8_t *idx, const float *R, const float *Q,
                      long B, int keep, uint8_t *ent, float *S, uint8_t *fin, const int *nact, const int *map, hipStream_t st) {
+    if (K == 16 && N >= 4 && keep <= 16) {       // four codebooks per wave, rank-in-row selection
+        const dim3 grid((unsigned)((B * (N / 4) + 3) / 4)), block(256);
+#define MCQ_S16_CASE(NN) \
+    case NN: hipLaunchKernelGGL((k_tf_stage0_k16<NN>), grid, block, 0, st, G, XC, idx, R, Q, B, keep, ent, S, nact, map); break;
+        switch (N) {
+            MCQ_S16_CASE(4) MCQ_S16_CASE(8) MCQ_S16_CASE(16) MCQ_S16_CASE(32) MCQ_S16_CASE(64)
+            default: return MCQ_EUNSUPPORTED;
+        }
+#undef MCQ_S16_CASE
+        MCQ_LAUNCH_CHECK();
+        return 0;
+    }
     switch (K) {
         case 16: return launch_tf_stage0_k<16>(N, G, XC, idx, R, Q, B, keep, ent, S, fin, nact, map, st);
         case 32: return launch_tf_stage0_k<32>(N, G, XC, idx, R, Q, B, keep, ent, S, fin, nact, map, st);

@@ -211,6 +211,76 @@ k_tf_stage0(const float *__restrict__ G, const float *__restrict__ XC, const uin
     }
 }
 
+// Stage 0 for 16-entry codebooks (the trainer's first phase, K = 16 inference): k_tf_stage0 gives a wave to one (vector,
+// codebook) and 16 of its 64 lanes a score; here a wave takes FOUR codebooks n0 .. n0 + 3 of a vector, lane = 16 * (n - n0) + k.
+// A row of G then serves all four (256 contiguous bytes), the own-codebook row is read and skipped (m ascending over m != n,
+// as in k_tf_stage0: same sums), and the sort-and-truncate of :470-503 is a rank within the lane's DPP row of 16: fifteen
+// row rotations of the 64-bit key (score bits || position), no scalar loop, no LDS.  Same results, bit for bit.
+template <int N>
+__global__ void __launch_bounds__(256)
+k_tf_stage0_k16(const float *__restrict__ G, const float *__restrict__ XC, const uint8_t *__restrict__ idx,
+                const float *__restrict__ R, const float *__restrict__ Q, long B, int keep,
+                uint8_t *__restrict__ ent_out, float *__restrict__ S_out, const int *__restrict__ nact,
+                const int *__restrict__ map) {
+    static_assert(N >= 4, "");
+    constexpr int K = 16, NK = N * K, NG = N / 4;
+    if (nact) B = *nact;
+    const long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long b = w / NG;
+    const int n0 = 4 * (int)(w % NG);
+    if (b >= B) return;
+    const int lane = lane_id();
+    const int n = n0 + (lane >> 4), k = lane & 15;
+    const float xcv = XC[(size_t)(map ? (long)map[b] : b) * NK + n0 * K + lane];
+    const float qv = Q[n0 * K + lane];
+    const float Rv = R[b * N + n];
+    // the vector's N index bytes through scalar loads (the vector is the same for the whole wave)
+    const long bu = __builtin_amdgcn_readfirstlane((int)b);
+    unsigned long long iw[N >= 8 ? N / 8 : 1];
+    if constexpr (N >= 8) {
+        const unsigned long long *ip = reinterpret_cast<const unsigned long long *>(idx) + (size_t)bu * (N / 8);
+#pragma unroll
+        for (int q8 = 0; q8 < N / 8; ++q8) iw[q8] = ip[q8];
+    } else {
+        iw[0] = (unsigned long long)reinterpret_cast<const uint32_t *>(idx)[bu];      // N == 4
+    }
+    auto code = [&](int m) -> int { return (int)((iw[m >> 3] >> (8 * (m & 7))) & 0xffull) & (K - 1); };
+    constexpr int CH = N < 8 ? N : 8;                 // rows in flight
+    float t = 0.f;
+    bool started = false;
+#pragma unroll
+    for (int m0 = 0; m0 < N; m0 += CH) {
+        float gv[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) gv[u] = G[(size_t)((m0 + u) * K + code(m0 + u)) * NK + n0 * K + lane];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const bool use = (m0 + u) != n;
+            const float sum = t + gv[u];
+            t = use ? (started ? sum : gv[u]) : t;
+            started = started || use;
+        }
+    }
+    const float X = t - xcv;
+    const float sv = (Rv + qv) + 2.0f * X;
+    // rank of (sv, k) among the 16 keys of this lane's row
+    const uint32_t hi = ord32(sv), lo = (uint32_t)k;
+    const u64 key = ((u64)hi << 32) | lo;
+    int rnk = 0;
+#define MCQ_ROR(r)                                                                                                      \
+    {                                                                                                                   \
+        const u64 o = ((u64)(uint32_t)dpp_i<0x120 + r>((int)hi) << 32) | (uint32_t)dpp_i<0x120 + r>((int)lo);           \
+        rnk += (o < key) ? 1 : 0;                                                                                       \
+    }
+    MCQ_ROR(1) MCQ_ROR(2) MCQ_ROR(3) MCQ_ROR(4) MCQ_ROR(5) MCQ_ROR(6) MCQ_ROR(7) MCQ_ROR(8)
+    MCQ_ROR(9) MCQ_ROR(10) MCQ_ROR(11) MCQ_ROR(12) MCQ_ROR(13) MCQ_ROR(14) MCQ_ROR(15)
+#undef MCQ_ROR
+    if (rnk < keep) {
+        ent_out[(b * N + n) * keep + rnk] = (uint8_t)k;
+        S_out[(b * N + n) * keep + rnk] = sv;
+    }
+}
+
 // ---------------------------------------------------------------- leaf table
 // D[n][m] (codebooks n < m) over the two level-0 lists of KC entries: lane holds positions p = VPL*lane + v
 // (row i = p / KC, column j = p % KC).  KC*KC core reads plus one read per lane for the 2*KC + 1 border values

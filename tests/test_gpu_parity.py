@@ -128,6 +128,20 @@ def test_exact_ties_and_degenerate_inputs():
     got = q.encode(torch.from_numpy(x).cuda(), 3, as_bytes=False).cpu().numpy()
     assert np.array_equal(got, o.compute_indexes(x, 3))
     assert (got < 16).all()
+    # the same with 16-entry codebooks (k_tf_stage0_k16: four codebooks per wave, the truncation is a rank within a DPP row)
+    for N16 in (4, 8, 16):
+        sd = gen.synthetic_state(6, 24, 16, N16)
+        sd["centers"][:, 8:] = sd["centers"][:, :8]
+        w = sd["to_logits.weight"].reshape(N16, 16, 24)
+        w[:, 8:] = w[:, :8]
+        sd["to_logits.weight"] = w.reshape(N16 * 16, 24)
+        sd["to_logits.bias"].reshape(N16, 16)[:, 8:] = sd["to_logits.bias"].reshape(N16, 16)[:, :8]
+        q = load_quantizer(sd, 24, 16, N16)
+        o = oracle_of(sd)
+        x = gen.make_gaussian(4, 333, 24)
+        got = q.encode(torch.from_numpy(x).cuda(), 3, as_bytes=False).cpu().numpy()
+        assert np.array_equal(got, o.compute_indexes(x, 3))
+        assert (got < 8).all()
 
 
 def test_full_size_properties_config_b():
