@@ -99,13 +99,18 @@ def load_quantizer(state, D, K, N, dev):
 
 
 def timed(fn, reps):
+    """seconds per call for the SECONDARY figures: median of `reps` individually synchronised calls after one untimed call
+    (one host hiccup inside a three-call average once reported dim 256 / 4 codebooks at a fifth of its rate)"""
     fn()
     torch.cuda.synchronize()
-    t = time.perf_counter()
-    for _ in range(reps):
+    ts = []
+    for _ in range(max(reps, 3)):
+        t = time.perf_counter()
         fn()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t) / reps
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t)
+    ts.sort()
+    return ts[len(ts) // 2]
 
 
 def cpu_baseline(state, D, budget_s=12.0):
