@@ -484,11 +484,20 @@ int run_encode(const float *x, long B, const void *prepared, float lscale, int N
     return 0;
 }
 
-// floats per lane of k_decode_backward: 4 (float4 loads) when every row involved is 16-byte aligned
-int db_cw(const void *g, const void *out, int D, long gsb, long gsn, const void *dotw = nullptr) {
+// floats per lane of k_decode_backward when every row involved is 16-byte aligned.  Codebooks of 64 entries and more: 4 (a
+// row has few matching vectors, the kernel is bound by scanning the index column, so as few waves per row as possible:
+// 22.5 us with 4, 28.3 with 2, 41.4 with 1 at 8 x 256, dim 512, 4,096 vectors).  Smaller codebooks: the widest of 4, 2, 1
+// that leaves four feature chunks (a row gathers many vectors; more, narrower waves and an L2 that holds a quarter of the
+// gradient matrix: 35.5 us with 4, 28.7 with 2, 30.2 with 1 at 16 x 16).  1 for unaligned rows.
+int db_cw_of(int D, int K) {
+    if ((D & 3) != 0) return 1;
+    if (K >= 64) return 4;
+    return D >= 1024 ? 4 : (D >= 512 ? 2 : 1);
+}
+int db_cw(const void *g, const void *out, int D, int K, long gsb, long gsn, const void *dotw = nullptr) {
     const bool al = ((D & 3) == 0) && ((gsb & 3) == 0) && ((gsn & 3) == 0) && ((reinterpret_cast<uintptr_t>(g) & 15) == 0) &&
                     ((reinterpret_cast<uintptr_t>(out) & 15) == 0) && ((reinterpret_cast<uintptr_t>(dotw) & 15) == 0);
-    return al ? 4 : 1;
+    return al ? db_cw_of(D, K) : 1;
 }
 int db_chunks(int D, int cw) { return (D + 64 * cw - 1) / (64 * cw); }
 
@@ -496,10 +505,14 @@ template <typename IdxT>
 int launch_decode_backward(const float *g, const IdxT *idx, long B, int N, int K, int D, float *out, long gsb, long gsn,
                            int idx_stride, hipStream_t st, const float *sa = nullptr, const float *sb = nullptr, float sc = 1.0f,
                            const float *dotw = nullptr, float *dot_part = nullptr) {
-    const int cw = db_cw(g, out, D, gsb, gsn, dotw), chunks = db_chunks(D, cw);
-    const long waves = (long)N * K * chunks;
-    const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+    const int cw = db_cw(g, out, D, K, gsb, gsn, dotw), chunks = db_chunks(D, cw);
+    const long rowgroups = ((long)N * K + 3) / 4;
+    long blocks;
+    if (chunks <= 8 && (8 % chunks) == 0) blocks = ((rowgroups + (8 / chunks) - 1) / (8 / chunks)) * 8;
+    else blocks = ((long)N * K * chunks + 3) / 4;
+    const dim3 grid((unsigned)blocks), block(256);
     if (cw == 4) hipLaunchKernelGGL((k_decode_backward<IdxT, 4>), grid, block, 0, st, g, idx, B, N, K, D, chunks, out, gsb, gsn, idx_stride, sa, sb, sc, dotw, dot_part);
+    else if (cw == 2) hipLaunchKernelGGL((k_decode_backward<IdxT, 2>), grid, block, 0, st, g, idx, B, N, K, D, chunks, out, gsb, gsn, idx_stride, sa, sb, sc, dotw, dot_part);
     else hipLaunchKernelGGL((k_decode_backward<IdxT, 1>), grid, block, 0, st, g, idx, B, N, K, D, chunks, out, gsb, gsn, idx_stride, sa, sb, sc, dotw, dot_part);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
@@ -996,7 +1009,7 @@ int mcq_scales_exp(const float *centers_scale, const float *logits_scale, float 
 
 // decode_backward_u8 with the trainer's epilogue: rows scaled by sa[0]*sb[0]*sc (device floats), and per-wave partials
 // of <unscaled sums, dotw> in dot_part[mcq_decode_backward_waves(N, K, D)]
-long mcq_decode_backward_waves(int N, int K, int D) { return (long)N * K * db_chunks(D, (D & 3) == 0 ? 4 : 1); }
+long mcq_decode_backward_waves(int N, int K, int D) { return (long)N * K * db_chunks(D, db_cw_of(D, K)); }
 
 int mcq_decode_backward_u8_ex(const float *grad_out, const uint8_t *codes, long B, int N, int K, int D, float *gC,
                               const float *sa, const float *sb, float sc, const float *dotw, float *dot_part, void *stream) {
@@ -1004,7 +1017,7 @@ int mcq_decode_backward_u8_ex(const float *grad_out, const uint8_t *codes, long 
     if (B > 0 && (!grad_out || !codes)) return MCQ_EINVAL;
     if ((dotw == nullptr) != (dot_part == nullptr)) return MCQ_EINVAL;
     // the caller sized dot_part by mcq_decode_backward_waves: the wide kernel must be the one that runs when D % 4 == 0
-    if ((D & 3) == 0 && db_cw(grad_out, gC, D, D, 0, dotw) != 4) return MCQ_EINVAL;     // misaligned buffers
+    if ((D & 3) == 0 && db_cw(grad_out, gC, D, K, D, 0, dotw) != db_cw_of(D, K)) return MCQ_EINVAL;     // misaligned buffers
     const int rc = launch_decode_backward<uint8_t>(grad_out, codes, B, N, K, D, gC, (long)D, 0L, N, static_cast<hipStream_t>(stream),
                                                    sa, sb, sc, dotw, dot_part);
     if (rc) return rc;

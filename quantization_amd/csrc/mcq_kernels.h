@@ -750,11 +750,26 @@ __global__ void k_decode_backward(const float *__restrict__ gout, const IdxT *__
                                   const float *__restrict__ sa = nullptr, const float *__restrict__ sb = nullptr, float sc = 1.0f,
                                   const float *__restrict__ dotw = nullptr, float *__restrict__ dot_part = nullptr) {
     typedef float vecw __attribute__((ext_vector_type(CW)));
-    const long w = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (w >= (long)N * K * chunks) return;
+    // wave -> (row, feature chunk).  When the chunk count divides 8 a chunk belongs to 8 / chunks XCDs (workgroup id mod 8 =
+    // the XCD): every codebook reads ALL vectors' gradients once, N times in total, and with the chunks spread over all XCDs
+    // each L2 was asked to hold the whole gradient matrix (8 MB at 4,096 x 512: the kernel ran at the 3.5 TB/s of the
+    // fabric behind the L2s, time proportional to the batch); an XCD that only ever sees its own columns keeps them
+    // (1 MB at 8 chunks).  w = row * chunks + chunk stays the index of the wave's partial in dot_part.
+    long row;
+    int chunk;
+    if (chunks <= 8 && (8 % chunks) == 0) {
+        const int per = 8 / chunks, xcd = blockIdx.x & 7;
+        chunk = xcd % chunks;
+        row = ((long)(blockIdx.x >> 3) * per + xcd / chunks) * 4 + (threadIdx.x >> 6);
+    } else {
+        const long w0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+        row = w0 / chunks;
+        chunk = (int)(w0 % chunks);
+    }
+    if (row >= (long)N * K) return;
+    const long w = row * chunks + chunk;
     const int lane = lane_id();
-    const long row = w / chunks;
-    const int d = ((int)(w % chunks) * 64 + lane) * CW;       // CW > 1: D is a multiple of CW
+    const int d = (chunk * 64 + lane) * CW;       // CW > 1: D is a multiple of CW
     const bool dok = d < D;
     const int dc = dok ? d : 0;
     const int n = (int)(row / K), k = (int)(row % K);
