@@ -257,32 +257,32 @@ k_recon_fwd(const float *__restrict__ x, const int64_t *__restrict__ idx, long B
 __global__ void __launch_bounds__(256)
 k_loss_tail(const float *__restrict__ sums, const float *__restrict__ prob_sum, const float *__restrict__ count, int N,
             int K, float entropy_scale, float *__restrict__ losses, float *__restrict__ g, float *__restrict__ g_prob) {
-    __shared__ float s_a[256], s_b[256];
-    const int tid = threadIdx.x;
+    // wave w takes the codebooks w, w + 4, ...: a codebook's two entropies are 64 lane-partial sums (entries k = lane,
+    // lane + 64, ... ascending) and one xor butterfly -- no workgroup barrier inside the loop (the first version reduced
+    // each codebook through a 256-thread LDS tree, nine barriers per codebook: 17.5 us at 16 codebooks)
+    __shared__ float s_hl[64], s_hi[64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float num = sums[0], den = sums[1], chosen = sums[2], Bt = sums[3];
     const float ref = logf((float)K);
-    // thread t owns entry k = t of every codebook (K <= 256): per-codebook entropies reduce over threads
-    float h_logits = 0.f, h_index = 0.f;     // sums over n of the per-codebook entropies (thread 0)
-    for (int n = 0; n < N; ++n) {
+    const float gscale = entropy_scale / (ref * (float)N * Bt);
+    for (int n = wave; n < N; n += 4) {
         float a = 0.f, b = 0.f;
-        if (tid < K) {
-            const float p = prob_sum[n * K + tid] / Bt + 1.0e-20f;
+        for (int k = lane; k < K; k += 64) {
+            const float p = prob_sum[n * K + k] / Bt + 1.0e-20f;
             const float lp = logf(p);
-            a = p * lp;
-            g_prob[n * K + tid] = entropy_scale * (lp + 1.0f) / (ref * (float)N * Bt);
-            const float c = count[n * K + tid] / Bt + 1.0e-20f;
-            b = c * logf(c);
+            a = a + p * lp;
+            g_prob[n * K + k] = (lp + 1.0f) * gscale;
+            const float c = count[n * K + k] / Bt + 1.0e-20f;
+            b = b + c * logf(c);
         }
-        s_a[tid] = a; s_b[tid] = b;
-        __syncthreads();
-        for (int m = 128; m >= 1; m >>= 1) {
-            if (tid < m) { s_a[tid] += s_a[tid + m]; s_b[tid] += s_b[tid + m]; }
-            __syncthreads();
-        }
-        if (tid == 0) { h_logits += -s_a[0]; h_index += -s_b[0]; }
-        __syncthreads();
+        a = wave_sum_butterfly(a);
+        b = wave_sum_butterfly(b);
+        if (lane == 0) { s_hl[n] = -a; s_hi[n] = -b; }
     }
+    __syncthreads();
     if (tid == 0) {
+        float h_logits = 0.f, h_index = 0.f;     // sums over n ascending of the per-codebook entropies
+        for (int n = 0; n < N; ++n) { h_logits += s_hl[n]; h_index += s_hi[n]; }
         losses[0] = num / (den + 1.0e-20f);
         losses[1] = -chosen / (Bt * (float)N);
         losses[2] = (ref - h_logits / (float)N) / ref;

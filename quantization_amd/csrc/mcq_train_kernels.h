@@ -148,16 +148,25 @@ k_wgrad_reduce(const float *__restrict__ part, const float *__restrict__ partb, 
                const float *__restrict__ scale, float *__restrict__ gW, float *__restrict__ gb) {
     const float s = *scale;
     const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (i < MN) {       // MN is a multiple of 4 (M = N*K is a multiple of 16)
-        f32x4 t = *reinterpret_cast<const f32x4 *>(part + i);
-        for (int q = 1; q < splits; ++q) t = t + *reinterpret_cast<const f32x4 *>(part + (size_t)q * MN + i);
-        *reinterpret_cast<f32x4 *>(gW + i) = t * s;
-    }
-    if (i < M) {
-        f32x4 t = *reinterpret_cast<const f32x4 *>(partb + i);
-        for (int q = 1; q < splits; ++q) t = t + *reinterpret_cast<const f32x4 *>(partb + (size_t)q * M + i);
-        *reinterpret_cast<f32x4 *>(gb + i) = t;
-    }
+    // the partials of eight splits are requested together, then added in ascending order (a plain loop became load, wait,
+    // add per split: one memory round trip each, 16.6 us for sixteen splits)
+    auto sum_splits = [&](const float *base, size_t stride) {
+        f32x4 t = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int q0 = 0; q0 < splits; q0 += 8) {
+            f32x4 r[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int q = q0 + u < splits ? q0 + u : splits - 1;
+                r[u] = *reinterpret_cast<const f32x4 *>(base + (size_t)q * stride);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (q0 + u < splits) t = (q0 + u == 0) ? r[u] : t + r[u];
+        }
+        return t;
+    };
+    if (i < MN) *reinterpret_cast<f32x4 *>(gW + i) = sum_splits(part + i, (size_t)MN) * s;       // MN is a multiple of 4 (M = N*K is a multiple of 16)
+    if (i < M) *reinterpret_cast<f32x4 *>(gb + i) = sum_splits(partb + i, (size_t)M);
 }
 
 // --------------------------------------------------------------------- Adam
