@@ -393,6 +393,10 @@ class Quantizer(nn.Module):
             # debugging aid (synchronises): the kernels mask digits with K - 1 where the reference's gather would
             # raise on an out-of-range index (quantization.py:142)
             assert int(flat.min()) >= 0 and int(flat.max()) < K ** (N // per_row), "codes outside [0, codebook_size)"
+        if flat.dtype == torch.int64 and per_row == N and N in (4, 8, 16) and B >= 16384:
+            # unpacked int64 indexes of a large batch: as bytes they take the block-staged LDS-resident kernel (the kernels
+            # mask a digit with K - 1 either way, and K <= 256: the low byte carries the same digit)
+            flat = flat.to(torch.uint8)
         blob = self._prepared(any_flavour=True)
         with torch.cuda.device(flat.device):
             st = torch.cuda.current_stream(flat.device).cuda_stream

@@ -481,6 +481,7 @@ def test_block_staged_decode_whole_and_partial_blocks(D, K, N, B):
         del os.environ["MCQ_DECODE_BLK"]
     assert torch.equal(other, got)
     assert torch.equal(q.decode(cd[1:]), got[1:])        # codes at an odd offset: not 16-byte aligned, another kernel
+    assert torch.equal(q.decode(cd.long()), got)         # int64 indexes (what _compute_indexes returns)
 
 
 def test_derived_state_follows_fused_optimizer_steps():
