@@ -7,5 +7,6 @@ Drop-in for the hot path of danpovey/quantization (`Quantizer.encode/decode`,
 from .quantizer import Quantizer  # noqa: F401
 from .trainer import QuantizerTrainer  # noqa: F401
 from .prediction import JointCodebookLoss  # noqa: F401   (the consumer of the codes, quantization/__init__.py:4)
+from .hdf5_data import read_hdf5_data  # noqa: F401      (the data helper, quantization/__init__.py:3)
 
-__all__ = ["Quantizer", "QuantizerTrainer", "JointCodebookLoss"]
+__all__ = ["Quantizer", "QuantizerTrainer", "JointCodebookLoss", "read_hdf5_data"]

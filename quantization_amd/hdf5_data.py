@@ -1,0 +1,272 @@
+"""`read_hdf5_data` of the reference (/root/reference/quantization/quantization.py:746-820): every dataset of an HDF5
+archive -> one (tot_frames, dim) float16 matrix, rows shuffled, split into (train, valid).
+
+The reference reads the archive with h5py.  h5py is used here too when it is importable; when it is not (the MI355X image
+ships without it) the archive is read by the small pure-Python reader below, which understands what
+`h5py.File(name, 'w').create_dataset(key, data=x)` writes (the layout of the reference's test_write_hdf5.py:25-31):
+superblock version 0 or 1, old-style groups (symbol-table B-tree + local heap), version-1 object headers, fixed- and
+floating-point little/big-endian element types, contiguous / compact / chunked-without-filters storage.  Anything else
+(compression filters, new-style groups, superblock >= 2) raises with a message that says so.
+
+Deviation, documented: the reference slices with `valid_frames = 0.05 * tot_frames`, a float, and therefore raises a
+TypeError for archives of <= 200,000 frames (:812-820; only above that does the cap of 10,000 make it an int).  Here the
+count is int(...) of the same expression, so small archives work; for archives the reference can read the split is
+identical (same order of datasets, same np.random.shuffle call on the same matrix).
+"""
+import logging
+import struct
+from typing import Dict, List, Tuple
+
+import numpy as np
+import torch
+
+_SIG = b"\x89HDF\r\n\x1a\n"
+_UNDEF = 0xFFFFFFFFFFFFFFFF
+
+
+class Hdf5FormatError(RuntimeError):
+    pass
+
+
+class MiniHdf5File:
+    """Read-only view of the datasets of the ROOT group of an HDF5 file (see the module docstring for the subset)."""
+
+    def __init__(self, filename: str):
+        with open(filename, "rb") as f:
+            self.buf = f.read()
+        b = self.buf
+        base = -1
+        off = 0
+        while off + 8 <= len(b):                       # the superblock may sit at 0, 512, 1024, ...
+            if b[off:off + 8] == _SIG:
+                base = off
+                break
+            off = 512 if off == 0 else off * 2
+        if base < 0:
+            raise Hdf5FormatError(f"{filename}: not an HDF5 file (no superblock signature)")
+        ver = b[base + 8]
+        if ver > 1:
+            raise Hdf5FormatError(f"{filename}: superblock version {ver} (written with libver='latest'?) is not supported "
+                                  "by the built-in reader; install h5py")
+        self.O, self.L = b[base + 13], b[base + 14]
+        if self.O not in (4, 8) or self.L not in (4, 8):
+            raise Hdf5FormatError("unsupported offset / length size")
+        p = base + 24 + (4 if ver == 1 else 0)
+        self.base_addr = self._off(p)
+        p += 4 * self.O                                 # base, free-space, end-of-file, driver-info addresses
+        # root group symbol table entry
+        self.root_header = self._off(p + self.O)
+        self._datasets = None
+
+    # ---- primitive reads
+    def _off(self, p: int) -> int:
+        return int.from_bytes(self.buf[p:p + self.O], "little")
+
+    def _len(self, p: int) -> int:
+        return int.from_bytes(self.buf[p:p + self.L], "little")
+
+    def _addr(self, a: int) -> int:
+        return a + self.base_addr
+
+    # ---- object headers (version 1)
+    def _messages(self, addr: int) -> List[Tuple[int, int, int]]:
+        """[(type, data offset, size)] of the object header at file address `addr`, continuation blocks included."""
+        b, p = self.buf, self._addr(addr)
+        if b[p:p + 4] == b"OHDR":
+            raise Hdf5FormatError("version-2 object headers (libver='latest') are not supported by the built-in reader")
+        if b[p] != 1:
+            raise Hdf5FormatError(f"object header version {b[p]} not supported")
+        nmsg = struct.unpack_from("<H", b, p + 2)[0]
+        size = struct.unpack_from("<I", b, p + 8)[0]
+        blocks = [(p + 16, size)]
+        out = []
+        while blocks and len(out) < nmsg:
+            q, n = blocks.pop(0)
+            end = q + n
+            while q + 8 <= end and len(out) < nmsg:
+                mtype, msize, _flags = struct.unpack_from("<HHB", b, q)
+                data = q + 8
+                if mtype == 0x10:                       # continuation
+                    blocks.append((self._addr(self._off(data)), self._len(data + self.O)))
+                out.append((mtype, data, msize))
+                q = data + msize
+        return out
+
+    # ---- groups (symbol table: B-tree version 1 of type 0 + local heap)
+    def _heap_data(self, addr: int) -> int:
+        p = self._addr(addr)
+        if self.buf[p:p + 4] != b"HEAP":
+            raise Hdf5FormatError("bad local heap")
+        return self._addr(self._off(p + 8 + 2 * self.L))
+
+    def _name(self, heap_data: int, off: int) -> str:
+        e = self.buf.index(b"\0", heap_data + off)
+        return self.buf[heap_data + off:e].decode("utf-8")
+
+    def _group_entries(self, btree: int, heap_data: int, out: List[Tuple[str, int]]):
+        b, p = self.buf, self._addr(btree)
+        if b[p:p + 4] == b"SNOD":
+            n = struct.unpack_from("<H", b, p + 6)[0]
+            q = p + 8
+            for _ in range(n):
+                out.append((self._name(heap_data, self._off(q)), self._off(q + self.O)))
+                q += 2 * self.O + 24
+            return
+        if b[p:p + 4] != b"TREE" or b[p + 4] != 0:
+            raise Hdf5FormatError("bad group B-tree node")
+        used = struct.unpack_from("<H", b, p + 6)[0]
+        q = p + 8 + 2 * self.O + self.L                 # past the siblings and key 0
+        for _ in range(used):
+            self._group_entries(self._off(q), heap_data, out)
+            q += self.O + self.L
+        return
+
+    def datasets(self) -> Dict[str, int]:
+        """name -> object header address of the root group's members, in the group's (name-sorted) order."""
+        if self._datasets is None:
+            sym = [m for m in self._messages(self.root_header) if m[0] == 0x11]
+            if not sym:
+                raise Hdf5FormatError("the root group is not an old-style (symbol table) group; install h5py")
+            data = sym[0][1]
+            entries: List[Tuple[str, int]] = []
+            self._group_entries(self._off(data), self._heap_data(self._off(data + self.O)), entries)
+            self._datasets = dict(entries)
+        return self._datasets
+
+    def keys(self) -> List[str]:
+        return list(self.datasets().keys())
+
+    # ---- datasets
+    def _dtype(self, p: int) -> np.dtype:
+        b = self.buf
+        cls, bits0 = b[p] & 0x0F, b[p + 1]
+        size = struct.unpack_from("<I", b, p + 4)[0]
+        order = ">" if (bits0 & 1) else "<"
+        if cls == 1:
+            kind = {2: "f2", 4: "f4", 8: "f8"}.get(size)
+        elif cls == 0:
+            kind = {1: "1", 2: "2", 4: "4", 8: "8"}.get(size)
+            kind = (("i" if (bits0 & 8) else "u") + kind) if kind else None
+        else:
+            kind = None
+        if kind is None:
+            raise Hdf5FormatError(f"element type class {cls} of {size} bytes is not supported by the built-in reader")
+        return np.dtype(order + kind if size > 1 else kind)
+
+    def read(self, name: str) -> np.ndarray:
+        b = self.buf
+        shape, dtype, layout = None, None, None
+        for mtype, data, _size in self._messages(self.datasets()[name]):
+            if mtype == 0x01:                           # dataspace
+                ver, rank = b[data], b[data + 1]
+                q = data + (8 if ver == 1 else 4)
+                shape = tuple(self._len(q + i * self.L) for i in range(rank))
+            elif mtype == 0x03:
+                dtype = self._dtype(data)
+            elif mtype == 0x08:
+                layout = data
+            elif mtype == 0x0B:
+                raise Hdf5FormatError(f"dataset {name!r} uses a filter pipeline (compression); install h5py to read it")
+        if shape is None or dtype is None or layout is None:
+            raise Hdf5FormatError(f"{name!r} is not a simple dataset")
+        count = int(np.prod(shape, dtype=np.int64)) if shape else 1
+        if b[layout] != 3:
+            raise Hdf5FormatError(f"data layout message version {b[layout]} not supported")
+        cls = b[layout + 1]
+        if cls == 1:                                    # contiguous
+            addr = self._off(layout + 2)
+            if addr == _UNDEF >> (64 - 8 * self.O):
+                return np.zeros(shape, dtype=dtype.newbyteorder("="))
+            return np.frombuffer(b, dtype=dtype, count=count, offset=self._addr(addr)).reshape(shape)
+        if cls == 0:                                    # compact
+            return np.frombuffer(b, dtype=dtype, count=count, offset=layout + 4).reshape(shape)
+        if cls == 2:                                    # chunked, no filters
+            rank1 = b[layout + 2]
+            bt = self._off(layout + 3)
+            cdims = struct.unpack_from("<%dI" % rank1, b, layout + 3 + self.O)
+            chunk = tuple(cdims[:-1])
+            if len(chunk) != len(shape) or cdims[-1] != dtype.itemsize:
+                raise Hdf5FormatError("inconsistent chunk description")
+            out = np.zeros(shape, dtype=dtype)
+            if bt != _UNDEF >> (64 - 8 * self.O):
+                self._read_chunks(bt, chunk, out)
+            return out
+        raise Hdf5FormatError(f"data layout class {cls} not supported")
+
+    def _read_chunks(self, node: int, chunk: Tuple[int, ...], out: np.ndarray):
+        b, p = self.buf, self._addr(node)
+        if b[p:p + 4] != b"TREE" or b[p + 4] != 1:
+            raise Hdf5FormatError("bad chunk B-tree node")
+        level, used = b[p + 5], struct.unpack_from("<H", b, p + 6)[0]
+        rank = len(chunk)
+        key = 8 + 8 * (rank + 1)
+        q = p + 8 + 2 * self.O
+        n = int(np.prod(chunk))
+        for _ in range(used):
+            nbytes, mask = struct.unpack_from("<II", b, q)
+            offs = struct.unpack_from("<%dQ" % rank, b, q + 8)
+            child = self._off(q + key)
+            if level > 0:
+                self._read_chunks(child, chunk, out)
+            else:
+                if mask != 0 or nbytes != n * out.dtype.itemsize:
+                    raise Hdf5FormatError("filtered chunk; install h5py to read this archive")
+                blk = np.frombuffer(b, dtype=out.dtype, count=n, offset=self._addr(child)).reshape(chunk)
+                sl = tuple(slice(o, min(o + c, s)) for o, c, s in zip(offs, chunk, out.shape))
+                out[sl] = blk[tuple(slice(0, s.stop - s.start) for s in sl)]
+            q += key + self.O
+
+
+def _open(filename: str):
+    """(keys in the archive's iteration order, shape(key), array(key)) through h5py when it is there, else MiniHdf5File."""
+    try:
+        import h5py  # noqa: F401
+    except ImportError:
+        mf = MiniHdf5File(filename)
+        cache = {}
+
+        def arr(k):
+            if k not in cache:
+                cache.clear()                           # one dataset alive at a time
+                cache[k] = mf.read(k)
+            return cache[k]
+        return mf.keys(), (lambda k: arr(k).shape), arr
+    hf = h5py.File(filename, "r")
+    return list(hf.keys()), (lambda k: hf[k].shape), (lambda k: hf[k][:])
+
+
+def read_hdf5_data(filename: str) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(train, valid): CPU float16 tensors (tot_train_frames, dim) and (tot_valid_frames, dim) with shuffled rows; valid is
+    5 % of the frames, at most 10,000.  quantization.py:746-820 (shuffle: numpy's global RNG, as there)."""
+    logging.info(f"Opening file {filename}")
+    keys, shape_of, array_of = _open(filename)
+    tot_frames, dim = 0, -1
+    for key in keys:                                                        # quantization.py:786-794
+        shape = list(shape_of(key))
+        if dim == -1:
+            dim = shape[-1]
+        else:
+            assert dim == shape[-1], "Dataset must have consistent dimension (last element of shape"
+        num_frames = 1
+        for i in shape[:-1]:
+            num_frames *= i
+        tot_frames += num_frames
+    logging.info(f"read_data: tot_frames = {tot_frames}")
+    ans = np.empty((tot_frames, dim), dtype=np.float16)
+    cur_pos = 0
+    for key in keys:                                                        # :797-803
+        array = np.ascontiguousarray(array_of(key)).reshape(-1, dim)
+        num_frames = array.shape[0]
+        ans[cur_pos:cur_pos + num_frames, :] = array
+        cur_pos += num_frames
+    assert cur_pos == tot_frames
+    np.random.shuffle(ans)                                                  # :806
+    ans_torch = torch.from_numpy(ans)
+    valid_proportion = 0.05
+    valid_frames = valid_proportion * tot_frames
+    if valid_frames > 10000:
+        valid_frames = 10000
+    valid_frames = int(valid_frames)             # (the reference slices with the float: module docstring)
+    train_frames = tot_frames - valid_frames
+    logging.info(f"read_data: train_frames={train_frames}, valid_frames={valid_frames}")
+    return ans_torch[valid_frames:tot_frames], ans_torch[:valid_frames]

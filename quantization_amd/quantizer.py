@@ -63,6 +63,12 @@ def _ensure_optimizer_hook():
         _hook_installed[0] = True
 
 
+class _PreparedState:
+    """The derived device state of one parameter version and everything that belongs to it: the scale factors it
+    was built with travel WITH the blob, so a cache hit can never pair a blob with another build's factors."""
+    __slots__ = ("key", "blob", "flavour", "stream", "event", "scales_dev", "scale_flags", "lscale_exp", "cscale_exp")
+
+
 def _is_pow2(n: int) -> bool:
     return n > 0 and (n & (n - 1)) == 0
 
@@ -107,8 +113,26 @@ class Quantizer(nn.Module):
         st["_prep"] = None
         st["_ws"] = None
         st.pop("_host_stage", None)
-        st.pop("_scales_dev", None)
         return st
+
+    # the scale factors of the CURRENT derived state (set by _prepared, dropped with it)
+    @property
+    def _scale_flags(self) -> int:
+        return self._prep.scale_flags
+
+    @property
+    def _lscale_exp(self) -> float:
+        return self._prep.lscale_exp
+
+    @property
+    def _cscale_exp(self) -> float:
+        return self._prep.cscale_exp
+
+    @property
+    def _scales_dev(self):
+        """device float[2] {exp(speed*centers_scale), exp(speed*logits_scale)} of the current derived state, or None
+        when that state was built with host-formed factors (the trainer's backward then forms them itself)."""
+        return self._prep.scales_dev if self._prep is not None else None
 
     # ------------------------------------------------------------ bookkeeping
     def load_state_dict(self, *args, **kwargs):
@@ -156,11 +180,15 @@ class Quantizer(nn.Module):
                         del _quantizer_params[k_]
                 _quantizer_params[id(p)] = weakref.ref(p)
         key = tuple((p.data_ptr(), p._version, str(p.device)) for p in ps) + (_param_epoch[0],)
-        if self._prep is not None and self._prep[0] == key and (self._prep[2] == "host" or training or any_flavour):
-            cur = torch.cuda.current_stream(self._prep[1].device)
-            if cur.cuda_stream != self._prep[3]:
-                cur.wait_event(self._prep[4])      # built (asynchronously) on another stream: order this one after it
-            return self._prep[1]
+        pr = self._prep
+        if pr is not None and pr.key == key and (pr.flavour == "host" or training or any_flavour):
+            cur = torch.cuda.current_stream(pr.blob.device)
+            if cur.cuda_stream != pr.stream:
+                cur.wait_event(pr.event)           # built (asynchronously) on another stream: order this one after it
+                pr.blob.record_stream(cur)         # and keep the allocator from recycling it under this stream's kernels
+                if pr.scales_dev is not None:
+                    pr.scales_dev.record_stream(cur)
+            return pr.blob
         on_device = training
         dev = self.centers.device
         if dev.type != "cuda":
@@ -179,18 +207,18 @@ class Quantizer(nn.Module):
                 cs, ls = self.centers_scale.detach(), self.logits_scale.detach()
                 assert cs.dtype == torch.float32 and ls.dtype == torch.float32
                 _lib.check(L.mcq_scales_exp(cs.data_ptr(), ls.data_ptr(), self.scale_speed, scales.data_ptr(), st), "mcq_scales_exp")
-                self._scales_dev = scales
-                self._scale_flags = 2       # MCQ_ENCODE_LSCALE_FROM_PREPARED
-                self._cscale_exp = self._lscale_exp = 1.0
+                scale_flags = 2             # MCQ_ENCODE_LSCALE_FROM_PREPARED
+                cscale_exp = lscale_exp = 1.0
                 rc = L.mcq_prepare_dev(centers.data_ptr(), scales.data_ptr(), weight.data_ptr(), bias.data_ptr(), N, K,
                                        D, blob.data_ptr(), st)
             else:
                 both = torch.stack([self.centers_scale.detach(), self.logits_scale.detach()]).to(torch.float32)
                 both = both.to("cpu")       # both scalars in one device->host copy; exp on the host
-                self._scale_flags = 0
-                self._cscale_exp = _scale_exp(both[0], self.scale_speed)
-                self._lscale_exp = _scale_exp(both[1], self.scale_speed)
-                rc = L.mcq_prepare(centers.data_ptr(), self._cscale_exp, weight.data_ptr(), bias.data_ptr(), N, K, D,
+                scales = None               # host-formed factors: no device copy belongs to this state
+                scale_flags = 0
+                cscale_exp = _scale_exp(both[0], self.scale_speed)
+                lscale_exp = _scale_exp(both[1], self.scale_speed)
+                rc = L.mcq_prepare(centers.data_ptr(), cscale_exp, weight.data_ptr(), bias.data_ptr(), N, K, D,
                                    blob.data_ptr(), st)
         _lib.check(rc, "mcq_prepare")
         # the inputs above may be temporaries: the stream orders their reuse after the kernel
@@ -198,7 +226,10 @@ class Quantizer(nn.Module):
             ev = torch.cuda.Event()
             cur = torch.cuda.current_stream(dev)
             ev.record(cur)
-        self._prep = (key, blob, "device" if on_device else "host", cur.cuda_stream, ev)
+        pr = _PreparedState()
+        pr.key, pr.blob, pr.flavour, pr.stream, pr.event = key, blob, "device" if on_device else "host", cur.cuda_stream, ev
+        pr.scales_dev, pr.scale_flags, pr.lscale_exp, pr.cscale_exp = scales, scale_flags, lscale_exp, cscale_exp
+        self._prep = pr
         return blob
 
     def _check_domain(self):

@@ -16,27 +16,58 @@ class _FlatAdam(torch.optim.Optimizer):
     """The reference's optimizer (torch.optim.Adam with weight decay, quantization.py:722-727) as ONE kernel
     (mcq_adam_step) over a flat bucket: the parameters' `.data` and `.grad` are views of `flat_p` / `flat_g`, the two
     moments are flat too.  A torch Optimizer subclass, so the reference's StepLR drives its learning rate unchanged and
-    optimizer step hooks fire."""
+    optimizer step hooks fire.
+
+    The moments and the step count live in `self.state` (under the first parameter, as flat tensors over the WHOLE
+    bucket), so `state_dict()` / `load_state_dict()` carry them like torch.optim.Adam's: a resumed run continues with
+    the same bias correction.  `zero_grad` always zeroes in place (the gradients must stay views of the bucket;
+    `set_to_none` is ignored)."""
 
     def __init__(self, params, flat_p, flat_g, lr, betas, eps, weight_decay):
+        params = list(params)
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.flat_p, self.flat_g = flat_p, flat_g
-        self.exp_avg = torch.zeros_like(flat_p)
-        self.exp_avg_sq = torch.zeros_like(flat_p)
-        self.t = 0
+        self._anchor = params[0]
+        self.state[self._anchor] = dict(step=0, exp_avg=torch.zeros_like(flat_p), exp_avg_sq=torch.zeros_like(flat_p))
+
+    # views of the optimizer state (load_state_dict replaces the tensors: always read through self.state)
+    @property
+    def exp_avg(self):
+        return self.state[self._anchor]["exp_avg"]
+
+    @property
+    def exp_avg_sq(self):
+        return self.state[self._anchor]["exp_avg_sq"]
+
+    @property
+    def t(self) -> int:
+        return int(self.state[self._anchor]["step"])
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        st = self.state[self._anchor]
+        n = self.flat_p.numel()
+        for k in ("exp_avg", "exp_avg_sq"):
+            v = st[k]
+            assert v.numel() == n, f"_FlatAdam.load_state_dict: {k} has {v.numel()} elements, the bucket {n}"
+            # an own copy (torch's load_state_dict keeps a tensor that already has the right device and dtype as it is:
+            # the moments would alias the state_dict's, i.e. those of the optimizer it came from)
+            st[k] = v.to(device=self.flat_p.device, dtype=torch.float32).reshape(n).clone()
+        st["step"] = int(st["step"])
 
     @torch.no_grad()
     def step(self, closure=None):
         assert closure is None
-        self.t += 1
+        st = self.state[self._anchor]
+        st["step"] = t = int(st["step"]) + 1
         g = self.param_groups[0]
         b1, b2 = g["betas"]
-        bc1 = 1.0 - b1 ** self.t
-        bc2_sqrt = math.sqrt(1.0 - b2 ** self.t)
+        bc1 = 1.0 - b1 ** t
+        bc2_sqrt = math.sqrt(1.0 - b2 ** t)
         dev = self.flat_p.device
         with torch.cuda.device(dev):
-            rc = _lib.lib().mcq_adam_step(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.exp_avg.data_ptr(),
-                                          self.exp_avg_sq.data_ptr(), self.flat_p.numel(), float(g["lr"]), float(b1), float(b2),
+            rc = _lib.lib().mcq_adam_step(self.flat_p.data_ptr(), self.flat_g.data_ptr(), st["exp_avg"].data_ptr(),
+                                          st["exp_avg_sq"].data_ptr(), self.flat_p.numel(), float(g["lr"]), float(b1), float(b2),
                                           float(g["eps"]), float(g["weight_decay"]), float(bc1), float(bc2_sqrt),
                                           torch.cuda.current_stream(dev).cuda_stream)
         _lib.check(rc, "mcq_adam_step")
@@ -57,7 +88,8 @@ class QuantizerTrainer(object):
     would have computed on the concatenated batch (multi-GPU)."""
 
     def __init__(self, dim: int, bytes_per_frame: int, device: torch.device, phase_one_iters: int = 10000,
-                 phase_two_iters: int = 10000, lr: float = 0.005, process_group=None, data_parallel: bool = False):
+                 phase_two_iters: int = 10000, lr: float = 0.005, process_group=None, data_parallel: bool = False,
+                 force_collectives: bool = False):
         super().__init__()
         assert bytes_per_frame in [1, 2, 4, 8, 16, 32]                   # quantization.py:614
         self.phase_one_iters = phase_one_iters
@@ -72,8 +104,12 @@ class QuantizerTrainer(object):
         self.start_time = time.time()
         self.process_group = process_group
         self.data_parallel = data_parallel or process_group is not None
+        # test hook: issue the step's collectives even in a group of ONE rank (sums over one rank are identities), so the
+        # RCCL call pattern -- asynchronous all-reduce on a slice of the bucket, the rest behind it -- runs on a 1-GPU box
+        self.force_collectives = force_collectives
         self.overlap_all_reduce = os.environ.get("MCQ_TRAINER_OVERLAP", "1") != "0"    # tuning hook: one collective per step
         self._pending = None
+        self._grads_dirty = False       # the gradient bucket holds a fused step's (never cleared) gradients
         if self.data_parallel:
             self._broadcast_parameters()
         self._init_optimizer()
@@ -89,9 +125,15 @@ class QuantizerTrainer(object):
         dist = self._dist()
         return dist.get_world_size(self.process_group) if dist.is_initialized() else 1
 
+    def _collective(self) -> bool:
+        """Does a step exchange anything?  (more than one rank, or the single-rank test hook)"""
+        if not self.data_parallel:
+            return False
+        return self._world() > 1 or (self.force_collectives and self._dist().is_initialized())
+
     def _broadcast_parameters(self):
         """All ranks start from rank 0's random initialisation."""
-        if self._world() == 1:
+        if not self._collective():
             return
         dist = self._dist()
         src = dist.get_global_rank(self.process_group, 0) if self.process_group is not None else 0
@@ -125,9 +167,19 @@ class QuantizerTrainer(object):
         x = x.reshape(-1, self.quantizer.dim)
         num_iters = 2 if random.random() < self.two_iter_prob else 1          # quantization.py:651
         fused = self.fused_step and x.is_cuda and not x.requires_grad and x.shape[0] > 0
+        if not fused and self._grads_dirty:
+            # the previous step was a fused one (its kernels OVERWRITE the gradient bucket and nothing clears it afterwards);
+            # autograd ACCUMULATES into .grad, so the bucket has to be cleared before this backward
+            self.optim.zero_grad()
+            self._grads_dirty = False
         if fused:
-            losses = self._fused_loss_and_grads(x, num_iters)
-        elif self._world() > 1:
+            try:
+                losses = self._fused_loss_and_grads(x, num_iters)
+            except BaseException:
+                self._drop_pending()        # a collective started by the backward must not pair with a later step's
+                raise
+            self._grads_dirty = self._flat is not None
+        elif self._collective():
             losses = self._dp_losses(x, num_iters)
         else:
             losses = self.quantizer.compute_loss(x, num_iters)
@@ -150,7 +202,7 @@ class QuantizerTrainer(object):
         if not fused:
             tot_loss = reconstruction_loss + logprob_loss + logits_entropy_loss * self.entropy_scale   # quantization.py:682-683
             tot_loss.backward()
-        if self._world() > 1:
+        if self._collective():
             if self._flat is not None:      # collectives on the bucket the gradients already live in
                 dist = self._dist()
                 pending, self._pending = self._pending, None
@@ -165,10 +217,19 @@ class QuantizerTrainer(object):
         self.optim.step()
         if not (fused and self._flat is not None):
             self.optim.zero_grad()          # the fused step overwrites every gradient: nothing to clear
+            self._grads_dirty = False
         self.scheduler.step()
         if self.cur_iter == self.phase_one_iters:                           # quantization.py:717-718
             self._begin_second_phase()
         self.cur_iter += 1
+
+    def _drop_pending(self):
+        pending, self._pending = self._pending, None
+        if pending is not None:
+            try:
+                pending[0].wait()
+            except Exception:
+                pass
 
     def _fused_loss_and_grads(self, x, num_iters):
         """The step's loss AND its parameter gradients without autograd (HIP device): forward kernels ->
@@ -194,7 +255,7 @@ class QuantizerTrainer(object):
                 st = torch.cuda.current_stream(dev).cuda_stream
                 _lib.check(L.mcq_loss_head(st_.parts[0].data_ptr(), st_.parts[1].data_ptr(), st_.parts.shape[1],
                                            st_.chosen_n.data_ptr(), N, float(B), head.data_ptr(), st), "mcq_loss_head")
-                if self._world() > 1:
+                if self._collective():
                     dist = self._dist()
                     dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=self.process_group)
                 _lib.check(L.mcq_loss_tail(head.data_ptr(), prob_sum.data_ptr(), count.data_ptr(), N, K, self.entropy_scale,
@@ -205,7 +266,7 @@ class QuantizerTrainer(object):
             hook = None
             if self._flat is not None:
                 views = {n_: p_.grad for n_, p_ in zip(names, params)}
-                if self._world() > 1 and self.overlap_all_reduce:
+                if self._collective() and self.overlap_all_reduce:
                     # two gradient buckets: the centers' (first in the flat bucket, complete after the scatter kernel) is
                     # all-reduced while the classifier's backward (softmax backward, weight-gradient GEMM) still runs
                     def hook(g_centers):
@@ -300,7 +361,7 @@ class QuantizerTrainer(object):
     def _begin_second_phase(self):
         # quantization.py:732-738
         self.quantizer = self.quantizer.get_product_quantizer()
-        if self._world() > 1:
+        if self._collective():
             # the product quantizer is a deterministic function of (identical) parameters; only
             # its fresh random id differs between ranks
             dist = self._dist()

@@ -272,3 +272,86 @@ def test_data_mean_in_the_prepared_state(D, K, N):
         got = blob[off:off + 4 * Dp].view(torch.float32)[:D].cpu()
         want = q.get_centers().mean(dim=1).sum(dim=0).cpu()
     assert torch.allclose(got, want, rtol=1e-5, atol=1e-6), (got - want).abs().max()
+
+
+def test_evaluation_between_steps_keeps_the_scale_factors_current():
+    """A no_grad encode / decode between two trainer steps (periodic evaluation) rebuilds the derived state with
+    HOST-formed scale factors; the next fused step must not pair it with the device factors of the step BEFORE the
+    optimizer update (they differ by exp(10 * lr) ~ 5 % after one Adam step).  The fused gradients are compared with
+    autograd's on the same parameters."""
+    from quantization_amd import QuantizerTrainer
+    dev = torch.device("cuda:0")
+    torch.manual_seed(31)
+    random.seed(31)
+    D, B = 64, 512
+    tr = QuantizerTrainer(dim=D, bytes_per_frame=4, device=dev, phase_one_iters=50, phase_two_iters=50)
+    q = tr.quantizer
+    for it in range(3):
+        tr.step(torch.from_numpy(gen.make_x(800 + it, B, D)).to(dev))
+        xe = torch.from_numpy(gen.make_x(900 + it, 256, D)).to(dev)
+        with torch.no_grad():
+            q.decode(q.encode(xe))                 # evaluation: host-flavour derived state for the new parameters
+        assert q._prep.flavour == "host" and q._scales_dev is None
+    x = torch.from_numpy(gen.make_x(850, B, D)).to(dev)
+    tr._fused_loss_and_grads(x, 1)
+    fused = {n: p.grad.detach().clone() for n, p in q.named_parameters()}
+    tr.optim.zero_grad()
+    losses = q.compute_loss(x.clone().requires_grad_(True), 1)      # the reference's torch op sequence under autograd
+    (losses[0] + losses[1] + losses[2] * tr.entropy_scale).backward()
+    for n, p in q.named_parameters():
+        scale = float(p.grad.abs().max()) + 1e-12
+        assert float((fused[n] - p.grad).abs().max()) <= 2e-4 * scale, (n, float((fused[n] - p.grad).abs().max()), scale)
+    tr.optim.zero_grad()
+
+
+def test_an_autograd_step_after_a_fused_step_starts_from_clean_gradients():
+    """Fused steps leave their gradients in the bucket (the next fused step overwrites them); a step that goes through
+    autograd accumulates into .grad, so the bucket must be cleared first."""
+    from quantization_amd import QuantizerTrainer
+    dev = torch.device("cuda:0")
+    runs = []
+    for pattern in ((True, False, True, False), (False, False, False, False)):
+        torch.manual_seed(41)
+        random.seed(41)
+        tr = QuantizerTrainer(dim=64, bytes_per_frame=4, device=dev, phase_one_iters=50, phase_two_iters=50)
+        for it, fused in enumerate(pattern):
+            tr.fused_step = fused
+            tr.step(torch.from_numpy(gen.make_x(600 + it, 512, 64)).to(dev))
+        runs.append({k: v.detach().cpu().numpy() for k, v in tr.quantizer.state_dict().items()})
+    a, b = runs
+    for k in ("centers", "to_logits.weight", "to_logits.bias", "logits_scale", "centers_scale"):
+        assert np.abs(a[k] - b[k]).max() <= 2e-4 * max(1e-3, np.abs(b[k]).max()), (k, np.abs(a[k] - b[k]).max())
+
+
+def test_flat_adam_state_dict_round_trip():
+    """The flat moments and the step count travel in state_dict(): a trainer resumed from it continues exactly."""
+    from quantization_amd import QuantizerTrainer
+    dev = torch.device("cuda:0")
+
+    def make():
+        torch.manual_seed(51)
+        random.seed(51)
+        return QuantizerTrainer(dim=64, bytes_per_frame=4, device=dev, phase_one_iters=50, phase_two_iters=50)
+
+    a = make()
+    for it in range(4):
+        a.step(torch.from_numpy(gen.make_x(700 + it, 512, 64)).to(dev))
+    sd_opt, sd_sched, sd_q = a.optim.state_dict(), a.scheduler.state_dict(), a.quantizer.state_dict()
+    assert sd_opt["state"][0]["step"] == 4 and sd_opt["state"][0]["exp_avg"].numel() == a._flat[0].numel()
+    b = make()
+    with torch.no_grad():
+        for (n, p), (_, pa) in zip(b.quantizer.named_parameters(), a.quantizer.named_parameters()):
+            p.copy_(pa)
+    b.quantizer.invalidate_cache()
+    b.optim.load_state_dict(sd_opt)
+    b.scheduler.load_state_dict(sd_sched)
+    b.cur_iter = a.cur_iter
+    assert b.optim.t == 4 and b.optim.exp_avg.data_ptr() != a.optim.exp_avg.data_ptr()
+    rs = random.getstate()
+    for tr in (a, b):
+        random.setstate(rs)
+        for it in range(3):
+            tr.step(torch.from_numpy(gen.make_x(710 + it, 512, 64)).to(dev))
+    for (n, pa), (_, pb) in zip(a.quantizer.named_parameters(), b.quantizer.named_parameters()):
+        assert torch.equal(pa, pb), n
+    del sd_q

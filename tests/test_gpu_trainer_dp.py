@@ -69,3 +69,50 @@ def test_two_ranks_on_the_device_equal_single_process():
     assert np.array_equal(r0["id_buf"], r1["id_buf"])
     assert np.allclose(r0["losses"], a["losses"], rtol=2e-4, atol=2e-5)
     assert np.array_equal(r0["losses"], r1["losses"])
+
+
+def _run_rccl_single(rank, port, out_path, overlap):
+    """One rank, backend nccl (= RCCL on ROCm): with `force_collectives` the step issues its collectives in a group of one
+    (sums over one rank are identities), so the call pattern the 8-GPU run uses -- broadcast of the initial parameters,
+    the forward all-reduce of the batch sums, the asynchronous all-reduce of the centers' slice of the gradient bucket
+    overlapping the classifier's backward, the rest of the bucket behind it -- runs through RCCL on the 1-GPU test box."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    os.environ["MCQ_TRAINER_OVERLAP"] = "1" if overlap else "0"
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    from quantization_amd import QuantizerTrainer
+    import torch.distributed as dist
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    use_group = port != 0
+    if use_group:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    torch.manual_seed(SEED)
+    random.seed(SEED)
+    tr = QuantizerTrainer(dim=D, bytes_per_frame=BYTES, device=dev, phase_one_iters=P1, phase_two_iters=P2,
+                          data_parallel=use_group, force_collectives=use_group)
+    assert tr.fused_step and tr._collective() == use_group
+    it, losses = 0, []
+    while not tr.done():
+        tr.step(torch.from_numpy(gen.make_x(7000 + it, BATCH, D)).to(dev))
+        losses.append(tr.last_losses)
+        it += 1
+    sd = {k: v.detach().cpu().numpy() for k, v in tr.get_quantizer().state_dict().items()}
+    np.savez(out_path, losses=np.array(losses), **sd)
+    if use_group:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_the_collectives_of_a_step_through_rccl(overlap):
+    tmp = tempfile.mkdtemp()
+    plain, coll = os.path.join(tmp, "plain.npz"), os.path.join(tmp, "rccl.npz")
+    mp.spawn(_run_rccl_single, args=(0, plain, overlap), nprocs=1, join=True)
+    mp.spawn(_run_rccl_single, args=(_free_port(), coll, overlap), nprocs=1, join=True)
+    a, b = np.load(plain), np.load(coll)
+    for k in ("centers", "to_logits.weight", "to_logits.bias", "logits_scale", "centers_scale"):
+        assert np.array_equal(a[k], b[k]), f"{k} differs after the RCCL collectives of a one-rank group"
+    assert np.array_equal(a["losses"], b["losses"])
