@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmcq_hip.so")
+# MCQ_LIB_PATH: another build of the same library (A/B timing of kernel variants on one box; tools/ only)
+LIB_PATH = os.environ.get("MCQ_LIB_PATH") or os.path.join(_HERE, "lib", "libmcq_hip.so")
 
 # every symbol include/mcq.h declares
 SYMBOLS = (

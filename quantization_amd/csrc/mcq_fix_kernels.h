@@ -172,17 +172,26 @@ struct FixGemm {
     int K, ncb;
 };
 
-// Persistent workgroups (one per CU: 132 KB of LDS, 512 registers per lane): workgroup w takes the tiles w, w + grid, ...
-// of an XCD-aware order and runs their k steps as ONE stream through the LDS ring -- the first steps of the next tile are
-// in flight while this one finishes and stores.  Four waves, each a 64 x 64 corner of the 128 x 128 tile (2 x 2 MFMA tiles x
-// 4 accumulator sets = 256 accumulator registers).  A k step: 40 MFMAs per wave against 16 ds_read_b128 (fragments of the
-// next step) and 8 LDS-DMA pieces of 1 KB (the step three ahead), dealt in four groups so that all three pipes stay busy.
+// Persistent workgroups (one per CU: 132 KB of LDS): workgroup w takes the tiles w, w + grid, ... of an XCD-aware order and
+// runs their k steps as ONE stream through the LDS ring -- the first steps of the next tile are in flight while this one
+// finishes and stores.  EIGHT waves, two per SIMD, each a 64 x 32 corner of the 128 x 128 tile (2 MFMA tiles x 4 accumulator
+// sets = 128 of its 256 registers).  A k step of a wave: 20 MFMAs against 12 ds_read_b128 (the fragments of the next step)
+// and 4 LDS-DMA pieces of 1 KB (the step four ahead), dealt in four groups.  With one wave per SIMD (four waves of 64 x 64,
+// the first version) a wave's DMA issue -- tens of cycles per piece in its in-order stream -- its fragment reads and its
+// waits left the matrix pipe idle: 0.72-0.75 ms per product at 65,536 x 2,048 x 512; two waves cover each other: 0.58.
+//
+// vmcnt bookkeeping: a wave's pieces of stage s are requested in step s - 4; before the fragment reads of stage s + 1 (the
+// sync of step s) it waits until only its pieces of the two later stages are outstanding (loads complete in the order they
+// were issued; the stores and the few extra pieces of a tile boundary only make that count conservative), then the
+// barrier makes every wave's pieces visible.  The row exponents and biases the epilogue needs reach LDS the same way (six
+// 256-byte DMA pieces per tile, requested when the tile starts).  Measured and dropped: draining the queue before the
+// epilogue's stores so that the next tile's first syncs need no count (0.566 against 0.549 ms).
 template <int MODE>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(512)
 k_fgemm(const FixGemm g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave & 1, wn = wave >> 1;
+    const int wm = wave & 1, wn = wave >> 1;          // 64-row half, 32-column quarter of the tile
     const int r32 = lane & 31, kh = lane >> 5;
     const long MT = g.RA / kFixTile, NT = g.RB / kFixTile;
     // K = 256 logits: the two row tiles of a codebook are consecutive tiles of one workgroup (running arg max in registers)
@@ -197,18 +206,17 @@ k_fgemm(const FixGemm g) {
         n0 = (g.walk_rows ? bt : st) * kFixTile;
         return bt < big;
     };
-    i32x16 acc[2][2][4];
+    i32x16 acc[2][4];
     const int nst = g.Dq / 32;
-    // this wave's 8 pieces of a stage (1 KB each): waves 0, 1 bring operand A, waves 2, 3 operand B; wave & 1 picks the
-    // 16-column chunk, g4 = 0..3 the limb plane; the two 64-row halves go out as one base with offset 0 / 1024 (the
-    // instruction offset applies to the global and to the LDS address alike)
+    // this wave's 4 pieces of a stage (1 KB each): waves 0..3 bring operand A, 4..7 operand B; bit 1 of the wave picks the
+    // 16-column chunk, bit 0 the 64-row half, g4 = 0..3 the limb plane
     const int wu = __builtin_amdgcn_readfirstlane(wave);
-    const int op = wu >> 1;
+    const int op = wu >> 2, chunk = (wu >> 1) & 1, half = wu & 1;
     const long R = op ? g.RB : g.RA;
     const long pl = R * 16, sstride = 8 * R * 16;
-    const unsigned dbase = (unsigned)(size_t)smem + op * kFixOperand + (4 * (wu & 1)) * 2048;
-    const unsigned voff = lane * 16;
-    auto base_of = [&](long m0, long n0) { return (op ? g.B + n0 * 16 : g.A + m0 * 16) + (long)(4 * (wu & 1)) * R * 16; };
+    const unsigned dbase = (unsigned)(size_t)smem + op * kFixOperand + (4 * chunk) * 2048 + half * 1024;
+    const unsigned voff = lane * 16, voff4 = lane * 4;
+    auto base_of = [&](long m0, long n0) { return (op ? g.B + n0 * 16 : g.A + m0 * 16) + (long)(4 * chunk) * R * 16 + half * 1024; };
     // (m0 is written without being declared clobbered -- the compiler rejects it as a reserved register; nothing else in
     // this kernel uses m0: LDS instructions need no m0 on gfx9+, and the kernel has no LDS-DMA builtin, movrel or GWS)
     auto issue1 = [&](const int8_t *p, int st, int g4) {
@@ -217,245 +225,229 @@ k_fgemm(const FixGemm g) {
         asm volatile(
             "s_mov_b32 m0, %[d]\n\ts_nop 0\n\t"
             "global_load_lds_dwordx4 %[vo], %[p]\n\t"
-            "global_load_lds_dwordx4 %[vo], %[p] offset:1024\n\t"
             :
             : [vo] "v"(voff), [p] "s"(pg), [d] "s"(d)
             : "memory");
     };
+    // the tile's row exponents ea (waves 0, 1), column exponents eb (2, 3) and, for the logits, row biases (4, 5) -> info:
+    // 64 words per piece; [0..127] ea, [128..255] eb, [256..383] bias, [384..] arg-max exchange.  (Rows past M read whatever
+    // follows the bias inside `prepared`: they never reach an output.)
+    auto issue_info = [&](long m0, long n0) {
+        if (wu < (MODE == FG_LOGITS ? 6 : 4)) {
+            const void *src = wu < 2 ? static_cast<const void *>(g.ea + m0 + 64 * wu)
+                                     : (wu < 4 ? static_cast<const void *>(g.eb + n0 + 64 * (wu - 2))
+                                               : static_cast<const void *>(g.bias + m0 + 64 * (wu - 4)));
+            const unsigned d = (unsigned)(size_t)smem + kFixInfo + 256 * wu;
+            asm volatile(
+                "s_mov_b32 m0, %[d]\n\ts_nop 0\n\t"
+                "global_load_lds_dword %[vo], %[p]\n\t"
+                :
+                : [vo] "v"(voff4), [p] "s"(src), [d] "s"(d)
+                : "memory");
+        }
+    };
     long m0, n0, m0n = 0, n0n = 0;
     if (!tile_of(0, m0, n0)) return;
     const int8_t *pcur = base_of(m0, n0), *pnext = pcur;
-    auto step = [&](int st, bool has_next, const i32x4 (&a)[2][4], const i32x4 (&b)[2][4], i32x4 (&an)[2][4], i32x4 (&bn)[2][4]) {
+    auto step = [&](int st, const i32x4 (&a)[2][4], const i32x4 (&b)[4], i32x4 (&an)[2][4], i32x4 (&bn)[4]) {
         const char *base = smem + ((st + 1) % kFixRing) * kFixSlot;
-        const bool load = (st + 4 < nst) || has_next;
+        // (after the last tile the stage four ahead does not exist: the pieces are requested all the same, from the start of
+        // the current tile (pnext == pcur then) into a slot nobody reads any more -- no branch round the DMA)
         const int8_t *p = (st + 4 < nst) ? pcur + (st + 4) * sstride : pnext + (st + 4 - nst) * sstride;
+        constexpr int PI[10] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 3};      // limb pairs (i, j), i + j <= 3, dealt 3, 3, 2, 2
+        constexpr int PJ[10] = {0, 1, 0, 2, 1, 0, 3, 2, 1, 0};
+        constexpr int LO[5] = {0, 3, 6, 8, 10};
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
-            if (load) issue1(p, st, g4);
+            issue1(p, st, g4);
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
+            for (int t = 0; t < 2; ++t)
                 an[t][g4] = *reinterpret_cast<const i32x4 *>(base + (kh * 4 + g4) * 2048 + (64 * wm + 32 * t + r32) * 16);
-                bn[t][g4] = *reinterpret_cast<const i32x4 *>(base + kFixOperand + (kh * 4 + g4) * 2048 + (64 * wn + 32 * t + r32) * 16);
-            }
-            constexpr int PI[10] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 3};      // limb pairs (i, j), i + j <= 3, dealt 3, 3, 2, 2
-            constexpr int PJ[10] = {0, 1, 0, 2, 1, 0, 3, 2, 1, 0};
-            constexpr int LO[5] = {0, 3, 6, 8, 10};
+            bn[g4] = *reinterpret_cast<const i32x4 *>(base + kFixOperand + (kh * 4 + g4) * 2048 + (32 * wn + r32) * 16);
 #pragma unroll
             for (int q = LO[g4]; q < LO[g4 + 1]; ++q)
 #pragma unroll
                 for (int ta = 0; ta < 2; ++ta)
-#pragma unroll
-                    for (int tb = 0; tb < 2; ++tb)
-                        acc[ta][tb][PI[q] + PJ[q]] =
-                            __builtin_amdgcn_mfma_i32_32x32x32_i8(a[ta][PI[q]], b[tb][PJ[q]], acc[ta][tb][PI[q] + PJ[q]], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+                    acc[ta][PI[q] + PJ[q]] =
+                        __builtin_amdgcn_mfma_i32_32x32x32_i8(a[ta][PI[q]], b[PJ[q]], acc[ta][PI[q] + PJ[q]], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);      // (everything requested up front instead: 0.59 against 0.53 ms)
         }
     };
-    i32x4 a0[2][4], b0[2][4], a1[2][4], b1[2][4];
+    i32x4 a0[2][4], b0[4], a1[2][4], b1[4];
+    issue_info(m0, n0);
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) issue1(pcur + q * sstride, q, g4);
-    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int l = 0; l < 4; ++l) {
 #pragma unroll
-        for (int l = 0; l < 4; ++l) {
+        for (int t = 0; t < 2; ++t)
             a0[t][l] = *reinterpret_cast<const i32x4 *>(smem + (kh * 4 + l) * 2048 + (64 * wm + 32 * t + r32) * 16);
-            b0[t][l] = *reinterpret_cast<const i32x4 *>(smem + kFixOperand + (kh * 4 + l) * 2048 + (64 * wn + 32 * t + r32) * 16);
-        }
-    int *info = reinterpret_cast<int *>(smem + kFixInfo);      // [0..127] ea of the tile rows, [128..255] eb of the columns,
-    float *infof = reinterpret_cast<float *>(smem + kFixInfo); // [256..383] bias of the rows, [384..] arg-max exchange
-    // running arg max of a codebook that spans several row tiles: per lane, its two columns
-    float runv[2] = {0.f, 0.f};
-    int runk[2] = {0, 0};
+        b0[l] = *reinterpret_cast<const i32x4 *>(smem + kFixOperand + (kh * 4 + l) * 2048 + (32 * wn + r32) * 16);
+    }
+    int *info = reinterpret_cast<int *>(smem + kFixInfo);
+    float *infof = reinterpret_cast<float *>(smem + kFixInfo);
+    // running arg max of a codebook that spans several row tiles: per lane, its column
+    float runv = 0.f;
+    int runk = 0;
     for (long t = 0;; ++t) {
         const bool has_next = tile_of(t + 1, m0n, n0n);
-        pnext = base_of(m0n, n0n);
+        pnext = has_next ? base_of(m0n, n0n) : pcur;
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
+            for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
-#pragma unroll
-                    for (int v = 0; v < 16; ++v) acc[a][b][s][v] = 0;
+                for (int v = 0; v < 16; ++v) acc[a][s][v] = 0;
         // before the reads of stage st + 1: it has landed everywhere and every wave has left slot st % ring.  Two later
-        // stages stay in flight (ordinary loads and stores of the epilogue only make the count conservative: loads
-        // complete in order)
-        auto sync = [&](int st) {
-            const int ahead = has_next ? 2 : (nst - 1 < st + 3 ? nst - 1 : st + 3) - (st + 1);
-            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
-            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-        };
+        // stages stay in flight
         for (int st = 0; st < nst; st += 2) {
-            sync(st);
-            step(st, has_next, a0, b0, a1, b1);
-            sync(st + 1);
-            step(st + 1, has_next, a1, b1, a0, b0);      // (reads past the end of the last tile hit a slot nobody uses)
+            asm volatile("s_waitcnt vmcnt(8)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            step(st, a0, b0, a1, b1);
+            asm volatile("s_waitcnt vmcnt(8)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            step(st + 1, a1, b1, a0, b0);      // (reads past the end of the last tile hit a slot nobody uses)
         }
-        // ---- epilogue: exponents (and bias) of the tile's rows and columns through LDS
-        if (tid < 128) {
-            info[tid] = g.ea[m0 + tid];
-            if (MODE == FG_LOGITS) infof[256 + tid] = (m0 + tid < g.M) ? g.bias[m0 + tid] : 0.f;
-        } else {
-            info[tid] = g.eb[n0 + tid - 128];
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        auto value = [&](int ta, int tb, int v, int e) -> float {
-            float tt = (float)acc[ta][tb][3][v];
-            tt = __builtin_fmaf((float)acc[ta][tb][2][v], 256.0f, tt);
-            tt = __builtin_fmaf((float)acc[ta][tb][1][v], 65536.0f, tt);
-            tt = __builtin_fmaf((float)acc[ta][tb][0][v], 16777216.0f, tt);
+        // ---- epilogue.  The info words of this tile landed during its first steps (requested at its start, made visible by
+        // the step barriers)
+        auto value = [&](int ta, int v, int e) -> float {
+            float tt = (float)acc[ta][3][v];
+            tt = __builtin_fmaf((float)acc[ta][2][v], 256.0f, tt);
+            tt = __builtin_fmaf((float)acc[ta][1][v], 65536.0f, tt);
+            tt = __builtin_fmaf((float)acc[ta][0][v], 16777216.0f, tt);
             return ldexpf(tt, e);
         };
-        // lane-dependent offsets are formed anew for every tile (hoisted out of the tile loop they would cost 128 registers)
-        int rbase = 64 * wm + 4 * kh, cbase = 64 * wn + r32;
+        // lane-dependent offsets are formed anew for every tile (hoisted out of the tile loop they would cost registers)
+        int rbase = 64 * wm + 4 * kh, cbase = 32 * wn + r32;
         asm volatile("" : "+v"(rbase), "+v"(cbase));
-        // the exponents (and biases) of this lane's 32 rows: eight 16-byte LDS reads up front -- read one by one next to
-        // their use, every output waited out an LDS round trip of its own (the epilogue was 0.13 ms of a 0.73 ms launch)
+        // the exponents (and biases) of this lane's 32 rows: eight 16-byte LDS reads up front
         i32x4 er[2][4];
 #pragma unroll
         for (int ta = 0; ta < 2; ++ta)
 #pragma unroll
             for (int q = 0; q < 4; ++q) er[ta][q] = *reinterpret_cast<const i32x4 *>(&info[rbase + 32 * ta + 8 * q]);
         const bool full = (m0 + kFixTile <= g.M) && (n0 + kFixTile <= g.N);      // whole tile inside: no per-element guards
+        const int ecol = info[128 + cbase] - 36;
+        const int rows_left = (int)((g.M - m0 - rbase) > 128 ? 128 : (g.M - m0 - rbase));
         if (MODE == FG_STORE) {
-            const int rows_left = (int)((g.M - m0 - rbase) > 128 ? 128 : (g.M - m0 - rbase));
+            const bool col_ok = n0 + cbase < g.N;
             float *orow = g.out + (m0 + rbase) * g.ldo + n0 + cbase;
+            if (full) {
 #pragma unroll
-            for (int tb = 0; tb < 2; ++tb) {
-                const bool col_ok = n0 + cbase + 32 * tb < g.N;
-                const int ecol = info[128 + cbase + 32 * tb] - 36;
-                if (full) {
+                for (int ta = 0; ta < 2; ++ta)
 #pragma unroll
-                    for (int ta = 0; ta < 2; ++ta)
+                    for (int v = 0; v < 16; ++v) {
+                        const int ro = 32 * ta + 8 * (v >> 2) + (v & 3);          // row of the lane's block
+                        orow[(long)ro * g.ldo] = value(ta, v, er[ta][v >> 2][v & 3] + ecol);
+                    }
+            } else {
 #pragma unroll
-                        for (int v = 0; v < 16; ++v) {
-                            const int ro = 32 * ta + 8 * (v >> 2) + (v & 3);          // row of the lane's block
-                            orow[(long)ro * g.ldo + 32 * tb] = value(ta, tb, v, er[ta][v >> 2][v & 3] + ecol);
-                        }
-                } else {
+                for (int ta = 0; ta < 2; ++ta)
 #pragma unroll
-                    for (int ta = 0; ta < 2; ++ta)
-#pragma unroll
-                        for (int v = 0; v < 16; ++v) {
-                            const int ro = 32 * ta + 8 * (v >> 2) + (v & 3);
-                            const float val = value(ta, tb, v, er[ta][v >> 2][v & 3] + ecol);
-                            if (col_ok && ro < rows_left) orow[(long)ro * g.ldo + 32 * tb] = val;
-                        }
-                }
+                    for (int v = 0; v < 16; ++v) {
+                        const int ro = 32 * ta + 8 * (v >> 2) + (v & 3);
+                        const float val = value(ta, v, er[ta][v >> 2][v & 3] + ecol);
+                        if (col_ok && ro < rows_left) orow[(long)ro * g.ldo] = val;
+                    }
             }
         } else {
             const float ls = g.lscale_ptr ? *g.lscale_ptr : g.lscale;
-            // per lane: columns (frames) cl(tb), rows 64 wm + 32 ta + 8 (v >> 2) + 4 kh + (v & 3), ascending in (ta, v)
-            float bv[2][4];       // best of the 16-row group (ta, v >> 3), this lane's 8 rows of it
-            int bk[2][4];
-            const int rows_left = (int)((g.M - m0 - rbase) > 128 ? 128 : (g.M - m0 - rbase));
+            // per lane: one column (frame), rows 64 wm + 32 ta + 8 (v >> 2) + 4 kh + (v & 3), ascending in (ta, v)
+            float bv[4];          // best of the 16-row group (ta, v >> 3), this lane's 8 rows of it
+            int bk[4];
             f32x4 br[2][4];
 #pragma unroll
             for (int ta = 0; ta < 2; ++ta)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) br[ta][q] = *reinterpret_cast<const f32x4 *>(&infof[256 + rbase + 32 * ta + 8 * q]);
+            const long col = n0 + cbase;
+            f32x4 q4[2][4];
 #pragma unroll
-            for (int tb = 0; tb < 2; ++tb) {
-                const long col = n0 + cbase + 32 * tb;
-                const int ecol = info[128 + cbase + 32 * tb] - 36;
-                float *lrow = g.logits ? g.logits + col * g.ldo + m0 + rbase : nullptr;
+            for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+                for (int v4 = 0; v4 < 4; ++v4) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int v = 4 * v4 + c;
+                        const int rl = rbase + 32 * ta + 8 * v4 + c;
+                        const float val = __fadd_rn(__fmul_rn(value(ta, v, er[ta][v4][c] + ecol), ls), br[ta][v4][c]);
+                        q4[ta][v4][c] = val;
+                        const int gi = 2 * ta + (v4 >> 1);
+                        if ((v4 & 1) == 0 && c == 0) { bv[gi] = val; bk[gi] = rl; }
+                        else if (val > bv[gi]) { bv[gi] = val; bk[gi] = rl; }
+                    }
+                }
+            if (g.logits) {
+                float *lrow = g.logits + col * g.ldo + m0 + rbase;
 #pragma unroll
                 for (int ta = 0; ta < 2; ++ta)
 #pragma unroll
-                    for (int v4 = 0; v4 < 4; ++v4) {
-                        f32x4 q4;
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            const int v = 4 * v4 + c;
-                            const int rl = rbase + 32 * ta + 8 * v4 + c;
-                            const float val = __fadd_rn(__fmul_rn(value(ta, tb, v, er[ta][v4][c] + ecol), ls), br[ta][v4][c]);
-                            q4[c] = val;
-                            const int gi = 2 * ta + (v4 >> 1);
-                            if ((v4 & 1) == 0 && c == 0) { bv[tb][gi] = val; bk[tb][gi] = rl; }
-                            else if (val > bv[tb][gi]) { bv[tb][gi] = val; bk[tb][gi] = rl; }
-                        }
-                        if (g.logits && (full || (col < g.N && 32 * ta + 8 * v4 < rows_left)))
-                            *reinterpret_cast<f32x4 *>(lrow + 32 * ta + 8 * v4) = q4;
-                    }
+                    for (int v4 = 0; v4 < 4; ++v4)
+                        if (full || (col < g.N && 32 * ta + 8 * v4 < rows_left))
+                            *reinterpret_cast<f32x4 *>(lrow + 32 * ta + 8 * v4) = q4[ta][v4];
             }
             if (g.idx) {
                 // a value beats another when it is larger, or equal with the lower row
                 auto better = [](float v1, int k1, float v2, int k2) { return v1 > v2 || (v1 == v2 && k1 < k2); };
                 const int K = g.K;
+                // the other half-wave holds the other 8 rows of every 16-row group
 #pragma unroll
-                for (int tb = 0; tb < 2; ++tb) {
-                    // the other half-wave holds the other 8 rows of every 16-row group
-#pragma unroll
-                    for (int gi = 0; gi < 4; ++gi) {
-                        const float ov = __shfl_xor(bv[tb][gi], 32, 64);
-                        const int ok = __shfl_xor(bk[tb][gi], 32, 64);
-                        if (better(ov, ok, bv[tb][gi], bk[tb][gi])) { bv[tb][gi] = ov; bk[tb][gi] = ok; }
-                    }
-                    // groups of 16 rows -> codebooks of K rows inside this wave's 64 rows (the later group wins only
-                    // with a strictly larger value)
-                    if (K >= 32) {
-                        if (bv[tb][1] > bv[tb][0]) { bv[tb][0] = bv[tb][1]; bk[tb][0] = bk[tb][1]; }
-                        if (bv[tb][3] > bv[tb][2]) { bv[tb][2] = bv[tb][3]; bk[tb][2] = bk[tb][3]; }
-                    }
-                    if (K >= 64 && bv[tb][2] > bv[tb][0]) { bv[tb][0] = bv[tb][2]; bk[tb][0] = bk[tb][2]; }
+                for (int gi = 0; gi < 4; ++gi) {
+                    const float ov = __shfl_xor(bv[gi], 32, 64);
+                    const int ok = __shfl_xor(bk[gi], 32, 64);
+                    if (better(ov, ok, bv[gi], bk[gi])) { bv[gi] = ov; bk[gi] = ok; }
                 }
-                const int cl0 = cbase;
+                // groups of 16 rows -> codebooks of K rows inside this wave's 64 rows (the later group wins only with a
+                // strictly larger value)
+                if (K >= 32) {
+                    if (bv[1] > bv[0]) { bv[0] = bv[1]; bk[0] = bk[1]; }
+                    if (bv[3] > bv[2]) { bv[2] = bv[3]; bk[2] = bk[3]; }
+                }
+                if (K >= 64 && bv[2] > bv[0]) { bv[0] = bv[2]; bk[0] = bk[2]; }
                 if (K <= 64) {
                     if (kh == 0) {
+                        const int span = K / 16;
 #pragma unroll
-                        for (int tb = 0; tb < 2; ++tb) {
-                            const long col = n0 + cl0 + 32 * tb;
-                            const int span = K / 16;
-#pragma unroll
-                            for (int gi = 0; gi < 4; ++gi) {
-                                const long row = m0 + bk[tb][gi];
-                                if ((gi % span) == 0 && col < g.N && row < g.M) g.idx[col * g.ncb + row / K] = (uint8_t)(row % K);
-                            }
+                        for (int gi = 0; gi < 4; ++gi) {
+                            const long row = m0 + bk[gi];
+                            if ((gi % span) == 0 && col < g.N && row < g.M) g.idx[col * g.ncb + row / K] = (uint8_t)(row % K);
                         }
                     }
                 } else {
                     // K = 128: the two waves of a column meet in LDS; K = 256: and the two row tiles in registers
                     float *exv = infof + 384;
                     int *exk = info + 384 + 128;
-                    if (wm == 1 && kh == 0) {
-#pragma unroll
-                        for (int tb = 0; tb < 2; ++tb) { exv[cl0 + 32 * tb] = bv[tb][0]; exk[cl0 + 32 * tb] = bk[tb][0]; }
-                    }
+                    if (wm == 1 && kh == 0) { exv[cbase] = bv[0]; exk[cbase] = bk[0]; }
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
                     if (wm == 0 && kh == 0) {
-                        const int half = (int)(t % H);
-#pragma unroll
-                        for (int tb = 0; tb < 2; ++tb) {
-                            const int cl = cl0 + 32 * tb;
-                            float v = bv[tb][0];
-                            long k = m0 + bk[tb][0];
-                            if (better(exv[cl], exk[cl], bv[tb][0], bk[tb][0])) { v = exv[cl]; k = m0 + exk[cl]; }
-                            if (half > 0 && !(v > runv[tb])) { v = runv[tb]; k = runk[tb]; }      // earlier rows win ties
-                            runv[tb] = v;
-                            runk[tb] = (int)k;
-                            const long col = n0 + cl;
-                            if (half == H - 1 && col < g.N && k < g.M) g.idx[col * g.ncb + k / K] = (uint8_t)(k % K);
-                        }
+                        const int hf = (int)(t % H);
+                        float v = bv[0];
+                        long k = m0 + bk[0];
+                        if (better(exv[cbase], exk[cbase], bv[0], bk[0])) { v = exv[cbase]; k = m0 + exk[cbase]; }
+                        if (hf > 0 && !(v > runv)) { v = runv; k = runk; }      // earlier rows win ties
+                        runv = v;
+                        runk = (int)k;
+                        if (hf == H - 1 && col < g.N && k < g.M) g.idx[col * g.ncb + k / K] = (uint8_t)(k % K);
                     }
                 }
             }
         }
         if (!has_next) break;
-        // the info words are rewritten in the next epilogue: every wave must have read them
+        // the info words are rewritten for the next tile: every wave must have read them (and every wave has waited for its
+        // pieces: the next tile's first stages have landed everywhere)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         m0 = m0n;
         n0 = n0n;
         pcur = pnext;
+        issue_info(m0, n0);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the pieces still on their way to this workgroup's LDS
 }
 
 }  // namespace mcq
