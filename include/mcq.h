@@ -20,8 +20,8 @@
  *  - return value: 0 = ok; MCQ_E* < 0 = rejected argument; > 0 = hipError_t of a
  *    failed launch.  Nothing is thrown across the boundary.
  *  - supported domain: codebook_size K a power of two in [16, 256], num_codebooks N
- *    a power of two, N <= 64 for K == 16 and N <= 32 for K >= 32 (what the reference's
- *    trainer can produce: bytes_per_frame <= 32, quantization/quantization.py:614), any
+ *    a power of two, N <= 64 (the reference's trainer produces at most 64 x 16 and 32 x 256:
+ *    bytes_per_frame <= 32, quantization/quantization.py:614; `prepared` holds the N*K x N*K Gram matrix), any
  *    dim 1 <= D <= 16384 (rows are zero-padded to a multiple of 16 inside `prepared`; the i32 accumulators
  *    of the fixed-point products bound D).  The reference crashes for K < 16
  *    (quantization/quantization.py:506) and needs K <= 256 for byte output (:271).

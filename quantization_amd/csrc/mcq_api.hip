@@ -144,11 +144,11 @@ Workspace carve(void *ws, long Bc, int N, int K, int D) {
     return w;
 }
 
-// N <= 64 for 16-entry codebooks, N <= 32 otherwise (what QuantizerTrainer can produce: bytes_per_frame <= 32)
+// up to 64 codebooks (QuantizerTrainer produces at most 64 x 16 and 32 x 256: bytes_per_frame <= 32)
 bool domain_ok(int N, int K, int D) {
-    return is_pow2(K) && K >= 16 && K <= 256 && is_pow2(N) && N <= (K == 16 ? 64 : 32) && D >= 1 && D <= 16384;
+    return is_pow2(K) && K >= 16 && K <= 256 && is_pow2(N) && N <= 64 && D >= 1 && D <= 16384;
 }
-int domain_err(int N, int K, int D = 1) { return (K < 16 || K > 256 || N > (K == 16 ? 64 : 32) || D > 16384) ? MCQ_EUNSUPPORTED : MCQ_EINVAL; }
+int domain_err(int N, int K, int D = 1) { return (K < 16 || K > 256 || N > 64 || D > 16384) ? MCQ_EUNSUPPORTED : MCQ_EINVAL; }
 
 // optional per-launch timing (mcq_profile_encode)
 struct Prof {
@@ -250,13 +250,7 @@ int launch_tf_stage0_k(int N, const float *G, const float *XC, const uint8_t *id
 #define MCQ_S0_CASE(NN) \
     case NN: hipLaunchKernelGGL((k_tf_stage0<K, NN>), grid, block, 0, st, G, XC, idx, R, Q, B, keep, ent, S, fin, nact, map); break;
     switch (N) {
-        MCQ_S0_CASE(1) MCQ_S0_CASE(2) MCQ_S0_CASE(4) MCQ_S0_CASE(8) MCQ_S0_CASE(16) MCQ_S0_CASE(32)
-        case 64:
-            if constexpr (K == 16) {
-                hipLaunchKernelGGL((k_tf_stage0<K, 64>), grid, block, 0, st, G, XC, idx, R, Q, B, keep, ent, S, fin, nact, map);
-                break;
-            }
-            return MCQ_EUNSUPPORTED;
+        MCQ_S0_CASE(1) MCQ_S0_CASE(2) MCQ_S0_CASE(4) MCQ_S0_CASE(8) MCQ_S0_CASE(16) MCQ_S0_CASE(32) MCQ_S0_CASE(64)
         default: return MCQ_EUNSUPPORTED;
     }
 #undef MCQ_S0_CASE
@@ -313,7 +307,7 @@ int launch_tf_up(int kh, int kc, const TfLists &L, long B, int N, int u, int nta
     const dim3 grid((unsigned)(B * ntab)), block(64);
 #define MCQ_UP_CASE(A, C) \
     if (kh == A && kc == C) { hipLaunchKernelGGL((k_tf_up<A, C>), grid, block, 0, st, L, B, N, u, ntab, per, in, out, nact); MCQ_LAUNCH_CHECK(); return 0; }
-    MCQ_UP_CASE(16, 32) MCQ_UP_CASE(32, 32) MCQ_UP_CASE(8, 16) MCQ_UP_CASE(16, 16) MCQ_UP_CASE(16, 32)
+    MCQ_UP_CASE(16, 32) MCQ_UP_CASE(32, 32) MCQ_UP_CASE(32, 64) MCQ_UP_CASE(8, 16) MCQ_UP_CASE(16, 16)
 #undef MCQ_UP_CASE
     return MCQ_EUNSUPPORTED;
 }
@@ -324,7 +318,7 @@ int launch_tf_comb(int kh, int kc, const float *E, const TfLists &L, long B, int
     const dim3 grid((unsigned)(B * (N >> (v + 1)))), block(64);
 #define MCQ_COMB_CASE(A, C) \
     if (kh == A && kc == C) { hipLaunchKernelGGL((k_tf_comb<A, C>), grid, block, 0, st, E, L, B, N, v, keep, tabs, fin, nact); MCQ_LAUNCH_CHECK(); return 0; }
-    MCQ_COMB_CASE(16, 32) MCQ_COMB_CASE(32, 32) MCQ_COMB_CASE(32, 64) MCQ_COMB_CASE(8, 16) MCQ_COMB_CASE(16, 16) MCQ_COMB_CASE(16, 32)
+    MCQ_COMB_CASE(16, 32) MCQ_COMB_CASE(32, 32) MCQ_COMB_CASE(32, 64) MCQ_COMB_CASE(64, 64) MCQ_COMB_CASE(8, 16) MCQ_COMB_CASE(16, 16)
 #undef MCQ_COMB_CASE
     return MCQ_EUNSUPPORTED;
 }

@@ -752,6 +752,9 @@ k_tf_comb(const float *__restrict__ E, TfLists L, long B, int N, int v, int keep
     constexpr int LDSF = (4 * MH * 4 >= kSelectLdsU64 * 8) ? 4 * MH : kSelectLdsU64 * 2;
     __shared__ __attribute__((aligned(16))) float th[LDSF];
     u64 *scratch = reinterpret_cast<u64 *>(th);
+    // (the chunked selection of 64 x 64 pairs runs while the tables are still being read: its scratch is its own)
+    __shared__ u64 sel2_store[(KC * KC / 64 > 16) ? kSelectLdsU64 : 1];
+    u64 *sel2 = sel2_store;
     if (nact) B = *nact;
     const int Gout = N >> (v + 1);
     const int h = (int)(blockIdx.x & (unsigned)(Gout - 1));
@@ -778,6 +781,38 @@ k_tf_comb(const float *__restrict__ E, TfLists L, long B, int N, int v, int keep
         }
         wave_lds_fence();
         tf_finish<VPL>(sv, sp, keep, KC, scratch, L, v + 1, b, N, h, idx_final);
+    } else if (idx_final == nullptr) {
+        // 4,096 pairs that are NOT the last combine (64 codebooks of more than 16 entries: 64 of them go on): the 64 smallest
+        // of every chunk of 1,024, then the 64 smallest of those 4 x 64 -- the same set and order as one selection over
+        // all of them (keys are unique)
+        static_assert(CHUNKS <= 4, "");
+        float cv[4];
+        int cp[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { cv[c] = INFINITY; cp[c] = kBigPos; }
+        for (int c = 0; c < CHUNKS; ++c) {
+            const int p0 = 64 * VPL * c + VPL * lane;
+            const int i = p0 / KC, j0 = p0 % KC;
+            const int i0 = px[2 * i], i1 = px[2 * i + 1];
+            const float se = Sx[i];
+            float sv[VPL];
+            int sp[VPL];
+#pragma unroll
+            for (int u = 0; u < VPL; ++u) {
+                const int jj0 = py[2 * (j0 + u)], jj1 = py[2 * (j0 + u) + 1];
+                const float t = ((th[i0 * KH + jj0] + th[MH + i0 * KH + jj1]) + th[2 * MH + i1 * KH + jj0]) + th[3 * MH + i1 * KH + jj1];
+                sv[u] = ((se + Sy[j0 + u]) - Eb) + 2.0f * t;
+                sp[u] = p0 + u;
+            }
+            float ov;
+            int op;
+            wave_select_fast<VPL>(sv, sp, keep, KC * KC, sel2, ov, op);
+            const bool got = lane < keep;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (q == c) { cv[q] = got ? ov : INFINITY; cp[q] = got ? op : kBigPos; }
+        }
+        tf_finish<4>(cv, cp, keep, KC, sel2, L, v + 1, b, N, h, nullptr);
     } else {
         float bv = INFINITY;
         int bp = kBigPos;

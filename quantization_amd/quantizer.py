@@ -236,8 +236,7 @@ class Quantizer(nn.Module):
         assert 16 <= self.codebook_size <= 256, (
             "the index search needs 16 <= codebook_size <= 256 (the reference itself fails below 16, "
             "quantization.py:506, and needs <= 256 for byte codes, :271)")
-        assert self.num_codebooks <= (64 if self.codebook_size == 16 else 32), (
-            "num_codebooks <= 64 for codebook_size 16, <= 32 otherwise (bytes_per_frame <= 32, quantization.py:614)")
+        assert self.num_codebooks <= 64, "num_codebooks <= 64 (QuantizerTrainer produces at most 64: quantization.py:614)"
         assert self.dim <= 16384, "dim <= 16384 (the i32 accumulators of the fixed-point products, include/mcq.h)"
 
     def _workspace(self, B: int, dev) -> Tensor:

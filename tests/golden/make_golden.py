@@ -228,6 +228,11 @@ def main(which):
         gen_synth("synth_d64_k16_n32", 64, 16, 32, 256, 21, 22, [0, 1, 3])
         gen_synth("synth_d32_k16_n64", 32, 16, 64, 128, 23, 24, [0, 1, 2])
         gen_synth("synth_d30_k32_n4", 30, 32, 4, 512, 25, 26, [0, 1, 3], x_kind="make_x")
+    if which in ("all", "wide"):
+        # 64 codebooks of more than 16 entries: outside what QuantizerTrainer produces (bytes_per_frame <= 32), inside what
+        # the reference's Quantizer accepts; lists of 64 at the two top levels
+        gen_synth("synth_d24_k32_n64", 24, 32, 64, 96, 27, 28, [0, 1, 2])
+        gen_synth("synth_d16_k256_n64", 16, 256, 64, 48, 29, 30, [0, 1, 2])
     if which in ("all", "configs"):
         # BASELINE.json config shapes (A, B, D) with seeded synthetic states
         gen_synth("config_a_d256_n4", 256, 256, 4, 1024, 101, 102, [0, 1, 5])

@@ -105,8 +105,8 @@ def test_workspace_and_prepared_sizes_over_the_domain():
     from quantization_amd import _lib as m
     L = m.lib()
     for K in (16, 32, 64, 128, 256):
-        for N in (1, 2, 4, 8, 16, 32, 64):
-            ok = N <= (64 if K == 16 else 32)
+        for N in (1, 2, 4, 8, 16, 32, 64, 128):
+            ok = N <= 64
             big = L.mcq_encode_workspace_bytes(10 ** 7, N, K, 512)
             small = L.mcq_encode_workspace_bytes(100, N, K, 512)
             if not ok:
