@@ -49,7 +49,7 @@ extern "C" {
 #define MCQ_EUNSUPPORTED (-2) /* outside the supported (K, N) domain             */
 #define MCQ_EWORKSPACE (-3) /* workspace smaller than mcq_encode_workspace_bytes */
 
-#define MCQ_ABI_VERSION 4   /* 4: fixed-point products: `prepared` holds limb planes of the centers and the classifier
+#define MCQ_ABI_VERSION 5   /* 5: mcq_prepared_decode_bytes, 64 codebooks for every codebook size; 4: fixed-point products: `prepared` holds limb planes of the centers and the classifier
                                (mcq_prepared_bytes changed), workspaces hold those of the frames (the workspace sizes
                                depend on D), mcq_logits takes a workspace, mcq_logits_workspace_bytes is new */
 int mcq_abi_version(void);
@@ -67,8 +67,11 @@ int mcq_padded_dim(int D);
  * 8 x 256; what the refinement passes read).
  * cscale_exp / lscale_exp = exp(10*centers_scale) / exp(10*logits_scale), formed
  * by the caller in fp32 exactly as the reference does (:78, :278).
- * weight/bias may be NULL when only decode is needed.                          */
+ * weight/bias may be NULL when only decode is needed: `prepared` then receives the scaled centers
+ * only and needs mcq_prepared_decode_bytes (no limb planes, no Gram matrix: 16 MB .. 1 GB less);
+ * such a state serves mcq_decode and nothing else.                                              */
 size_t mcq_prepared_bytes(int N, int K, int D);
+size_t mcq_prepared_decode_bytes(int N, int K, int D);
 /* byte offset inside `prepared` of float[mcq_padded_dim(D)]: get_data_mean() (:67-75) of the scaled centers,
  * sum_n mean_k C[n][k][:] (the scaled centers themselves are at offset 0, [N][K][mcq_padded_dim(D)])            */
 size_t mcq_prepared_mean_offset(int N, int K, int D);

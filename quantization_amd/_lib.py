@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("MCQ_LIB_PATH") or os.path.join(_HERE, "lib", "libmcq_
 
 # every symbol include/mcq.h declares
 SYMBOLS = (
-    "mcq_abi_version", "mcq_padded_dim", "mcq_prepared_bytes", "mcq_prepared_mean_offset", "mcq_prepare", "mcq_prepare_dev", "mcq_encode_workspace_bytes",
+    "mcq_abi_version", "mcq_padded_dim", "mcq_prepared_bytes", "mcq_prepared_decode_bytes", "mcq_prepared_mean_offset", "mcq_prepare", "mcq_prepare_dev", "mcq_encode_workspace_bytes",
     "mcq_encode", "mcq_encode_ex", "mcq_refine_indexes", "mcq_decode", "mcq_decode_backward", "mcq_logits", "mcq_logits_workspace_bytes", "mcq_last_encode_launches", "mcq_test_select", "mcq_profile_encode",
     "mcq_logits_argmax", "mcq_logits_refine", "mcq_loss_workspace_bytes", "mcq_loss_fwd", "mcq_loss_bwd", "mcq_recon_fwd", "mcq_loss_tail",
     "mcq_jcl_prefix_fwd", "mcq_jcl_prefix_bwd", "mcq_scatter_rows", "mcq_decode_backward_u8",
@@ -42,6 +42,8 @@ def lib():
     L.mcq_padded_dim.argtypes = [i32]
     L.mcq_prepared_bytes.restype = sz
     L.mcq_prepared_bytes.argtypes = [i32, i32, i32]
+    L.mcq_prepared_decode_bytes.restype = sz
+    L.mcq_prepared_decode_bytes.argtypes = [i32, i32, i32]
     L.mcq_prepare.restype = i32
     L.mcq_prepare.argtypes = [vp, f32, vp, vp, i32, i32, i32, vp, vp]
     L.mcq_prepare_dev.restype = i32
@@ -112,7 +114,7 @@ def lib():
     L.mcq_last_encode_launches.restype = i32
     L.mcq_profile_encode.restype = i32
     L.mcq_profile_encode.argtypes = [vp, i64, vp, f32, i32, i32, i32, i32, vp, sz, vp, ctypes.POINTER(f32), i32]
-    assert L.mcq_abi_version() == 4
+    assert L.mcq_abi_version() == 5
     _lib = L
     return L
 

@@ -541,6 +541,7 @@ static int prepare_impl(const float *centers, float cscale_exp, const float *sca
                        scales_dev ? reinterpret_cast<float *>(b + l.offScales) : static_cast<float *>(nullptr));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
+    if (!weight) return 0;      // decode only: the scaled centers are all mcq_decode reads (mcq_prepared_decode_bytes)
     const float *C = reinterpret_cast<const float *>(b + l.offC);
     hipLaunchKernelGGL(k_centers_mean, dim3((unsigned)(Dp / 16)), dim3(1024), 0, st, C, N, K, Dp,
                        reinterpret_cast<float *>(b + l.offMean));
@@ -550,12 +551,12 @@ static int prepare_impl(const float *centers, float cscale_exp, const float *sca
     int rc = launch_fix_rows(C, 0, rows, Dp, Dp, reinterpret_cast<int8_t *>(b + l.offCf), reinterpret_cast<int *>(b + l.offCe),
                              nullptr, st);
     if (rc) return rc;
-    if (weight) {
+    {
         rc = launch_fix_rows(weight, 0, rows, D, D, reinterpret_cast<int8_t *>(b + l.offWf), reinterpret_cast<int *>(b + l.offWe),
                              nullptr, st, bias, reinterpret_cast<float *>(b + l.offBias));      // (the bias rides along)
         if (rc) return rc;
     }
-    if (weight) {
+    {
         // Gram matrix of the scaled centers: the x.C product with the centers themselves as the frames
         rc = launch_xc(reinterpret_cast<const int8_t *>(b + l.offCf), reinterpret_cast<const int *>(b + l.offCe), rows,
                        reinterpret_cast<const int8_t *>(b + l.offCf), reinterpret_cast<const int *>(b + l.offCe), rows, D,
@@ -563,6 +564,11 @@ static int prepare_impl(const float *centers, float cscale_exp, const float *sca
         if (rc) return rc;
     }
     return 0;
+}
+
+size_t mcq_prepared_decode_bytes(int N, int K, int D) {
+    if (N <= 0 || K <= 0 || D <= 0) return 0;
+    return prepared_layout(N, K, D).offCf;      // scaled centers + their sums of squares
 }
 
 size_t mcq_prepared_mean_offset(int N, int K, int D) {

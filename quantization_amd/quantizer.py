@@ -167,7 +167,8 @@ class Quantizer(nn.Module):
         CPU (parity with its fixtures).  Training (autograd recording): the scales are read on the
         device (mcq_prepare_dev) so that a training loop never synchronises with the host.  A blob of
         the training flavour is never used for an inference search (its scale factors may differ from
-        the host's by an ulp); decode (`any_flavour`) takes whichever is current."""
+        the host's by an ulp); decode (`any_flavour`) takes whichever is current, and builds a state of its own kind when
+        there is none: the scaled centers only ("decode"), which no search accepts."""
         ps = (self.centers, self.centers_scale, self.logits_scale, self.to_logits.weight, self.to_logits.bias)
         trainable = any(p.requires_grad for p in ps)
         if trainable:
@@ -181,7 +182,7 @@ class Quantizer(nn.Module):
                 _quantizer_params[id(p)] = weakref.ref(p)
         key = tuple((p.data_ptr(), p._version, str(p.device)) for p in ps) + (_param_epoch[0],)
         pr = self._prep
-        if pr is not None and pr.key == key and (pr.flavour == "host" or training or any_flavour):
+        if pr is not None and pr.key == key and (any_flavour or pr.flavour == "host" or (training and pr.flavour != "decode")):
             cur = torch.cuda.current_stream(pr.blob.device)
             if cur.cuda_stream != pr.stream:
                 cur.wait_event(pr.event)           # built (asynchronously) on another stream: order this one after it
@@ -190,13 +191,17 @@ class Quantizer(nn.Module):
                     pr.scales_dev.record_stream(cur)
             return pr.blob
         on_device = training
+        # decode with nothing cached (a quantizer that is only ever decoded with): the scaled centers alone -- no limb
+        # planes, no Gram matrix (16 MB at 8 x 256, 1 GB at 64 x 256)
+        decode_only = any_flavour and not training
         dev = self.centers.device
         if dev.type != "cuda":
             raise _lib.McqError("quantization_amd.Quantizer runs on a HIP device only: move the module with "
                                 ".to('cuda') (the CPU oracle under oracle/ is test infrastructure)")
         L = _lib.lib()
         N, K, D = self.num_codebooks, self.codebook_size, self.dim
-        blob = torch.empty(L.mcq_prepared_bytes(N, K, D), dtype=torch.uint8, device=dev)
+        blob = torch.empty(L.mcq_prepared_decode_bytes(N, K, D) if decode_only else L.mcq_prepared_bytes(N, K, D),
+                           dtype=torch.uint8, device=dev)
         centers = self.centers.detach().to(torch.float32).contiguous()
         weight = self.to_logits.weight.detach().to(torch.float32).contiguous()
         bias = self.to_logits.bias.detach().to(torch.float32).contiguous()
@@ -218,8 +223,8 @@ class Quantizer(nn.Module):
                 scale_flags = 0
                 cscale_exp = _scale_exp(both[0], self.scale_speed)
                 lscale_exp = _scale_exp(both[1], self.scale_speed)
-                rc = L.mcq_prepare(centers.data_ptr(), cscale_exp, weight.data_ptr(), bias.data_ptr(), N, K, D,
-                                   blob.data_ptr(), st)
+                rc = L.mcq_prepare(centers.data_ptr(), cscale_exp, None if decode_only else weight.data_ptr(),
+                                   None if decode_only else bias.data_ptr(), N, K, D, blob.data_ptr(), st)
         _lib.check(rc, "mcq_prepare")
         # the inputs above may be temporaries: the stream orders their reuse after the kernel
         with torch.cuda.device(dev):
@@ -227,7 +232,8 @@ class Quantizer(nn.Module):
             cur = torch.cuda.current_stream(dev)
             ev.record(cur)
         pr = _PreparedState()
-        pr.key, pr.blob, pr.flavour, pr.stream, pr.event = key, blob, "device" if on_device else "host", cur.cuda_stream, ev
+        pr.key, pr.blob, pr.stream, pr.event = key, blob, cur.cuda_stream, ev
+        pr.flavour = "device" if on_device else ("decode" if decode_only else "host")
         pr.scales_dev, pr.scale_flags, pr.lscale_exp, pr.cscale_exp = scales, scale_flags, lscale_exp, cscale_exp
         self._prep = pr
         return blob

@@ -595,3 +595,29 @@ def test_wave_selection_paths(per_lane, cnt):
         order = np.lexsort((np.arange(M), sc[c]))[:cnt]          # by value, then position
         assert np.array_equal(op[c, :cnt].cpu().numpy(), order), (c, per_lane, cnt)
         assert np.array_equal(ov[c, :cnt].cpu().numpy(), sc[c][order])
+
+
+def test_decode_only_state_is_small_and_a_later_search_rebuilds():
+    """decode() on a quantizer that was never searched with builds the scaled centers only (mcq_prepared_decode_bytes: no
+    limb planes, no Gram matrix); a search afterwards replaces it by the full state; decode gives the same bits either way."""
+    from quantization_amd import Quantizer, _lib
+    L = _lib.lib()
+    D, K, N = 96, 256, 8
+    torch.manual_seed(2)
+    q = Quantizer(D, K, N).cuda()
+    codes = torch.randint(0, K, (777, N), device="cuda", dtype=torch.uint8)
+    with torch.no_grad():
+        y0 = q.decode(codes)
+        assert q._prep.flavour == "decode" and q._prep.blob.numel() == L.mcq_prepared_decode_bytes(N, K, D)
+        assert L.mcq_prepared_decode_bytes(N, K, D) < L.mcq_prepared_bytes(N, K, D) // 8
+        x = torch.randn(300, D, device="cuda")
+        c = q.encode(x, 2)
+        assert q._prep.flavour == "host" and q._prep.blob.numel() == L.mcq_prepared_bytes(N, K, D)
+        y1 = q.decode(codes)
+        assert q._prep.flavour == "host"
+    assert torch.equal(y0, y1)
+    ref = q.get_centers().detach()[torch.arange(N, device="cuda"), codes.long()]      # (B, N, D), summed in codebook order
+    acc = ref[:, 0]
+    for n in range(1, N):
+        acc = acc + ref[:, n]
+    assert torch.equal(y0, acc) and tuple(c.shape) == (300, N)
