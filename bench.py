@@ -336,13 +336,15 @@ def main():
     # HBM-side traffic of the dominant kernel: from the committed rocprofv3 --pmc passes of this same
     # workload (counters cannot be collected from inside the timed process); null for other shapes / kernels
     traffic, traffic_note = None, None
-    pmc_file = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-    if (D, N, K, B, iters) == (512, 8, 256, 65536, 5) and os.path.exists(pmc_file):
+    import glob as _glob
+    pmc_files = sorted(_glob.glob(os.path.join(ROOT, "profiles", "r??_pmc_traffic.json")))     # the newest round's passes
+    pmc_file = pmc_files[-1] if pmc_files else ""
+    if (D, N, K, B, iters) == (512, 8, 256, 65536, 5) and pmc_file:
         pmc = json.load(open(pmc_file))
         if dom_name in pmc:
             traffic = pmc[dom_name]["traffic_bytes"]
-            traffic_note = ("bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 of kernel %s, profiles/r02_pmc_traffic.json"
-                            % pmc[dom_name]["kernel"])
+            traffic_note = ("bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 of kernel %s, profiles/%s"
+                            % (pmc[dom_name]["kernel"], os.path.basename(pmc_file)))
     if dom_fl > 0:
         achieved = LIMB_PRODUCTS * dom_fl / (dom_ms * 1e-3) / 1e12
         roofline = {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 1), "peak": PEAK_I8_MFMA_TOPS,
