@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""profiles/r02_pmc_traffic.json from the FETCH_SIZE / WRITE_SIZE passes of tools/pmc_passes.sh.
-usage: pmc_traffic.py gpurun_out/<pmc dir> > profiles/r02_pmc_traffic.json   (keys = bench.py's kernel categories)"""
+"""profiles/r03_pmc_traffic.json from the FETCH_SIZE / WRITE_SIZE passes of tools/pmc_passes.sh.
+usage: pmc_traffic.py gpurun_out/<pmc dir> > profiles/r03_pmc_traffic.json   (keys = bench.py's kernel categories)"""
 import collections, csv, glob, json, os, re, sys
 root = sys.argv[1]
 KERNELS = {"logits_product_argmax": "k_fgemm<1>", "xc_product": "k_fgemm<0>", "frames_to_limbs": "k_fix_rows<4>",
@@ -17,7 +17,7 @@ out = {"_note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, KB pe
                 "traffic_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 -- gfx950 FETCH_SIZE reads 1/2 of a wide streaming read "
                 "(MI355X_MICROARCH.md, HBM).  Counts fabric-side requests of the XCDs' L2s, so Infinity-Cache hits "
                 "are included; Gram-table reads served by an L2 are not.",
-       "source": "profiles/r02_pmc_counters.txt (tools/pmc_passes.sh, tools/pmc_traffic.py)"}
+       "source": "profiles/r03_pmc_counters.txt (tools/pmc_passes.sh, tools/pmc_traffic.py)"}
 for cat, k in KERNELS.items():
     f, w = vals[k]["FETCH_SIZE"], vals[k]["WRITE_SIZE"]
     if not (f and w):
