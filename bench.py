@@ -365,6 +365,16 @@ def main():
                             "inputs, lists written); what bounds it is the L2 -> L1 fabric that carries the Gram row segments "
                             "(table_*: measured ceiling 17-25 TB/s for such pieces, DESIGN.md section 5).  The two matrix-core products "
                             "(logits, x.C) are in `kernels` with their fraction of the i8-MFMA peak"}
+        if dom_name == "stage0_tables":
+            # the yardstick of SURVEY.md 8(d) for the same launch: the matmul FLOPs of the reference's stage-0 GEMM
+            # (quantization.py:413-416, 2*D*N*K per vector and pass) that this kernel replaces by table reads
+            ref_fl = 2.0 * D * N * K * B
+            roofline["reference_algorithm"] = {
+                "gflop_per_launch": round(ref_fl / 1e9, 2), "tflops": round(ref_fl / (dom_ms * 1e-3) / 1e12, 1),
+                "frac_of_f32_mfma_peak": round(ref_fl / (dom_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                "note": "FLOPs of the reference's stage-0 matmul for the vectors of one launch / this launch's duration / "
+                        "157.3 TFLOP/s (SURVEY.md 8d prices encode against the fp32-MFMA peak); above 1 because the table "
+                        "form reads these inner products from the Gram matrix instead of executing them"}
 
     fpv = reference_flops_per_vector(D, N, K, iters)
     exec_fpv = 2 * 2.0 * D * N * K          # the logits and x.C products only (each multiply-add = ten i8 limb products)
