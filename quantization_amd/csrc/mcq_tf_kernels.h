@@ -351,14 +351,22 @@ template <int VPL>
 __device__ __forceinline__ void tf_finish(const float (&sv)[VPL], const int (&sp)[VPL], int keep, int KCin, u64 *scratch,
                                           const TfLists &L, int vout /* level of the list written */, long b, int N,
                                           int gout, uint8_t *__restrict__ idx_final) {
-    float ov;
-    int op;
-    wave_select_fast<VPL>(sv, sp, keep, KCin * KCin, scratch, ov, op);
-    if (idx_final != nullptr) {     // one group left, keep == 1: lane 0 holds the winner
-        const int win = __builtin_amdgcn_readfirstlane(op);
+    if (idx_final != nullptr) {     // one group left, keep == 1: the smallest (score, position) is the result
+        // (wave_select's rule for one winner -- smallest (score, position), NaN never taken -- without its general
+        // bookkeeping of the previous winner: ten instructions per candidate there)
+        float bv = INFINITY;
+        int bp = kBigPos;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) lexmin(bv, bp, sv[i], sp[i]);
+        wave_lexmin(bv, bp);
+        int win = __builtin_amdgcn_readfirstlane(bp);
+        if (win > KCin * KCin - 1) win = KCin * KCin - 1;          // only reachable with NaN keys
         tf_emit(L, b, N, vout, win, idx_final);
         return;
     }
+    float ov;
+    int op;
+    wave_select_fast<VPL>(sv, sp, keep, KCin * KCin, scratch, ov, op);
     if (lane_id() < keep) {
         const long o = (b * (N >> vout) + gout) * keep + lane_id();
         L.pos[vout][2 * o] = (uint8_t)(op / KCin);
