@@ -241,19 +241,28 @@ __device__ __forceinline__ void wave_select_fast(const float (&v)[VPL], const in
         if (lane < 8) ldsS[c0 + lane] = kKeyMax;                       // sentinel tail
         wave_lds_fence();
         const u64 ka = (lane < c0) ? ldsS[lane] : kKeyMax;
-        const u64 kb = (lane + 64 < c0) ? ldsS[lane + 64] : kKeyMax;
-        int ra = 0, rb = 0;
         const int c8 = (c0 + 7) & ~7;
-        for (int j = 0; j < c8; j += 8) {
+        int ra = 0;
+        if (c0 <= 64) {
+            // the usual case (about 41 survivors for 32 of 256): nobody holds a second survivor, half the compares
+            for (int j = 0; j < c8; j += 8) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const u64 o = ldsS[j + u];
-                ra += (o < ka) ? 1 : 0;
-                rb += (o < kb) ? 1 : 0;
+                for (int u = 0; u < 8; ++u) ra += (ldsS[j + u] < ka) ? 1 : 0;
             }
+        } else {
+            const u64 kb = ldsS[lane + 64 < c0 ? lane + 64 : c0];      // (slot c0 holds a sentinel)
+            int rb = 0;
+            for (int j = 0; j < c8; j += 8) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const u64 o = ldsS[j + u];
+                    ra += (o < ka) ? 1 : 0;
+                    rb += (o < kb) ? 1 : 0;
+                }
+            }
+            if (lane + 64 < c0 && rb < cnt) ldsO[rb] = kb;
         }
         if (lane < c0 && ra < cnt) ldsO[ra] = ka;
-        if (lane + 64 < c0 && rb < cnt) ldsO[rb] = kb;
         wave_lds_fence();
         out_v = INFINITY;
         out_p = M - 1;
