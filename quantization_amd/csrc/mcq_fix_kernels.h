@@ -392,7 +392,7 @@ k_fgemm(const FixGemm g) {
             }
             if (g.idx) {
                 // a value beats another when it is larger, or equal with the lower row
-                auto better = [](float v1, int k1, float v2, int k2) { return v1 > v2 || (v1 == v2 && k1 < k2); };
+                auto better = [](float v1, int k1, float v2, int k2) { return (v1 > v2) | ((v1 == v2) & (k1 < k2)); };
                 const int K = g.K;
                 // the other half-wave holds the other 8 rows of every 16-row group
 #pragma unroll
