@@ -52,7 +52,7 @@ k_tf_gram_terms(const float *__restrict__ G, const uint8_t *__restrict__ idx, lo
     if (b >= B) return;
     const uint8_t *id = idx + b * N;
     const int NK = N * K;
-    gterms[(b * N + m) * N + m2] = G[(size_t)(m * K + id[m]) * NK + m2 * K + id[m2]];
+    gterms[(b * N + m) * N + m2] = G[((size_t)(m * K + id[m]) << __builtin_ctz((unsigned)NK)) + m2 * K + id[m2]];
 }
 
 // One wave per vector: E = |x_err|^2 and R[n] = |x_err - old_n|^2 (:401-409) from the N*N Gram terms, N entries of XC
@@ -293,6 +293,7 @@ __device__ __forceinline__ void tf_leaf(const float *__restrict__ G, int NK, int
     const int lane = lane_id();
     const int i = (VPL * lane) / KC, j0 = (VPL * lane) % KC;
     const uint32_t rown = (uint32_t)(n * K), colm = (uint32_t)(m * K);
+    const int nksh = __builtin_ctz((unsigned)NK);      // N and K are powers of two: a row offset is a shift (v_mul_lo_u32 runs at a quarter of the rate)
     // every list byte this lane needs (its row entry, its VPL column entries, its border entry) is requested before the first
     // use: left to the compiler the border bytes were loaded one after the other BEHIND the first wait, and the Gram reads
     // started four memory round trips into the kernel instead of two
@@ -315,12 +316,12 @@ __device__ __forceinline__ void tf_leaf(const float *__restrict__ G, int NK, int
     float g[VPL];
     if constexpr (VPL == 4) {
 #pragma unroll
-        for (int v = 0; v < 4; ++v) g[v] = G[si * (uint32_t)NK + colm + ((w4 >> (8 * v)) & 0xffu)];
+        for (int v = 0; v < 4; ++v) g[v] = G[(si << nksh) + colm + ((w4 >> (8 * v)) & 0xffu)];
     } else {
 #pragma unroll
-        for (int v = 0; v < VPL; ++v) g[v] = G[si * (uint32_t)NK + colm + (uint32_t)ej[v]];
+        for (int v = 0; v < VPL; ++v) g[v] = G[(si << nksh) + colm + (uint32_t)ej[v]];
     }
-    const float bv = G[br * (uint32_t)NK + bc];
+    const float bv = G[(br << nksh) + bc];
     const float u = shfl_f(bv, i), w = shfl_f(bv, 2 * KC);
 #pragma unroll
     for (int v = 0; v < VPL; ++v) {
@@ -433,6 +434,7 @@ __device__ __forceinline__ void tf_table1(const float *__restrict__ G, const uin
         int *cent = reinterpret_cast<int *>(leaf + 4 * LS);   // [4][16] compact list -> codebook entry
         int *crank = cent + 64;                               // [4][16] candidate -> compact rank of its leaf
         const int NK = N * K;
+        const int nksh = __builtin_ctz((unsigned)NK);
         // quarter w of the wave = one of the four halves' lists: 0, 1 = the halves of X, 2, 3 = those of Y
         const int w = lane >> 4, c = lane & 15;
         const int cb = (w < 2) ? 2 * X + w : 2 * Y + (w - 2);      // this quarter's codebook
@@ -476,7 +478,7 @@ __device__ __forceinline__ void tf_table1(const float *__restrict__ G, const uin
             const bool isu = lane < na_[tb], isv = lane >= na_[tb] && lane < na_[tb] + nc_[tb];
             const uint32_t br = rown_[tb] + (uint32_t)(isu ? cent[a * 16 + lane] : oldq[a]);
             const uint32_t bc = colm_[tb] + (uint32_t)(isv ? cent[(2 + cc) * 16 + (lane - na_[tb])] : oldq[2 + cc]);
-            bv[tb] = G[br * (uint32_t)NK + bc];
+            bv[tb] = G[(br << nksh) + bc];
         }
         float g[4][4];
         int rr[4][4];      // ra * 16 + rc of this lane's entry, -1 if none
@@ -496,7 +498,7 @@ __device__ __forceinline__ void tf_table1(const float *__restrict__ G, const uin
                     ra -= (ra * nc > qc);
                     ra += ((ra + 1) * nc <= qc);
                     const int rc = qc - ra * nc;
-                    g[tb][it] = G[(rown_[tb] + (uint32_t)cent[a * 16 + ra]) * (uint32_t)NK + colm_[tb] + (uint32_t)cent[(2 + cc) * 16 + rc]];
+                    g[tb][it] = G[((rown_[tb] + (uint32_t)cent[a * 16 + ra]) << nksh) + colm_[tb] + (uint32_t)cent[(2 + cc) * 16 + rc]];
                     rr[tb][it] = q < na * nc ? ra * 16 + rc : -1;
                 }
             }
@@ -530,6 +532,7 @@ __device__ __forceinline__ void tf_table1(const float *__restrict__ G, const uin
         // move together -- all list / index bytes in one batch, all eight Gram reads in a second one -- instead of four
         // tf_leaf calls in a row (eight dependent round trips: this path is the trainer's first phase)
         const int NK = N * K;
+        const int nksh = __builtin_ctz((unsigned)NK);
         const int i = lane / KCH, j = lane % KCH;
         const int bl = lane < 2 * KCH ? lane : 2 * KCH;
         int cbk[4] = {2 * X, 2 * X + 1, 2 * Y, 2 * Y + 1};
@@ -554,10 +557,10 @@ __device__ __forceinline__ void tf_table1(const float *__restrict__ G, const uin
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 const uint32_t rown = (uint32_t)(cbk[a] * K), colm = (uint32_t)(cbk[2 + c] * K);
-                g[a * 2 + c] = G[(rown + (uint32_t)e_row[a]) * (uint32_t)NK + colm + (uint32_t)e_col[c]];
+                g[a * 2 + c] = G[((rown + (uint32_t)e_row[a]) << nksh) + colm + (uint32_t)e_col[c]];
                 const uint32_t br = bl < KCH ? rown + (uint32_t)e_brd[a] : rown + (uint32_t)oldq[a];
                 const uint32_t bc = (bl >= KCH && bl < 2 * KCH) ? colm + (uint32_t)e_brd[2 + c] : colm + (uint32_t)oldq[2 + c];
-                bv[a * 2 + c] = G[br * (uint32_t)NK + bc];
+                bv[a * 2 + c] = G[(br << nksh) + bc];
             }
 #pragma unroll
         for (int tb = 0; tb < 4; ++tb) {
