@@ -134,6 +134,27 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// The key with exactly `target` smaller keys among the 64 per-lane keys `k` (unique; kKeyMax = no key): a quickselect whose
+// candidate set is a wave-uniform 64-bit mask handled by scalar instructions.  One round = first candidate as the pivot,
+// one ballot, one popcount; written as a do-while with both successor masks formed unconditionally (the while-with-break
+// form compiled to 22 instructions and four branches per round, this one to about 14 and one).  kKeyMax when there are
+// fewer than target + 1 keys.
+__device__ __forceinline__ u64 wave_kth_lane_key(u64 k, int target) {
+    u64 cm = __ballot(k != kKeyMax);
+    if (__popcll(cm) <= target) return kKeyMax;
+    u64 kp;
+    int rr;
+    do {                          // every round removes at least the pivot's lane from the candidates: <= 64 rounds
+        const int pl = __ffsll((long long)cm) - 1;
+        kp = readlane_u64(k, pl);
+        const u64 ltm = __ballot(k < kp);
+        rr = __popcll(ltm);
+        const u64 lo = cm & ltm, hi = cm & ~(ltm | (1ull << pl));
+        cm = (rr > target) ? lo : hi;
+    } while (rr != target);
+    return kp;
+}
+
 template <int VPL>
 __device__ __forceinline__ void wave_select_fast(const float (&v)[VPL], const int (&p)[VPL], int cnt, int M,
                                                  u64 *lds /* kSelectLdsU64 per wave */, float &out_v, int &out_p) {
@@ -163,16 +184,7 @@ __device__ __forceinline__ void wave_select_fast(const float (&v)[VPL], const in
         // round the loop is materialised as 0/1 VGPRs with v_cndmask / v_cmp pairs and nops on every round: the
         // selection is bound by exactly that scalar/VALU ping-pong).  Keys are unique, so the lanes above the
         // pivot are the complement of those below it minus the pivot's lane.
-        u64 cm = __ballot(lmin != kKeyMax);
-        u64 T0 = kKeyMax;
-        while (cm != 0) {     // every round removes at least the pivot's lane from the candidates: <= 64 rounds
-            const int pl = __ffsll((long long)cm) - 1;
-            const u64 kp = readlane_u64(lmin, pl);
-            const u64 ltm = __ballot(lmin < kp);
-            const int rr = __popcll(ltm);
-            if (rr == target) { T0 = kp; break; }
-            cm &= (rr > target) ? ltm : ~(ltm | (1ull << pl));
-        }
+        const u64 T0 = wave_kth_lane_key(lmin, target);
         int base = 0;
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
@@ -215,16 +227,7 @@ __device__ __forceinline__ void wave_select_fast(const float (&v)[VPL], const in
         u64 lmin = key[0];
 #pragma unroll
         for (int i = 1; i < VPL; ++i) lmin = key[i] < lmin ? key[i] : lmin;
-        u64 cm = __ballot(lmin != kKeyMax);
-        u64 T0 = kKeyMax;
-        while (cm != 0) {
-            const int pl = __ffsll((long long)cm) - 1;
-            const u64 kp = readlane_u64(lmin, pl);
-            const u64 ltm = __ballot(lmin < kp);
-            const int rr = __popcll(ltm);
-            if (rr == target) { T0 = kp; break; }
-            cm &= (rr > target) ? ltm : ~(ltm | (1ull << pl));
-        }
+        const u64 T0 = wave_kth_lane_key(lmin, target);
         int nsurv = 0;
 #pragma unroll
         for (int i = 0; i < VPL; ++i) nsurv += __popcll(__ballot(key[i] <= T0));
