@@ -155,6 +155,11 @@ int mcq_logits_argmax(const float *x, long B, const void *prepared, float lscale
 int mcq_logits_refine(const float *x, long B, const void *prepared, float lscale_exp, int N, int K, int D,
                       int refine_iters, float *logits_out, int64_t *idx_out, void *workspace, size_t workspace_bytes,
                       void *stream, unsigned flags);
+/* the same, and the indexes a second time as unpacked bytes codes_out uint8 [B][N] (may be NULL): what
+ * mcq_decode_backward_u8(_ex) scans -- the trainer's step needs both and would otherwise convert one into the other */
+int mcq_logits_refine_codes(const float *x, long B, const void *prepared, float lscale_exp, int N, int K, int D,
+                            int refine_iters, float *logits_out, int64_t *idx_out, uint8_t *codes_out, void *workspace,
+                            size_t workspace_bytes, void *stream, unsigned flags);
 
 /* Log-softmax statistics of logits [B][N*K] against indexes int64 [B][N] (:221-240):
  *   lse[b][n] = logsumexp_k;  chosen_sum[n] = sum_b (logit[b][n][idx] - lse);

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("MCQ_LIB_PATH") or os.path.join(_HERE, "lib", "libmcq_
 SYMBOLS = (
     "mcq_abi_version", "mcq_padded_dim", "mcq_prepared_bytes", "mcq_prepared_decode_bytes", "mcq_prepared_mean_offset", "mcq_prepare", "mcq_prepare_dev", "mcq_encode_workspace_bytes",
     "mcq_encode", "mcq_encode_ex", "mcq_refine_indexes", "mcq_decode", "mcq_decode_backward", "mcq_logits", "mcq_logits_workspace_bytes", "mcq_last_encode_launches", "mcq_test_select", "mcq_profile_encode",
-    "mcq_logits_argmax", "mcq_logits_refine", "mcq_loss_workspace_bytes", "mcq_loss_fwd", "mcq_loss_bwd", "mcq_recon_fwd", "mcq_loss_tail",
+    "mcq_logits_argmax", "mcq_logits_refine", "mcq_logits_refine_codes", "mcq_loss_workspace_bytes", "mcq_loss_fwd", "mcq_loss_bwd", "mcq_recon_fwd", "mcq_loss_tail",
     "mcq_jcl_prefix_fwd", "mcq_jcl_prefix_bwd", "mcq_scatter_rows", "mcq_decode_backward_u8",
     "mcq_weight_grad", "mcq_weight_grad_workspace_bytes", "mcq_adam_step", "mcq_loss_head", "mcq_scales_exp",
     "mcq_decode_backward_waves", "mcq_decode_backward_u8_ex", "mcq_loss_bwd_waves", "mcq_loss_bwd_ex", "mcq_grad_tail",
@@ -72,6 +72,8 @@ def lib():
     L.mcq_logits_argmax.argtypes = [vp, i64, vp, f32, i32, i32, i32, vp, vp, vp, sz, vp, ctypes.c_uint]
     L.mcq_logits_refine.restype = i32
     L.mcq_logits_refine.argtypes = [vp, i64, vp, f32, i32, i32, i32, i32, vp, vp, vp, sz, vp, ctypes.c_uint]
+    L.mcq_logits_refine_codes.restype = i32
+    L.mcq_logits_refine_codes.argtypes = [vp, i64, vp, f32, i32, i32, i32, i32, vp, vp, vp, vp, sz, vp, ctypes.c_uint]
     L.mcq_loss_workspace_bytes.restype = sz
     L.mcq_loss_workspace_bytes.argtypes = [i64, i32, i32]
     L.mcq_loss_fwd.restype = i32

@@ -129,6 +129,8 @@ Workspace carve(void *ws, long Bc, int N, int K, int D) {
     w.xe = reinterpret_cast<int *>(take((size_t)fix_round_rows(Bc) * 4));
     const int nlev = tf_levels(N);
     w.tf.ent = nullptr;
+    w.tf.out_i64 = nullptr;
+    w.tf.out_u8 = nullptr;
     for (int v = 0; v < kTfLevels; ++v) {
         w.tf.kc[v] = k_cutoff(K, 1 << v);
         w.tf.pos[v] = nullptr;
@@ -285,12 +287,16 @@ int launch_tf_stage0(int K, int N, const float *G, const float *XC, const uint8_
 int launch_tf_er(int N, const float *G, const float *XC, const uint8_t *idx, const float *xx, long B, int K, float *E, float *R,
                  float *gterms, const int *nact, const int *map, hipStream_t st) {
     const dim3 grid((unsigned)((B + 3) / 4)), block(256);
+    const bool direct = B <= 8192;          // one launch instead of two (E / R of a trainer batch: 4.9 + 4.7 -> about 5 us)
 #define MCQ_ER_CASE(NN)                                                                                                  \
     case NN:                                                                                                             \
-        hipLaunchKernelGGL((k_tf_gram_terms<NN>), dim3((unsigned)(((B + 4 * (64 / NN) - 1) / (4 * (64 / NN))) * NN)), block, 0, st, G, idx, \
-                           B, K, gterms, nact);                                                                          \
-        MCQ_LAUNCH_CHECK();                                                                                              \
-        hipLaunchKernelGGL((k_tf_er<NN>), grid, block, 0, st, gterms, XC, idx, xx, B, K, E, R, nact, map);                 \
+        if (!direct) {                                                                                                   \
+            hipLaunchKernelGGL((k_tf_gram_terms<NN>), dim3((unsigned)(((B + 4 * (64 / NN) - 1) / (4 * (64 / NN))) * NN)), block, 0, st, G, idx, \
+                               B, K, gterms, nact);                                                                      \
+            MCQ_LAUNCH_CHECK();                                                                                          \
+        }                                                                                                                \
+        hipLaunchKernelGGL((k_tf_er<NN>), grid, block, 0, st, gterms, XC, idx, xx, B, K, E, R, nact, map,                  \
+                           direct ? G : static_cast<const float *>(nullptr));                                           \
         break;
     switch (N) {
         MCQ_ER_CASE(1) MCQ_ER_CASE(2) MCQ_ER_CASE(4) MCQ_ER_CASE(8) MCQ_ER_CASE(16) MCQ_ER_CASE(32) MCQ_ER_CASE(64)
@@ -328,10 +334,9 @@ enum { CAT_LOGITS = 0, CAT_XX = 1, CAT_STAGE0 = 2, CAT_XC = 3, CAT_LEVEL0 = 4, C
        CAT_ER = 10 };
 
 // the combines of one refinement pass; lists of K >= 32 hold 16, 16, 32, 32, 64 candidates, of K == 16: 8, 8, 16, 16, 32, 32
-int run_tf_combines(const float *G, const uint8_t *idx_cur, uint8_t *idx_new, const Workspace &w, long B, int N, int K,
-                    const int *nact, hipStream_t st, Prof *prof) {
+int run_tf_combines(const float *G, const uint8_t *idx_cur, uint8_t *idx_new, const Workspace &w, const TfLists &L, long B, int N,
+                    int K, const int *nact, hipStream_t st, Prof *prof) {
     const bool small = (K == 16);
-    const TfLists &L = w.tf;
     const int nlev = tf_levels(N);
     {   // level 0: single codebooks
         const int keep = (N == 2) ? 1 : L.kc[1];
@@ -388,7 +393,8 @@ int run_tf_combines(const float *G, const uint8_t *idx_cur, uint8_t *idx_new, co
 
 int run_encode(const float *x, long B, const void *prepared, float lscale, int N, int K, int D, int iters,
                uint8_t *out_u8, int64_t *out_i64, void *workspace, size_t workspace_bytes, hipStream_t st,
-               Prof *prof, const int64_t *init_idx = nullptr, unsigned flags = 0, float *logits_out = nullptr) {
+               Prof *prof, const int64_t *init_idx = nullptr, unsigned flags = 0, float *logits_out = nullptr,
+               uint8_t *codes_also = nullptr /* with out_i64: the same indexes as unpacked bytes [B][N] */) {
     g_last_launches = 0;
     if (!domain_ok(N, K, D)) return domain_err(N, K, D);
     if (B < 0 || iters < 0 || iters > 60 || (out_u8 == nullptr) == (out_i64 == nullptr)) return MCQ_EINVAL;
@@ -445,6 +451,7 @@ int run_encode(const float *x, long B, const void *prepared, float lscale, int N
             hipError_t e = hipMemsetAsync(w.cnt, 0, 64 * sizeof(int), st);
             if (e != hipSuccess) return (int)e;
         }
+        bool wrote_direct = false;
         for (int it = 0; it < iters; ++it) {
             if (prof) prof->begin();
             rc = launch_tf_er(N, P.G, w.XC, idx_cur, w.xx, Bc, K, w.E, w.R, w.gterms, nact, map_cur, st);
@@ -455,7 +462,15 @@ int run_encode(const float *x, long B, const void *prepared, float lscale, int N
             if (rc) return rc;
             if (prof) prof->end(CAT_STAGE0);
             if (N >= 2) {
-                rc = run_tf_combines(P.G, idx_cur, idx_new, w, Bc, N, K, nact, st, prof);
+                // last pass, nothing to pack or to scatter back: the winners go straight to the caller's arrays (tf_emit)
+                TfLists L = w.tf;
+                const bool direct_out = (it + 1 == iters) && !skip && pack == 1 && prof == nullptr;
+                if (direct_out) {
+                    L.out_i64 = out_i64 ? out_i64 + lo * N : nullptr;
+                    L.out_u8 = out_u8 ? out_u8 + lo * N : (codes_also ? codes_also + lo * N : nullptr);
+                    wrote_direct = true;
+                }
+                rc = run_tf_combines(P.G, idx_cur, idx_new, w, L, Bc, N, K, nact, st, prof);
                 if (rc) return rc;
             }
             if (skip) {
@@ -471,10 +486,12 @@ int run_encode(const float *x, long B, const void *prepared, float lscale, int N
                 nact = w.cnt + it;
             }
         }
+        if (wrote_direct) continue;
         const uint8_t *result = (skip && iters > 0) ? w.final_idx : w.idx;
         const long outn = (out_i64 != nullptr) ? Bc * N : Bc * (N / pack);
         hipLaunchKernelGGL(k_finalize, dim3((unsigned)((outn + 255) / 256)), dim3(256), 0, st, result, Bc, N, pack,
-                           out_u8 ? out_u8 + lo * (N / pack) : nullptr, out_i64 ? out_i64 + lo * N : nullptr);
+                           out_u8 ? out_u8 + lo * (N / pack) : nullptr, out_i64 ? out_i64 + lo * N : nullptr,
+                           codes_also ? codes_also + lo * N : nullptr);
         MCQ_LAUNCH_CHECK();
     }
     return 0;
@@ -855,9 +872,17 @@ int mcq_logits_argmax(const float *x, long B, const void *prepared, float lscale
 int mcq_logits_refine(const float *x, long B, const void *prepared, float lscale_exp, int N, int K, int D, int refine_iters,
                       float *logits_out, int64_t *idx_out, void *workspace, size_t workspace_bytes, void *stream,
                       unsigned flags) {
+    return mcq_logits_refine_codes(x, B, prepared, lscale_exp, N, K, D, refine_iters, logits_out, idx_out, nullptr, workspace,
+                                   workspace_bytes, stream, flags);
+}
+
+int mcq_logits_refine_codes(const float *x, long B, const void *prepared, float lscale_exp, int N, int K, int D, int refine_iters,
+                            float *logits_out, int64_t *idx_out, uint8_t *codes_out, void *workspace, size_t workspace_bytes,
+                            void *stream, unsigned flags) {
     if (B > 0 && (!logits_out || !idx_out)) return MCQ_EINVAL;
     return run_encode(x, B, prepared, lscale_exp, N, K, D, refine_iters, nullptr, idx_out, workspace, workspace_bytes,
-                      static_cast<hipStream_t>(stream), nullptr, nullptr, flags & ~MCQ_ENCODE_SKIP_FIXED_POINTS, logits_out);
+                      static_cast<hipStream_t>(stream), nullptr, nullptr, flags & ~MCQ_ENCODE_SKIP_FIXED_POINTS, logits_out,
+                      codes_out);
 }
 
 namespace {

@@ -430,10 +430,13 @@ __global__ void k_compact(const uint8_t *__restrict__ idx_old, const uint8_t *__
 // encode tail (quantization.py:266-275): uint8 with nibble packing when K == 16
 // (low nibble = even codebook, :269), or int64 indexes.
 __global__ void k_finalize(const uint8_t *__restrict__ idx, long B, int N, int pack, uint8_t *__restrict__ out_u8,
-                           int64_t *__restrict__ out_i64) {
+                           int64_t *__restrict__ out_i64, uint8_t *__restrict__ codes_also) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (out_i64 != nullptr) {
-        if (i < B * N) out_i64[i] = idx[i];
+        if (i < B * N) {
+            out_i64[i] = idx[i];
+            if (codes_also) codes_also[i] = idx[i];
+        }
     } else {
         const int per = N / pack;
         if (i < B * per) {

@@ -26,6 +26,10 @@ struct TfLists {
     uint8_t *pos[kTfLevels];    // [B][N >> v][kc[v]][2]    level v >= 1: positions in the halves' lists
     float *S[kTfLevels];        // [B][N >> v][kc[v]]       scores
     int kc[kTfLevels];
+    // set for the LAST pass of a call when the result can leave in its final form: the winner's entries also go straight
+    // to the caller's arrays (int64 [B][N] and / or uint8 [B][N]) and the encode tail needs no launch of its own
+    int64_t *out_i64;
+    uint8_t *out_u8;
 };
 
 __device__ __forceinline__ float shfl_f(float v, int src) {
@@ -61,7 +65,7 @@ template <int N>
 __global__ void __launch_bounds__(256)
 k_tf_er(const float *__restrict__ gterms, const float *__restrict__ XC, const uint8_t *__restrict__ idx,
         const float *__restrict__ xx, long B, int K, float *__restrict__ E_out, float *__restrict__ R_out,
-        const int *__restrict__ nact, const int *__restrict__ map) {
+        const int *__restrict__ nact, const int *__restrict__ map, const float *__restrict__ Gdirect) {
     constexpr int NT = (N * N + 63) / 64;          // Gram terms per lane
     if (nact) B = *nact;
     const long b = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -76,7 +80,10 @@ k_tf_er(const float *__restrict__ gterms, const float *__restrict__ XC, const ui
     for (int j = 0; j < NT; ++j) {
         const int t = lane + 64 * j;
         const int tc = t < N * N ? t : 0;
-        const float g = gterms[b * (N * N) + tc];
+        // small batches (a trainer step): the Gram entries are gathered here, without the XCD-by-XCD launch in front --
+        // its few microseconds of launch outweigh the L2 misses it avoids
+        const float g = Gdirect ? Gdirect[(size_t)((tc / N) * K + id[tc / N]) * NK + (tc % N) * K + id[tc % N]]
+                                : gterms[b * (N * N) + tc];
         gt[j] = t < N * N ? g : 0.f;
     }
     const int lm = lane < N ? lane : 0;
@@ -344,7 +351,10 @@ __device__ __forceinline__ void tf_emit(const TfLists &L, long b, int N, int nle
         --v;
         g = n >> v;
     }
-    idx_out[b * N + n] = L.ent[(b * N + n) * L.kc[0] + p];
+    const uint8_t e = L.ent[(b * N + n) * L.kc[0] + p];
+    idx_out[b * N + n] = e;
+    if (L.out_i64) L.out_i64[b * N + n] = e;
+    if (L.out_u8) L.out_u8[b * N + n] = e;
 }
 
 // select `keep` of the wave's scores and write the next level's list (or, for the last combine, the result)

@@ -576,7 +576,7 @@ class _DecodeFn(torch.autograd.Function):
 
 class _LossState:
     """What the forward loss kernels leave behind for the backward ones."""
-    __slots__ = ("xf", "idx", "err", "logits", "lse", "parts", "chosen_n", "prob_sum", "count")
+    __slots__ = ("xf", "idx", "codes", "err", "logits", "lse", "parts", "chosen_n", "prob_sum", "count")
 
 
 def _loss_forward_kernels(module, x, iters, blob, lscale_exp, flags, prob_sum=None, count=None) -> _LossState:
@@ -591,6 +591,7 @@ def _loss_forward_kernels(module, x, iters, blob, lscale_exp, flags, prob_sum=No
     st_ = _LossState()
     st_.logits = torch.empty((B, N * K), **f32)
     st_.idx = torch.empty((B, N), dtype=torch.int64, device=dev)
+    st_.codes = torch.empty((B, N), dtype=torch.uint8, device=dev)     # the same indexes as bytes (the scatter scans these)
     ws = module._workspace(B, dev)
     st_.xf = xk.float() if x_fp16 else xk
     # get_data_mean() (:67-75) of the scaled centers: formed by mcq_prepare inside the prepared blob
@@ -606,9 +607,9 @@ def _loss_forward_kernels(module, x, iters, blob, lscale_exp, flags, prob_sum=No
     lws = torch.empty(L.mcq_loss_workspace_bytes(B, N, K), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         st = torch.cuda.current_stream(dev).cuda_stream
-        _lib.check(L.mcq_logits_refine(xk.data_ptr(), B, blob.data_ptr(), lscale_exp, N, K, D, iters, st_.logits.data_ptr(),
-                                       st_.idx.data_ptr(), ws.data_ptr(), ws.numel(), st, flags | (4 if x_fp16 else 0)),
-                   "mcq_logits_refine")
+        _lib.check(L.mcq_logits_refine_codes(xk.data_ptr(), B, blob.data_ptr(), lscale_exp, N, K, D, iters,
+                                             st_.logits.data_ptr(), st_.idx.data_ptr(), st_.codes.data_ptr(), ws.data_ptr(),
+                                             ws.numel(), st, flags | (4 if x_fp16 else 0)), "mcq_logits_refine_codes")
         _lib.check(L.mcq_recon_fwd(st_.xf.data_ptr(), st_.idx.data_ptr(), B, blob.data_ptr(), mean.data_ptr(), N, K, D,
                                    st_.err.data_ptr(), st_.parts[0].data_ptr(), st_.parts[1].data_ptr(), st), "mcq_recon_fwd")
         _lib.check(L.mcq_loss_fwd(st_.logits.data_ptr(), st_.idx.data_ptr(), B, N, K, st_.lse.data_ptr(),
@@ -656,7 +657,7 @@ def _loss_backward_kernels(module, st_: _LossState, g_num, g_chosen, g_prob, cen
             gn = g_num.detach().to(torch.float32).reshape(1)
             cw = centers.detach()
             assert cw.dtype == torch.float32 and cw.is_contiguous()
-            codes = st_.idx.to(torch.uint8)         # the scatter is bound by scanning the index column: 1 byte, not 8
+            codes = st_.codes                       # the scatter is bound by scanning the index column: 1 byte, not 8
             part_c = torch.empty(L.mcq_decode_backward_waves(N, K, D), **f32)
             _lib.check(L.mcq_decode_backward_u8_ex(st_.err.data_ptr(), codes.data_ptr(), B, N, K, D, g_centers.data_ptr(),
                                                    scales.data_ptr(), gn.data_ptr(), 2.0, cw.data_ptr(), part_c.data_ptr(), st),
