@@ -85,6 +85,14 @@ int mcq_prepare(const float *centers, float cscale_exp, const float *weight, con
 int mcq_prepare_dev(const float *centers, const float *scales_exp, const float *weight, const float *bias,
                     int N, int K, int D, void *prepared, void *stream);
 
+/* As mcq_prepare_dev with the scale PARAMETERS read from device memory: centers_scale / logits_scale are the two scalar
+ * parameters themselves, speed = 10 (Quantizer.scale_speed); exp(speed * scale) is formed on the device (the expf of
+ * mcq_scales_exp) in the first kernel of the chain.  scales_exp_out (may be NULL) receives float[2]
+ * {exp(speed*centers_scale), exp(speed*logits_scale)}: what the backward kernels take as `sa` / `scale_dev`.      */
+int mcq_prepare_params(const float *centers, const float *centers_scale, const float *logits_scale, float speed,
+                       const float *weight, const float *bias, int N, int K, int D, void *prepared,
+                       float *scales_exp_out, void *stream);
+
 /* ---- index search ----------------------------------------------------------
  * Replaces Quantizer._compute_indexes (:281-305): learned-logit argmax followed
  * by `refine_iters` passes of Quantizer._refine_indexes (:308-547).
@@ -209,6 +217,11 @@ int mcq_adam_step(float *p, const float *g, float *m, float *v, long n, double l
 int mcq_loss_head(const float *num_part, const float *den_part, long nparts, const float *chosen_n, int N, float batch,
                   float *head, void *stream);
 int mcq_scales_exp(const float *centers_scale, const float *logits_scale, float speed, float *out2, void *stream);
+/* mcq_loss_head followed by mcq_loss_tail in ONE launch (same results; for a single process, where no all-reduce of the
+ * sums sits between the two) */
+int mcq_loss_head_tail(const float *num_part, const float *den_part, long nparts, const float *chosen_n, int N, float batch,
+                       float *head, const float *prob_sum, const float *count, int K, float entropy_scale, float *losses,
+                       float *g, float *g_prob, void *stream);
 
 /* The scalar gradients without library reductions.  mcq_decode_backward_u8_ex: mcq_decode_backward_u8 whose stored
  * rows are scaled by sa[0]*sb[0]*sc (device floats sa, sb; host float sc) and which also leaves, per wave, the share of

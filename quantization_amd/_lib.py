@@ -12,11 +12,11 @@ LIB_PATH = os.environ.get("MCQ_LIB_PATH") or os.path.join(_HERE, "lib", "libmcq_
 
 # every symbol include/mcq.h declares
 SYMBOLS = (
-    "mcq_abi_version", "mcq_padded_dim", "mcq_prepared_bytes", "mcq_prepared_decode_bytes", "mcq_prepared_mean_offset", "mcq_prepare", "mcq_prepare_dev", "mcq_encode_workspace_bytes",
+    "mcq_abi_version", "mcq_padded_dim", "mcq_prepared_bytes", "mcq_prepared_decode_bytes", "mcq_prepared_mean_offset", "mcq_prepare", "mcq_prepare_dev", "mcq_prepare_params", "mcq_encode_workspace_bytes",
     "mcq_encode", "mcq_encode_ex", "mcq_refine_indexes", "mcq_decode", "mcq_decode_backward", "mcq_logits", "mcq_logits_workspace_bytes", "mcq_last_encode_launches", "mcq_test_select", "mcq_profile_encode",
     "mcq_logits_argmax", "mcq_logits_refine", "mcq_logits_refine_codes", "mcq_loss_workspace_bytes", "mcq_loss_fwd", "mcq_loss_bwd", "mcq_recon_fwd", "mcq_loss_tail",
     "mcq_jcl_prefix_fwd", "mcq_jcl_prefix_bwd", "mcq_scatter_rows", "mcq_decode_backward_u8",
-    "mcq_weight_grad", "mcq_weight_grad_workspace_bytes", "mcq_adam_step", "mcq_loss_head", "mcq_scales_exp",
+    "mcq_weight_grad", "mcq_weight_grad_workspace_bytes", "mcq_adam_step", "mcq_loss_head", "mcq_loss_head_tail", "mcq_scales_exp",
     "mcq_decode_backward_waves", "mcq_decode_backward_u8_ex", "mcq_loss_bwd_waves", "mcq_loss_bwd_ex", "mcq_grad_tail",
 )
 
@@ -48,6 +48,8 @@ def lib():
     L.mcq_prepare.argtypes = [vp, f32, vp, vp, i32, i32, i32, vp, vp]
     L.mcq_prepare_dev.restype = i32
     L.mcq_prepare_dev.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp]
+    L.mcq_prepare_params.restype = i32
+    L.mcq_prepare_params.argtypes = [vp, vp, vp, f32, vp, vp, i32, i32, i32, vp, vp, vp]
     L.mcq_prepared_mean_offset.restype = sz
     L.mcq_prepared_mean_offset.argtypes = [i32, i32, i32]
     L.mcq_encode_workspace_bytes.restype = sz
@@ -101,6 +103,8 @@ def lib():
     L.mcq_adam_step.argtypes = [vp, vp, vp, vp, i64, f64, f64, f64, f64, f64, f64, f64, vp]
     L.mcq_loss_head.restype = i32
     L.mcq_loss_head.argtypes = [vp, vp, i64, vp, i32, f32, vp, vp]
+    L.mcq_loss_head_tail.restype = i32
+    L.mcq_loss_head_tail.argtypes = [vp, vp, i64, vp, i32, f32, vp, vp, vp, i32, f32, vp, vp, vp, vp]
     L.mcq_scales_exp.restype = i32
     L.mcq_scales_exp.argtypes = [vp, vp, f32, vp, vp]
     L.mcq_decode_backward_waves.restype = i64

@@ -182,13 +182,24 @@ thread_local int g_last_launches = 0;
     } while (0)
 
 // rows -> limb planes + exponents (+ |row|^2): the operands of every product of the path
+FixRowsArgs fix_rows_args(const float *src, int xh, long R, int D, long ld, int8_t *planes, int *exps, float *xx,
+                          const float *bias_src = nullptr, float *bias_dst = nullptr) {
+    return FixRowsArgs{src, xh, R, fix_round_rows(R), D, ld, fix_round_cols(D), planes, exps, xx, bias_src, bias_dst};
+}
+
 int launch_fix_rows(const float *src, int xh, long R, int D, long ld, int8_t *planes, int *exps, float *xx, hipStream_t st,
                     const float *bias_src = nullptr, float *bias_dst = nullptr) {
-    const long Rp = fix_round_rows(R);
+    const FixRowsArgs a = fix_rows_args(src, xh, R, D, ld, planes, exps, xx, bias_src, bias_dst);
     // four rows per workgroup, one per wave (16 rows per workgroup and 256-byte runs into the planes measured slower:
     // 0.086 vs 0.071 ms at 65,536 x 512)
-    hipLaunchKernelGGL(k_fix_rows<4>, dim3((unsigned)(Rp / 4)), dim3(256), 0, st, src, xh, R, Rp, D, ld, fix_round_cols(D),
-                       planes, exps, xx, bias_src, bias_dst);
+    hipLaunchKernelGGL(k_fix_rows<4>, dim3((unsigned)(a.Rp / 4)), dim3(256), 0, st, a);
+    MCQ_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_fix_rows2(const FixRowsArgs &a, const FixRowsArgs &b, hipStream_t st) {
+    const unsigned na = (unsigned)(a.Rp / 4), nb = (unsigned)(b.Rp / 4);
+    hipLaunchKernelGGL(k_fix_rows2<4>, dim3(na + nb), dim3(256), 0, st, a, b, na);
     MCQ_LAUNCH_CHECK();
     return 0;
 }
@@ -544,7 +555,8 @@ size_t mcq_prepared_bytes(int N, int K, int D) {
 }
 
 static int prepare_impl(const float *centers, float cscale_exp, const float *scales_dev, const float *weight,
-                        const float *bias, int N, int K, int D, void *prepared, void *stream) {
+                        const float *bias, int N, int K, int D, void *prepared, void *stream, const float *raw_cs = nullptr,
+                        const float *raw_ls = nullptr, float speed = 0.f, float *scales_out2 = nullptr) {
     if (!domain_ok(N, K, D)) return domain_err(N, K, D);
     if (!centers || !prepared || ((weight == nullptr) != (bias == nullptr))) return MCQ_EINVAL;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -555,7 +567,8 @@ static int prepare_impl(const float *centers, float cscale_exp, const float *sca
     const unsigned grid = (unsigned)((rows + 3) / 4);
     hipLaunchKernelGGL(k_prepare_rows, dim3(grid), dim3(256), 0, st, centers, cscale_exp, 1, rows, D, Dp,
                        reinterpret_cast<float *>(b + l.offC), reinterpret_cast<float *>(b + l.offQ), scales_dev,
-                       scales_dev ? reinterpret_cast<float *>(b + l.offScales) : static_cast<float *>(nullptr));
+                       (scales_dev || raw_cs) ? reinterpret_cast<float *>(b + l.offScales) : static_cast<float *>(nullptr), raw_cs,
+                       raw_ls, speed, scales_out2);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     if (!weight) return 0;      // decode only: the scaled centers are all mcq_decode reads (mcq_prepared_decode_bytes)
@@ -564,15 +577,12 @@ static int prepare_impl(const float *centers, float cscale_exp, const float *sca
                        reinterpret_cast<float *>(b + l.offMean));
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
-    // the scaled centers (and the classifier rows) as limb planes: the tables of the fixed-point products
-    int rc = launch_fix_rows(C, 0, rows, Dp, Dp, reinterpret_cast<int8_t *>(b + l.offCf), reinterpret_cast<int *>(b + l.offCe),
-                             nullptr, st);
+    // the scaled centers and the classifier rows as limb planes (the tables of the fixed-point products), one launch; the
+    // bias rides along
+    int rc = launch_fix_rows2(fix_rows_args(C, 0, rows, Dp, Dp, reinterpret_cast<int8_t *>(b + l.offCf), reinterpret_cast<int *>(b + l.offCe), nullptr),
+                              fix_rows_args(weight, 0, rows, D, D, reinterpret_cast<int8_t *>(b + l.offWf), reinterpret_cast<int *>(b + l.offWe),
+                                            nullptr, bias, reinterpret_cast<float *>(b + l.offBias)), st);
     if (rc) return rc;
-    {
-        rc = launch_fix_rows(weight, 0, rows, D, D, reinterpret_cast<int8_t *>(b + l.offWf), reinterpret_cast<int *>(b + l.offWe),
-                             nullptr, st, bias, reinterpret_cast<float *>(b + l.offBias));      // (the bias rides along)
-        if (rc) return rc;
-    }
     {
         // Gram matrix of the scaled centers: the x.C product with the centers themselves as the frames
         rc = launch_xc(reinterpret_cast<const int8_t *>(b + l.offCf), reinterpret_cast<const int *>(b + l.offCe), rows,
@@ -602,6 +612,14 @@ int mcq_prepare_dev(const float *centers, const float *scales_exp, const float *
                     int K, int D, void *prepared, void *stream) {
     if (!scales_exp) return MCQ_EINVAL;
     return prepare_impl(centers, 1.0f, scales_exp, weight, bias, N, K, D, prepared, stream);
+}
+
+int mcq_prepare_params(const float *centers, const float *centers_scale, const float *logits_scale, float speed,
+                       const float *weight, const float *bias, int N, int K, int D, void *prepared, float *scales_exp_out,
+                       void *stream) {
+    if (!centers_scale || !logits_scale) return MCQ_EINVAL;
+    return prepare_impl(centers, 1.0f, nullptr, weight, bias, N, K, D, prepared, stream, centers_scale, logits_scale, speed,
+                        scales_exp_out);
 }
 
 size_t mcq_encode_workspace_bytes(long B, int N, int K, int D) {
@@ -1018,6 +1036,16 @@ int mcq_adam_step(float *p, const float *g, float *m, float *v, long n, double l
     return 0;
 }
 
+int mcq_loss_head_tail(const float *num_part, const float *den_part, long nparts, const float *chosen_n, int N, float batch,
+                       float *head, const float *prob_sum, const float *count, int K, float entropy_scale, float *losses,
+                       float *g, float *g_prob, void *stream) {
+    if (!is_pow2(K) || K < 16 || K > 256 || N < 1) return MCQ_EUNSUPPORTED;
+    if (nparts <= 0 || !num_part || !den_part || !chosen_n || !head || !prob_sum || !count || !losses || !g || !g_prob) return MCQ_EINVAL;
+    hipLaunchKernelGGL(k_loss_head_tail, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), num_part, den_part, nparts,
+                       chosen_n, N, batch, head, prob_sum, count, K, entropy_scale, losses, g, g_prob);
+    MCQ_LAUNCH_CHECK();
+    return 0;
+}
 int mcq_loss_head(const float *num_part, const float *den_part, long nparts, const float *chosen_n, int N, float batch,
                   float *head, void *stream) {
     if (nparts <= 0 || N <= 0 || !num_part || !den_part || !chosen_n || !head) return MCQ_EINVAL;

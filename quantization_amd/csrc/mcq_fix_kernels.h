@@ -48,15 +48,35 @@ __device__ __forceinline__ int fix_q(float v, int e) {
 // limbs to LDS as [plane][row][16 bytes], then runs of RW x 16 bytes (RW rows of one plane) to the planes.
 // src: fp32 rows of `ld` floats (or fp16 rows of `ld` halves when xh), D valid columns; rows >= R are written as zeros.
 // bias_src / bias_dst: optional copy of R floats riding along (the classifier's bias into `prepared`).
+struct FixRowsArgs {
+    const float *src;
+    int xh;
+    long R, Rp;
+    int D;
+    long ld;
+    int Dq;
+    int8_t *planes;
+    int *exps;
+    float *xx;
+    const float *bias_src;
+    float *bias_dst;
+};
+
 template <int RW>
-__global__ void __launch_bounds__(256)
-k_fix_rows(const float *__restrict__ src, int xh, long R, long Rp, int D, long ld, int Dq, int8_t *__restrict__ planes,
-           int *__restrict__ exps, float *__restrict__ xx, const float *__restrict__ bias_src, float *__restrict__ bias_dst) {
+__device__ __forceinline__ void fix_rows_body(const FixRowsArgs &a, unsigned bid) {
+    const float *__restrict__ src = a.src;
+    const int xh = a.xh, D = a.D, Dq = a.Dq;
+    const long R = a.R, Rp = a.Rp, ld = a.ld;
+    int8_t *__restrict__ planes = a.planes;
+    int *__restrict__ exps = a.exps;
+    float *__restrict__ xx = a.xx;
+    const float *__restrict__ bias_src = a.bias_src;
+    float *__restrict__ bias_dst = a.bias_dst;
     constexpr int RPW = RW / 4;
     __shared__ __attribute__((aligned(16))) unsigned tile[128 * RW * 4];      // [plane of the block][row][4 words]
     __shared__ int es[RW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long row0 = (long)blockIdx.x * RW;
+    const long row0 = (long)bid * RW;
     if (bias_src && tid < RW && row0 + tid < R) bias_dst[row0 + tid] = bias_src[row0 + tid];
     const _Float16 *srch = reinterpret_cast<const _Float16 *>(src);
     const bool vec_ok = ((ld & 3) == 0) && ((D & 3) == 0) && ((reinterpret_cast<uintptr_t>(src) & (xh ? 7 : 15)) == 0);
@@ -145,6 +165,16 @@ k_fix_rows(const float *__restrict__ src, int xh, long R, long Rp, int D, long l
         }
         __syncthreads();
     }
+}
+
+template <int RW>
+__global__ void __launch_bounds__(256) k_fix_rows(const FixRowsArgs a) { fix_rows_body<RW>(a, blockIdx.x); }
+
+// two matrices in one launch (the centers and the classifier rows of mcq_prepare: one launch boundary less per trainer step)
+template <int RW>
+__global__ void __launch_bounds__(256) k_fix_rows2(const FixRowsArgs a, const FixRowsArgs b, unsigned blocks_a) {
+    if (blockIdx.x < blocks_a) fix_rows_body<RW>(a, blockIdx.x);
+    else fix_rows_body<RW>(b, blockIdx.x - blocks_a);
 }
 
 // ------------------------------------------------------------------ the GEMM

@@ -371,13 +371,25 @@ k_test_select(const float *__restrict__ scores, int cnt, float *__restrict__ out
 __global__ void k_prepare_rows(const float *__restrict__ src, float scale, int apply_scale, long rows, int D,
                                int Dp, float *__restrict__ dst, float *__restrict__ Q,
                                const float *__restrict__ scale_ptr /* overrides `scale` when non-null */,
-                               float *__restrict__ scales_out /* optional: scale_ptr[0..1] is copied here */) {
+                               float *__restrict__ scales_out /* optional: scale_ptr[0..1] is copied here */,
+                               const float *__restrict__ raw_cs = nullptr, const float *__restrict__ raw_ls = nullptr,
+                               float speed = 0.f, float *__restrict__ scales_out2 = nullptr) {
     const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = lane_id();
     if (scale_ptr) {
         scale = *scale_ptr;
         if (scales_out && row == 0 && lane < 2) scales_out[lane] = scale_ptr[lane];
+    }
+    if (raw_cs) {
+        // the scale PARAMETERS themselves (mcq_prepare_params): exp(speed * centers_scale) is formed here by every wave (the
+        // same expf as mcq_scales_exp: same bits) and row 0 leaves both factors for the kernels that follow
+        scale = expf(*raw_cs * speed);
+        if (row == 0 && lane == 0) {
+            const float ls = expf(*raw_ls * speed);
+            if (scales_out) { scales_out[0] = scale; scales_out[1] = ls; }
+            if (scales_out2) { scales_out2[0] = scale; scales_out2[1] = ls; }
+        }
     }
     const float *s = src + row * D;
     float *d = dst + row * Dp;

@@ -254,15 +254,14 @@ k_recon_fwd(const float *__restrict__ x, const int64_t *__restrict__ idx, long B
 //   total = rel + logprob + entropy_scale * logits_entropy:
 //   g[0] = d total / d num = 1 / (den + 1e-20);  g[1] = d total / d chosen = -1 / (Btot * N);
 //   g_prob[n][k] = d total / d prob_sum[n][k] = entropy_scale * (log(pbar) + 1) / (ref * N * Btot)
-__global__ void __launch_bounds__(256)
-k_loss_tail(const float *__restrict__ sums, const float *__restrict__ prob_sum, const float *__restrict__ count, int N,
-            int K, float entropy_scale, float *__restrict__ losses, float *__restrict__ g, float *__restrict__ g_prob) {
+__device__ __forceinline__ void loss_tail_body(float num, float den, float chosen, float Bt, const float *__restrict__ prob_sum,
+                                               const float *__restrict__ count, int N, int K, float entropy_scale,
+                                               float *__restrict__ losses, float *__restrict__ g, float *__restrict__ g_prob) {
     // wave w takes the codebooks w, w + 4, ...: a codebook's two entropies are 64 lane-partial sums (entries k = lane,
     // lane + 64, ... ascending) and one xor butterfly -- no workgroup barrier inside the loop (the first version reduced
     // each codebook through a 256-thread LDS tree, nine barriers per codebook: 17.5 us at 16 codebooks)
     __shared__ float s_hl[64], s_hi[64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float num = sums[0], den = sums[1], chosen = sums[2], Bt = sums[3];
     const float ref = logf((float)K);
     const float gscale = entropy_scale / (ref * (float)N * Bt);
     for (int n = wave; n < N; n += 4) {
@@ -290,6 +289,12 @@ k_loss_tail(const float *__restrict__ sums, const float *__restrict__ prob_sum, 
         g[0] = 1.0f / (den + 1.0e-20f);
         g[1] = -1.0f / (Bt * (float)N);
     }
+}
+
+__global__ void __launch_bounds__(256)
+k_loss_tail(const float *__restrict__ sums, const float *__restrict__ prob_sum, const float *__restrict__ count, int N,
+            int K, float entropy_scale, float *__restrict__ losses, float *__restrict__ g, float *__restrict__ g_prob) {
+    loss_tail_body(sums[0], sums[1], sums[2], sums[3], prob_sum, count, N, K, entropy_scale, losses, g, g_prob);
 }
 
 // ------------------------------------------------------------ JointCodebookLoss

@@ -209,10 +209,9 @@ k_adam(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m
 // ------------------------------------------------------------- small pieces
 // head[4] = {sum num_part, sum den_part, sum chosen_n, Bf}: the sums mcq_loss_tail consumes (one workgroup; each sum
 // is 256 strided partials added in thread order, then a fixed tree)
-__global__ void __launch_bounds__(256)
-k_loss_head(const float *__restrict__ num_part, const float *__restrict__ den_part, long nparts,
-            const float *__restrict__ chosen_n, int N, float Bf, float *__restrict__ head) {
-    __shared__ float s[3][256];
+__device__ __forceinline__ void loss_head_body(const float *__restrict__ num_part, const float *__restrict__ den_part, long nparts,
+                                               const float *__restrict__ chosen_n, int N, float Bf, float *__restrict__ head,
+                                               float (&s)[3][256]) {
     const int t = threadIdx.x;
     float a = 0.f, b = 0.f, c = 0.f;
     for (long i = t; i < nparts; i += 256) { a += num_part[i]; b += den_part[i]; }
@@ -224,6 +223,28 @@ k_loss_head(const float *__restrict__ num_part, const float *__restrict__ den_pa
         __syncthreads();
     }
     if (t == 0) { head[0] = s[0][0]; head[1] = s[1][0]; head[2] = s[2][0]; head[3] = Bf; }
+}
+
+__global__ void __launch_bounds__(256)
+k_loss_head(const float *__restrict__ num_part, const float *__restrict__ den_part, long nparts,
+            const float *__restrict__ chosen_n, int N, float Bf, float *__restrict__ head) {
+    __shared__ float s[3][256];
+    loss_head_body(num_part, den_part, nparts, chosen_n, N, Bf, head, s);
+}
+
+// k_loss_head and k_loss_tail in one launch (a single process: no all-reduce of the sums between them); the sums pass
+// through shared memory, `head` is written as well
+__global__ void __launch_bounds__(256)
+k_loss_head_tail(const float *__restrict__ num_part, const float *__restrict__ den_part, long nparts,
+                 const float *__restrict__ chosen_n, int N, float Bf, float *__restrict__ head,
+                 const float *__restrict__ prob_sum, const float *__restrict__ count, int K, float entropy_scale,
+                 float *__restrict__ losses, float *__restrict__ g, float *__restrict__ g_prob) {
+    __shared__ float s[3][256];
+    loss_head_body(num_part, den_part, nparts, chosen_n, N, Bf, head, s);
+    __syncthreads();
+    const float num = s[0][0], den = s[1][0], chosen = s[2][0];
+    __syncthreads();
+    loss_tail_body(num, den, chosen, Bf, prob_sum, count, N, K, entropy_scale, losses, g, g_prob);
 }
 
 // The two scalar gradients from per-wave partials (fixed order: 1,024 strided sums, then a tree):

@@ -211,11 +211,11 @@ class Quantizer(nn.Module):
                 scales = torch.empty(2, dtype=torch.float32, device=dev)     # {exp(speed*centers_scale), exp(speed*logits_scale)}
                 cs, ls = self.centers_scale.detach(), self.logits_scale.detach()
                 assert cs.dtype == torch.float32 and ls.dtype == torch.float32
-                _lib.check(L.mcq_scales_exp(cs.data_ptr(), ls.data_ptr(), self.scale_speed, scales.data_ptr(), st), "mcq_scales_exp")
                 scale_flags = 2             # MCQ_ENCODE_LSCALE_FROM_PREPARED
                 cscale_exp = lscale_exp = 1.0
-                rc = L.mcq_prepare_dev(centers.data_ptr(), scales.data_ptr(), weight.data_ptr(), bias.data_ptr(), N, K,
-                                       D, blob.data_ptr(), st)
+                # exp(speed * scale) is formed by the first kernel of the chain (no launch of its own)
+                rc = L.mcq_prepare_params(centers.data_ptr(), cs.data_ptr(), ls.data_ptr(), self.scale_speed, weight.data_ptr(),
+                                          bias.data_ptr(), N, K, D, blob.data_ptr(), scales.data_ptr(), st)
             else:
                 both = torch.stack([self.centers_scale.detach(), self.logits_scale.detach()]).to(torch.float32)
                 both = both.to("cpu")       # both scalars in one device->host copy; exp on the host

@@ -253,13 +253,18 @@ class QuantizerTrainer(object):
             out = torch.empty(6 + N * K, dtype=torch.float32, device=dev)
             with torch.cuda.device(dev):
                 st = torch.cuda.current_stream(dev).cuda_stream
-                _lib.check(L.mcq_loss_head(st_.parts[0].data_ptr(), st_.parts[1].data_ptr(), st_.parts.shape[1],
-                                           st_.chosen_n.data_ptr(), N, float(B), head.data_ptr(), st), "mcq_loss_head")
                 if self._collective():
+                    _lib.check(L.mcq_loss_head(st_.parts[0].data_ptr(), st_.parts[1].data_ptr(), st_.parts.shape[1],
+                                               st_.chosen_n.data_ptr(), N, float(B), head.data_ptr(), st), "mcq_loss_head")
                     dist = self._dist()
                     dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=self.process_group)
-                _lib.check(L.mcq_loss_tail(head.data_ptr(), prob_sum.data_ptr(), count.data_ptr(), N, K, self.entropy_scale,
-                                           out.data_ptr(), out[4:].data_ptr(), out[6:].data_ptr(), st), "mcq_loss_tail")
+                    _lib.check(L.mcq_loss_tail(head.data_ptr(), prob_sum.data_ptr(), count.data_ptr(), N, K, self.entropy_scale,
+                                               out.data_ptr(), out[4:].data_ptr(), out[6:].data_ptr(), st), "mcq_loss_tail")
+                else:       # nothing to exchange between the sums and the losses: one launch
+                    _lib.check(L.mcq_loss_head_tail(st_.parts[0].data_ptr(), st_.parts[1].data_ptr(), st_.parts.shape[1],
+                                                    st_.chosen_n.data_ptr(), N, float(B), head.data_ptr(), prob_sum.data_ptr(),
+                                                    count.data_ptr(), K, self.entropy_scale, out.data_ptr(), out[4:].data_ptr(),
+                                                    out[6:].data_ptr(), st), "mcq_loss_head_tail")
             names = ("centers", "centers_scale", "to_logits.weight", "to_logits.bias", "logits_scale")
             params = (q.centers, q.centers_scale, q.to_logits.weight, q.to_logits.bias, q.logits_scale)
             views = None
