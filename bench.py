@@ -491,6 +491,16 @@ def main():
         out["fp16_input"] = {"vectors_per_s": round(B / t16, 1),
                              "codes_equal_widened_input": bool(torch.equal(c16, q.encode(x16.float(), iters)))}
 
+    # ---- secondary: latency of small encodes (a serving-sized request: the launch chain, not the kernels, is what it waits for)
+    with torch.no_grad():
+        lat = {}
+        for bs in (64, 4096):
+            xs = x[:bs].contiguous()
+            q.encode(xs, iters)
+            lat["batch_%d_ms" % bs] = round(timed(lambda: q.encode(xs, iters), 50) * 1e3, 4)
+        lat["note"] = "Quantizer.encode of one small batch, 5 passes, median of 50 synchronised calls (host launch + ~30 dependent kernels)"
+        out["small_batch_latency"] = lat
+
     # ---- secondary: QuantizerTrainer.step (BASELINE config E shape on one GPU: dim 512, 8 bytes, batch 4096)
     if world == 1:
         ms_t, _ = trainer_leg(dev, D, N, 4096, 60)
