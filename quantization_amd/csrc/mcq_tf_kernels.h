@@ -614,19 +614,18 @@ constexpr int tf_leaf_lds_floats(int KCH) { return 4 * (KCH * KCH + 64) + 128; }
 
 // combine of level 1: siblings X = 2g, Y = 2g + 1 (pairs of codebooks).  One wave per (b, g).
 template <int KCH, int KC>
-__global__ void __launch_bounds__(64)
-k_tf_pair1(const float *__restrict__ G, const uint8_t *__restrict__ idx, const float *__restrict__ E, TfLists L, long B,
-           int N, int K, int keep, uint8_t *__restrict__ idx_final, const int *__restrict__ nact) {
+__device__ __forceinline__ void tf_pair1_body(unsigned bid, float *leaf, const float *__restrict__ G, const uint8_t *__restrict__ idx,
+                                              const float *__restrict__ E, const TfLists &L, long B, int N, int K, int keep,
+                                              uint8_t *__restrict__ idx_final, const int *__restrict__ nact) {
     constexpr int VPL = KC * KC / 64;
     // the selection's scratch reuses the leaf tables' LDS (dead once the level-1 table sits in registers): 5.6 instead of
-    // 7.3 KB per single-wave workgroup, i.e. 29 instead of 22 waves per CU -- the kernel is bound by latency, not by bytes
+    // 7.3 KB per single-wave workgroup, i.e. 29 instead of 22 waves per CU
     static_assert(tf_leaf_lds_floats(KCH) * 4 >= kSelectLdsU64 * 8, "");
-    __shared__ __attribute__((aligned(16))) float leaf[tf_leaf_lds_floats(KCH)];
     u64 *scratch = reinterpret_cast<u64 *>(leaf);
     if (nact) B = *nact;
     const int Gout = N >> 2;
-    const int g = (int)(blockIdx.x & (unsigned)(Gout - 1));
-    const long b = (long)(blockIdx.x >> __builtin_ctz((unsigned)Gout));
+    const int g = (int)(bid & (unsigned)(Gout - 1));
+    const long b = (long)(bid >> __builtin_ctz((unsigned)Gout));
     if (b >= B) return;
     const int lane = lane_id();
     const int X = 2 * g, Y = X + 1, G1 = N >> 1;
@@ -649,18 +648,25 @@ k_tf_pair1(const float *__restrict__ G, const uint8_t *__restrict__ idx, const f
     tf_finish<VPL>(sv, sp, keep, KC, scratch, L, 2, b, N, g, idx_final);
 }
 
+template <int KCH, int KC>
+__global__ void __launch_bounds__(64)
+k_tf_pair1(const float *__restrict__ G, const uint8_t *__restrict__ idx, const float *__restrict__ E, TfLists L, long B,
+           int N, int K, int keep, uint8_t *__restrict__ idx_final, const int *__restrict__ nact) {
+    __shared__ __attribute__((aligned(16))) float leaf[tf_leaf_lds_floats(KCH)];
+    tf_pair1_body<KCH, KC>(blockIdx.x, leaf, G, idx, E, L, B, N, K, keep, idx_final, nact);
+}
+
 // T_1 of COUSIN pairs under the siblings of a higher level -> tabs[b][t][KC*KC].  One wave per (b, t); workgroup id
 // mod ntab = t, so an XCD reads the leaf blocks of its own tables only.  Under sibling pair g each side has `per`
 // level-1 groups: t = (g * per + a) * per + c  ->  X = 2 g per + a,  Y = (2 g + 1) per + c.
 template <int KCH, int KC>
-__global__ void __launch_bounds__(64)
-k_tf_table1(const float *__restrict__ G, const uint8_t *__restrict__ idx, TfLists L, long B, int N, int K, int ntab,
-            int per, float *__restrict__ tabs, const int *__restrict__ nact) {
+__device__ __forceinline__ void tf_table1_body(unsigned bid, float *leaf, const float *__restrict__ G, const uint8_t *__restrict__ idx,
+                                               const TfLists &L, long B, int N, int K, int ntab, int per, float *__restrict__ tabs,
+                                               const int *__restrict__ nact) {
     constexpr int VPL = KC * KC / 64;
-    __shared__ __attribute__((aligned(16))) float leaf[tf_leaf_lds_floats(KCH)];
     if (nact) B = *nact;
-    const int t = (int)(blockIdx.x & (unsigned)(ntab - 1));
-    const long b = (long)(blockIdx.x >> __builtin_ctz((unsigned)ntab));
+    const int t = (int)(bid & (unsigned)(ntab - 1));
+    const long b = (long)(bid >> __builtin_ctz((unsigned)ntab));
     if (b >= B) return;
     const int lane = lane_id();
     const int psh = __builtin_ctz((unsigned)per);
@@ -675,6 +681,26 @@ k_tf_table1(const float *__restrict__ G, const uint8_t *__restrict__ idx, TfList
 #pragma unroll
         for (int v = 0; v < VPL; ++v) dst[v] = tv[v];
     }
+}
+
+template <int KCH, int KC>
+__global__ void __launch_bounds__(64)
+k_tf_table1(const float *__restrict__ G, const uint8_t *__restrict__ idx, TfLists L, long B, int N, int K, int ntab,
+            int per, float *__restrict__ tabs, const int *__restrict__ nact) {
+    __shared__ __attribute__((aligned(16))) float leaf[tf_leaf_lds_floats(KCH)];
+    tf_table1_body<KCH, KC>(blockIdx.x, leaf, G, idx, L, B, N, K, ntab, per, tabs, nact);
+}
+
+// The sibling combines of level 1 and the cousin tables the level-2 combine needs, in ONE launch: both read the level-1 lists
+// and nothing of each other; the workgroup-to-XCD mapping of both kinds is what it is in their own launches (the pair
+// blocks are a multiple of 8).
+template <int KCH, int KC>
+__global__ void __launch_bounds__(64)
+k_tf_level1(const float *__restrict__ G, const uint8_t *__restrict__ idx, const float *__restrict__ E, TfLists L, long B, int N,
+            int K, int keep, int ntab, int per, float *__restrict__ tabs, const int *__restrict__ nact, unsigned pair_blocks) {
+    __shared__ __attribute__((aligned(16))) float leaf[tf_leaf_lds_floats(KCH)];
+    if (blockIdx.x < pair_blocks) tf_pair1_body<KCH, KC>(blockIdx.x, leaf, G, idx, E, L, B, N, K, keep, nullptr, nact);
+    else tf_table1_body<KCH, KC>(blockIdx.x - pair_blocks, leaf, G, idx, L, B, N, K, ntab, per, tabs, nact);
 }
 
 // copy COUNT tables of M floats each from global memory to LDS (wave-cooperative).  The loads go out in batches of up to
