@@ -131,6 +131,9 @@ Workspace carve(void *ws, long Bc, int N, int K, int D) {
     w.tf.ent = nullptr;
     w.tf.out_i64 = nullptr;
     w.tf.out_u8 = nullptr;
+    w.tf.erG = w.tf.erXC = w.tf.erxx = nullptr;
+    w.tf.erE = w.tf.erR = nullptr;
+    w.tf.erK = 0;
     for (int v = 0; v < kTfLevels; ++v) {
         w.tf.kc[v] = k_cutoff(K, 1 << v);
         w.tf.pos[v] = nullptr;
@@ -476,10 +479,17 @@ int run_encode(const float *x, long B, const void *prepared, float lscale, int N
             if (e != hipSuccess) return (int)e;
         }
         bool wrote_direct = false;
+        // E / R of pass it + 1 can be formed by the wave that emits the indexes of pass it (tf_emit), which saves that pass
+        // its two E / R launches: 4, 8 or 16 codebooks, no compaction of the vectors between the passes, not under the profiler
+        const bool er_in_emit = !skip && prof == nullptr && (N == 4 || N == 8 || N == 16);
+        bool er_ready = false;
         for (int it = 0; it < iters; ++it) {
             if (prof) prof->begin();
-            rc = launch_tf_er(N, P.G, w.XC, idx_cur, w.xx, Bc, K, w.E, w.R, w.gterms, nact, map_cur, st);
-            if (rc) return rc;
+            if (!er_ready) {
+                rc = launch_tf_er(N, P.G, w.XC, idx_cur, w.xx, Bc, K, w.E, w.R, w.gterms, nact, map_cur, st);
+                if (rc) return rc;
+            }
+            er_ready = false;
             if (prof) { prof->end(CAT_ER); prof->begin(); }
             rc = launch_tf_stage0(K, N, P.G, w.XC, idx_cur, w.R, P.Q, Bc, (N == 1) ? 1 : w.tf.kc[0], w.tf.ent, w.tf.S[0],
                                   (N == 1) ? idx_new : nullptr, nact, map_cur, st);
@@ -488,6 +498,10 @@ int run_encode(const float *x, long B, const void *prepared, float lscale, int N
             if (N >= 2) {
                 // last pass, nothing to pack or to scatter back: the winners go straight to the caller's arrays (tf_emit)
                 TfLists L = w.tf;
+                if (er_in_emit && it + 1 < iters) {
+                    L.erG = P.G; L.erXC = w.XC; L.erxx = w.xx; L.erE = w.E; L.erR = w.R; L.erK = K;
+                    er_ready = true;
+                }
                 const bool direct_out = (it + 1 == iters) && !skip && pack == 1 && prof == nullptr;
                 if (direct_out) {
                     L.out_i64 = out_i64 ? out_i64 + lo * N : nullptr;

@@ -30,6 +30,11 @@ struct TfLists {
     // to the caller's arrays (int64 [B][N] and / or uint8 [B][N]) and the encode tail needs no launch of its own
     int64_t *out_i64;
     uint8_t *out_u8;
+    // set for every pass but the last: the wave that emits a vector's new indexes also forms E and R[n] of the NEXT pass from
+    // them (tf_er_wave: the arithmetic of k_tf_er), so that pass needs neither k_tf_gram_terms nor k_tf_er
+    const float *erG, *erXC, *erxx;
+    float *erE, *erR;
+    int erK;
 };
 
 __device__ __forceinline__ float shfl_f(float v, int src) {
@@ -61,33 +66,32 @@ k_tf_gram_terms(const float *__restrict__ G, const uint8_t *__restrict__ idx, lo
 
 // One wave per vector: E = |x_err|^2 and R[n] = |x_err - old_n|^2 (:401-409) from the N*N Gram terms, N entries of XC
 // and |x|^2 (oracle "TABLE FORM", E, R).
-template <int N>
-__global__ void __launch_bounds__(256)
-k_tf_er(const float *__restrict__ gterms, const float *__restrict__ XC, const uint8_t *__restrict__ idx,
-        const float *__restrict__ xx, long B, int K, float *__restrict__ E_out, float *__restrict__ R_out,
-        const int *__restrict__ nact, const int *__restrict__ map, const float *__restrict__ Gdirect) {
+// The indexes come from memory (`id`) or, when the wave has just chosen them, from lane m of `e_reg` (FROM_REG).
+template <int N, bool FROM_REG>
+__device__ __forceinline__ void tf_er_wave(long b, long bx, const uint8_t *__restrict__ id, int e_reg,
+                                           const float *__restrict__ gterms, const float *__restrict__ Gdirect,
+                                           const float *__restrict__ XC, const float *__restrict__ xx, int K,
+                                           float *__restrict__ E_out, float *__restrict__ R_out) {
     constexpr int NT = (N * N + 63) / 64;          // Gram terms per lane
-    if (nact) B = *nact;
-    const long b = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= B) return;
     const int lane = lane_id();
     const int NK = N * K;
-    const uint8_t *id = idx + b * N;
-    const long bx = map ? (long)map[b] : b;          // row of the per-call arrays (XC, xx)
+#define MCQ_ER_CODE(m) (FROM_REG ? __builtin_amdgcn_ds_bpermute((m) << 2, e_reg) : (int)id[FROM_REG ? 0 : (m)])
     // term t = m * N + m2 (lane t % 64, slot t / 64) is G[o_m][o_m2]
     float gt[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int t = lane + 64 * j;
         const int tc = t < N * N ? t : 0;
-        // small batches (a trainer step): the Gram entries are gathered here, without the XCD-by-XCD launch in front --
-        // its few microseconds of launch outweigh the L2 misses it avoids
-        const float g = Gdirect ? Gdirect[(size_t)((tc / N) * K + id[tc / N]) * NK + (tc % N) * K + id[tc % N]]
+        // without the XCD-by-XCD launch in front (small batches; the wave that has just chosen the indexes) the Gram entries
+        // are gathered here
+        const float g = Gdirect ? Gdirect[(size_t)((tc / N) * K + MCQ_ER_CODE(tc / N)) * NK + (tc % N) * K + MCQ_ER_CODE(tc % N)]
                                 : gterms[b * (N * N) + tc];
         gt[j] = t < N * N ? g : 0.f;
     }
     const int lm = lane < N ? lane : 0;
-    const float xt = lane < N ? XC[(size_t)bx * NK + lm * K + id[lm]] : 0.f;        // XC[o_m] in lane m
+    const int clm = MCQ_ER_CODE(lm);
+#undef MCQ_ER_CODE
+    const float xt = lane < N ? XC[(size_t)bx * NK + lm * K + clm] : 0.f;        // XC[o_m] in lane m
     const float xxb = xx[bx];
     float gp = gt[0];
 #pragma unroll
@@ -107,6 +111,18 @@ k_tf_er(const float *__restrict__ gterms, const float *__restrict__ XC, const ui
     const float Rv = (E - 2.0f * xo) + gnn;
     if (lane < N) R_out[b * N + lane] = Rv;
     if (lane == 0) E_out[b] = E;
+}
+
+template <int N>
+__global__ void __launch_bounds__(256)
+k_tf_er(const float *__restrict__ gterms, const float *__restrict__ XC, const uint8_t *__restrict__ idx,
+        const float *__restrict__ xx, long B, int K, float *__restrict__ E_out, float *__restrict__ R_out,
+        const int *__restrict__ nact, const int *__restrict__ map, const float *__restrict__ Gdirect) {
+    if (nact) B = *nact;
+    const long b = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const long bx = map ? (long)map[b] : b;          // row of the per-call arrays (XC, xx)
+    tf_er_wave<N, false>(b, bx, idx + b * N, 0, gterms, Gdirect, XC, xx, K, E_out, R_out);
 }
 
 // ------------------------------------------------------------------ stage 0
@@ -337,24 +353,37 @@ __device__ __forceinline__ void tf_leaf(const float *__restrict__ G, int NK, int
     }
 }
 
+// E and R[n] of the next pass for the vector whose new indexes sit in lanes 0 .. N - 1 of `e` (tf_emit).  A function of its
+// own (not inlined: the three instantiations inside every last-combine kernel sent the compiler's CFG simplification into
+// a crash).
+__device__ __attribute__((noinline)) void tf_er_next(const float *G, const float *XC, const float *xx, int K, float *E, float *R,
+                                                     long b, int N, int e) {
+    if (N == 8) tf_er_wave<8, true>(b, b, nullptr, e, nullptr, G, XC, xx, K, E, R);
+    else if (N == 4) tf_er_wave<4, true>(b, b, nullptr, e, nullptr, G, XC, xx, K, E, R);
+    else if (N == 16) tf_er_wave<16, true>(b, b, nullptr, e, nullptr, G, XC, xx, K, E, R);
+}
+
 // The winner's leaves, codebook by codebook (:468-469): lane n walks down the position tree.
 // `win` = position a*kc + b of the winner among the pairs of the two top-level lists.
 __device__ __forceinline__ void tf_emit(const TfLists &L, long b, int N, int nlev, int win, uint8_t *__restrict__ idx_out) {
     const int n = lane_id();
-    if (n >= N) return;
-    int v = nlev - 1;
-    int g = n >> v;
-    int p = (g & 1) ? win % L.kc[v] : win / L.kc[v];
-    while (v > 0) {
-        const int child = (n >> (v - 1)) & 1;
-        p = L.pos[v][((b * (N >> v) + g) * L.kc[v] + p) * 2 + child];
-        --v;
-        g = n >> v;
+    int e = 0;
+    if (n < N) {
+        int v = nlev - 1;
+        int g = n >> v;
+        int p = (g & 1) ? win % L.kc[v] : win / L.kc[v];
+        while (v > 0) {
+            const int child = (n >> (v - 1)) & 1;
+            p = L.pos[v][((b * (N >> v) + g) * L.kc[v] + p) * 2 + child];
+            --v;
+            g = n >> v;
+        }
+        e = L.ent[(b * N + n) * L.kc[0] + p];
+        idx_out[b * N + n] = (uint8_t)e;
+        if (L.out_i64) L.out_i64[b * N + n] = e;
+        if (L.out_u8) L.out_u8[b * N + n] = (uint8_t)e;
     }
-    const uint8_t e = L.ent[(b * N + n) * L.kc[0] + p];
-    idx_out[b * N + n] = e;
-    if (L.out_i64) L.out_i64[b * N + n] = e;
-    if (L.out_u8) L.out_u8[b * N + n] = e;
+    if (L.erE) tf_er_next(L.erG, L.erXC, L.erxx, L.erK, L.erE, L.erR, b, N, e);      // E, R[n] of the next pass, from the indexes in lanes 0 .. N - 1
 }
 
 // select `keep` of the wave's scores and write the next level's list (or, for the last combine, the result)
