@@ -365,13 +365,18 @@ int run_tf_combines(const float *G, const uint8_t *idx_cur, uint8_t *idx_new, co
     // the level-1 combines and the cousin tables of level 2 share a launch (k_tf_level1): same workgroup-to-XCD mapping as the two
     // launches, one boundary and one tail less (5.95 -> 5.86 ms per encode of 65,536 vectors, 0.55 -> 0.51 ms at 4,096)
     const bool fuse_l1 = (N >= 8) && (prof == nullptr);      // (mcq_profile_encode times the two kinds of workgroups as two launches)
+    // 16 codebooks: the 16 cousin tables of level 3 ride along (into tabs[1]).  With 256-entry codebooks at 65,536 vectors
+    // that launch is 0.93 ms long and the merge bought nothing (23.99 / 23.92 against 23.90 / 24.0 ms per encode); a trainer
+    // step of the first phase (16 x 16 codebooks, 4,096 vectors) saves a 29 us launch per pass
+    const bool fuse_l3 = fuse_l1 && N == 16 && small;
     if (fuse_l1) {
         const int keep = L.kc[2];
         const int groups2 = N >> 3, per1 = 2, ntab1 = groups2 * per1 * per1;
-        const unsigned pair_blocks = (unsigned)(B * (N / 4));
-        const dim3 grid(pair_blocks + (unsigned)(B * ntab1));
-        if (small) hipLaunchKernelGGL((k_tf_level1<8, 8>), grid, dim3(64), 0, st, G, idx_cur, w.E, L, B, N, K, keep, ntab1, per1, w.tabs[0], nact, pair_blocks);
-        else hipLaunchKernelGGL((k_tf_level1<16, 16>), grid, dim3(64), 0, st, G, idx_cur, w.E, L, B, N, K, keep, ntab1, per1, w.tabs[0], nact, pair_blocks);
+        const unsigned pair_blocks = (unsigned)(B * (N / 4)), tab_blocks = (unsigned)(B * ntab1);
+        const int ntab3 = fuse_l3 ? 16 : 1, per3 = fuse_l3 ? 4 : 1;
+        const dim3 grid(pair_blocks + tab_blocks + (fuse_l3 ? (unsigned)(B * ntab3) : 0u));
+        if (small) hipLaunchKernelGGL((k_tf_level1<8, 8>), grid, dim3(64), 0, st, G, idx_cur, w.E, L, B, N, K, keep, ntab1, per1, w.tabs[0], nact, pair_blocks, tab_blocks, ntab3, per3, w.tabs[1]);
+        else hipLaunchKernelGGL((k_tf_level1<16, 16>), grid, dim3(64), 0, st, G, idx_cur, w.E, L, B, N, K, keep, ntab1, per1, w.tabs[0], nact, pair_blocks, tab_blocks, ntab3, per3, w.tabs[1]);
         MCQ_LAUNCH_CHECK();
     } else if (N >= 4) {   // level 1: pairs of codebooks
         const int keep = (N == 4) ? 1 : L.kc[2];
@@ -390,15 +395,16 @@ int run_tf_combines(const float *G, const uint8_t *idx_cur, uint8_t *idx_new, co
         uint8_t *fin = last ? idx_new : nullptr;
         const int per1 = 1 << (v - 1), ntab1 = groups * per1 * per1;
         if (prof) prof->begin();
-        if (!(fuse_l1 && v == 2)) {     // (level 2's tables came with the level-1 combines)
+        if (!(fuse_l1 && v == 2) && !(fuse_l3 && v == 3)) {     // (these tables came with the level-1 combines)
             if (small) hipLaunchKernelGGL((k_tf_table1<8, 8>), dim3((unsigned)(B * ntab1)), dim3(64), 0, st, G, idx_cur, L, B, N, K, ntab1, per1, w.tabs[0], nact);
             else hipLaunchKernelGGL((k_tf_table1<16, 16>), dim3((unsigned)(B * ntab1)), dim3(64), 0, st, G, idx_cur, L, B, N, K, ntab1, per1, w.tabs[0], nact);
             MCQ_LAUNCH_CHECK();
         }
         if (N == 16 && v == 3) {       // two groups of eight: levels 2 and 3 in one kernel, tables in LDS
             if (prof) { prof->end(CAT_TABLES + 2); prof->begin(); }
-            if (small) hipLaunchKernelGGL((k_tf_comb3<8, 16, 16>), dim3((unsigned)B), dim3(256), 0, st, idx_cur, w.E, L, B, N, w.tabs[0], idx_new, nact);
-            else hipLaunchKernelGGL((k_tf_comb3<16, 32, 32>), dim3((unsigned)B), dim3(256), 0, st, idx_cur, w.E, L, B, N, w.tabs[0], idx_new, nact);
+            const float *t3 = fuse_l3 ? w.tabs[1] : w.tabs[0];
+            if (small) hipLaunchKernelGGL((k_tf_comb3<8, 16, 16>), dim3((unsigned)B), dim3(256), 0, st, idx_cur, w.E, L, B, N, t3, idx_new, nact);
+            else hipLaunchKernelGGL((k_tf_comb3<16, 32, 32>), dim3((unsigned)B), dim3(256), 0, st, idx_cur, w.E, L, B, N, t3, idx_new, nact);
             MCQ_LAUNCH_CHECK();
             if (prof) prof->end(CAT_COMBINE + 2);
             continue;

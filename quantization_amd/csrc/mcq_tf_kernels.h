@@ -726,10 +726,12 @@ k_tf_table1(const float *__restrict__ G, const uint8_t *__restrict__ idx, TfList
 template <int KCH, int KC>
 __global__ void __launch_bounds__(64)
 k_tf_level1(const float *__restrict__ G, const uint8_t *__restrict__ idx, const float *__restrict__ E, TfLists L, long B, int N,
-            int K, int keep, int ntab, int per, float *__restrict__ tabs, const int *__restrict__ nact, unsigned pair_blocks) {
+            int K, int keep, int ntab, int per, float *__restrict__ tabs, const int *__restrict__ nact, unsigned pair_blocks,
+            unsigned tab_blocks, int ntab2, int per2, float *__restrict__ tabs2) {
     __shared__ __attribute__((aligned(16))) float leaf[tf_leaf_lds_floats(KCH)];
     if (blockIdx.x < pair_blocks) tf_pair1_body<KCH, KC>(blockIdx.x, leaf, G, idx, E, L, B, N, K, keep, nullptr, nact);
-    else tf_table1_body<KCH, KC>(blockIdx.x - pair_blocks, leaf, G, idx, L, B, N, K, ntab, per, tabs, nact);
+    else if (blockIdx.x < pair_blocks + tab_blocks) tf_table1_body<KCH, KC>(blockIdx.x - pair_blocks, leaf, G, idx, L, B, N, K, ntab, per, tabs, nact);
+    else tf_table1_body<KCH, KC>(blockIdx.x - pair_blocks - tab_blocks, leaf, G, idx, L, B, N, K, ntab2, per2, tabs2, nact);   // (16 codebooks: the tables of level 3 as well)
 }
 
 // copy COUNT tables of M floats each from global memory to LDS (wave-cooperative).  The loads go out in batches of up to
