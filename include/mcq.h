@@ -49,7 +49,8 @@ extern "C" {
 #define MCQ_EUNSUPPORTED (-2) /* outside the supported (K, N) domain             */
 #define MCQ_EWORKSPACE (-3) /* workspace smaller than mcq_encode_workspace_bytes */
 
-#define MCQ_ABI_VERSION 5   /* 5: mcq_prepared_decode_bytes, 64 codebooks for every codebook size; 4: fixed-point products: `prepared` holds limb planes of the centers and the classifier
+#define MCQ_ABI_VERSION 5   /* 5: mcq_prepared_decode_bytes, 64 codebooks for every codebook size, and (additions) mcq_prepare_params,
+                               mcq_logits_refine_codes, mcq_loss_head_tail; 4: fixed-point products: `prepared` holds limb planes of the centers and the classifier
                                (mcq_prepared_bytes changed), workspaces hold those of the frames (the workspace sizes
                                depend on D), mcq_logits takes a workspace, mcq_logits_workspace_bytes is new */
 int mcq_abi_version(void);
