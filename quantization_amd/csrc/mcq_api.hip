@@ -26,13 +26,13 @@ int k_cutoff(int K, int L) {
 }
 
 struct Prepared {
-    const float *C, *Q, *bias, *scales, *G;
+    const float *C, *Q, *bias, *scales, *G, *mean;
     const int8_t *Cf, *Wf;      // limb planes of the scaled centers / of to_logits.weight (mcq_fix_kernels.h)
     const int *Ce, *We;         // their row exponents
 };
 
 struct PreparedLayout {
-    size_t offC, offQ, offCf, offCe, offWf, offWe, offBias, offScales, offMean, offG, total;
+    size_t offC, offQ, offCf, offCe, offWf, offWe, offBias, offScales, offMean, offCMean, offG, total;
 };
 
 PreparedLayout prepared_layout(int N, int K, int D) {
@@ -48,7 +48,8 @@ PreparedLayout prepared_layout(int N, int K, int D) {
     l.offBias = align256(l.offWe + exps);
     l.offScales = align256(l.offBias + nk * 4);   // float[2] {cscale_exp, lscale_exp} (mcq_prepare_dev)
     l.offMean = align256(l.offScales + 8);        // get_data_mean() of the scaled centers, float[Dp]
-    l.offG = align256(l.offMean + Dp * 4);        // Gram matrix G[nk][nk] of the scaled centers
+    l.offCMean = align256(l.offMean + Dp * 4);    // the codebooks' own means mu_n, float[N][Dp] (mean = mu_0 + mu_1 + ...)
+    l.offG = align256(l.offCMean + (size_t)N * Dp * 4);   // Gram matrix G[nk][nk] of the CENTERED rows C[n][k] - mu_n
     l.total = align256(l.offG + nk * nk * 4);
     return l;
 }
@@ -58,7 +59,7 @@ Prepared prepared_view(const void *p, int N, int K, int D) {
     const char *b = static_cast<const char *>(p);
     return Prepared{reinterpret_cast<const float *>(b + l.offC), reinterpret_cast<const float *>(b + l.offQ),
                     reinterpret_cast<const float *>(b + l.offBias), reinterpret_cast<const float *>(b + l.offScales),
-                    reinterpret_cast<const float *>(b + l.offG),
+                    reinterpret_cast<const float *>(b + l.offG), reinterpret_cast<const float *>(b + l.offMean),
                     reinterpret_cast<const int8_t *>(b + l.offCf), reinterpret_cast<const int8_t *>(b + l.offWf),
                     reinterpret_cast<const int *>(b + l.offCe), reinterpret_cast<const int *>(b + l.offWe)};
 }
@@ -68,8 +69,10 @@ struct Workspace {
     int *map[2], *cnt;
     float *E, *R, *xx, *XC;                   // per vector: |x_err|^2, |x_err - old_n|^2, |x|^2, x.C products
     float *gterms;                            // per vector: the N*N Gram entries G[o_m][o_m2] of the current indexes
-    int8_t *xf;                               // limb planes of the frames of a chunk
+    int8_t *xf;                               // limb planes of the CENTERED frames of a chunk (x - mean: the x.C product)
     int *xe;                                  // and their row exponents
+    int8_t *xfr;                              // limb planes of the frames as they are (the logits product)
+    int *xer;
     float *tabs[2];                           // group tables of two consecutive levels (ping-pong)
     TfLists tf;                               // candidate lists of every level
 };
@@ -95,10 +98,10 @@ size_t workspace_per_vector(int N, int K, int D) {
     // idx x4, maps, E, xx, R, XC, lists (entries / positions / scores: <= 16 + 2*16 + 4*16 bytes per codebook and level), tabs x2,
     // the frame as limb planes + its exponent, the N*N Gram terms of E / R
     return 4 * (size_t)N + 8 + 8 + 4 * (size_t)N + 4 * (size_t)N * K + (size_t)tf_levels(N) * N * (16 + 2 * 16 + 4 * 16) + 64 +
-           2 * 4 * tf_tab_floats(N, K) + 4 * (size_t)fix_round_cols(D) + 4 + 4 * (size_t)N * N;
+           2 * 4 * tf_tab_floats(N, K) + 2 * (4 * (size_t)fix_round_cols(D) + 4) + 4 * (size_t)N * N;
 }
 // alignment of the carved arrays + the rows the limb planes are padded by (to a multiple of 128)
-size_t workspace_slack(int D) { return 48 * 256 + (size_t)kFixTile * (4 * (size_t)fix_round_cols(D) + 4); }
+size_t workspace_slack(int D) { return 52 * 256 + 2 * (size_t)kFixTile * (4 * (size_t)fix_round_cols(D) + 4); }
 
 // default chunk: 65,536 vectors, fewer when a vector's share of the workspace is large (N >= 32), so that the workspace
 // mcq_encode_workspace_bytes asks for stays near 2 GB
@@ -127,6 +130,8 @@ Workspace carve(void *ws, long Bc, int N, int K, int D) {
     w.XC = reinterpret_cast<float *>(take((size_t)Bc * N * K * 4));
     w.xf = reinterpret_cast<int8_t *>(take(fix_plane_bytes(Bc, D)));
     w.xe = reinterpret_cast<int *>(take((size_t)fix_round_rows(Bc) * 4));
+    w.xfr = reinterpret_cast<int8_t *>(take(fix_plane_bytes(Bc, D)));
+    w.xer = reinterpret_cast<int *>(take((size_t)fix_round_rows(Bc) * 4));
     const int nlev = tf_levels(N);
     w.tf.ent = nullptr;
     w.tf.out_i64 = nullptr;
@@ -186,13 +191,17 @@ thread_local int g_last_launches = 0;
 
 // rows -> limb planes + exponents (+ |row|^2): the operands of every product of the path
 FixRowsArgs fix_rows_args(const float *src, int xh, long R, int D, long ld, int8_t *planes, int *exps, float *xx,
-                          const float *bias_src = nullptr, float *bias_dst = nullptr) {
-    return FixRowsArgs{src, xh, R, fix_round_rows(R), D, ld, fix_round_cols(D), planes, exps, xx, bias_src, bias_dst};
+                          const float *bias_src = nullptr, float *bias_dst = nullptr, const float *sub = nullptr,
+                          long sub_per = 0, long sub_ld = 0, int8_t *planes_raw = nullptr, int *exps_raw = nullptr) {
+    return FixRowsArgs{src, xh, R, fix_round_rows(R), D, ld, fix_round_cols(D), planes, exps, xx, bias_src, bias_dst,
+                       sub, sub_per, sub_ld, planes_raw, exps_raw};
 }
 
+// sub != nullptr: the rows are centered by sub[0 .. D) (the frames of the search: x - mean); planes_raw / exps_raw then
+// receive the limbs of the rows as they are
 int launch_fix_rows(const float *src, int xh, long R, int D, long ld, int8_t *planes, int *exps, float *xx, hipStream_t st,
-                    const float *bias_src = nullptr, float *bias_dst = nullptr) {
-    const FixRowsArgs a = fix_rows_args(src, xh, R, D, ld, planes, exps, xx, bias_src, bias_dst);
+                    const float *sub = nullptr, int8_t *planes_raw = nullptr, int *exps_raw = nullptr) {
+    const FixRowsArgs a = fix_rows_args(src, xh, R, D, ld, planes, exps, xx, nullptr, nullptr, sub, 0, 0, planes_raw, exps_raw);
     // four rows per workgroup, one per wave (16 rows per workgroup and 256-byte runs into the planes measured slower:
     // 0.086 vs 0.071 ms at 65,536 x 512)
     hipLaunchKernelGGL(k_fix_rows<4>, dim3((unsigned)(a.Rp / 4)), dim3(256), 0, st, a);
@@ -452,9 +461,12 @@ int run_encode(const float *x, long B, const void *prepared, float lscale, int N
         const float *xc = xh ? reinterpret_cast<const float *>(reinterpret_cast<const uint16_t *>(x) + lo * D) : x + lo * D;
         int rc;
         // the frames as limb planes (and |x|^2), once per call: both products of the call read them
-        if (init_idx == nullptr || iters > 0) {
+        // (the logits product reads the frames as they are, the x.C product the centered ones, x - mean; |x - mean|^2 rides along)
+        const bool need_raw = (init_idx == nullptr), need_cen = (iters > 0);
+        if (need_raw || need_cen) {
             if (prof) prof->begin();
-            rc = launch_fix_rows(xc, xh, Bc, D, D, w.xf, w.xe, w.xx, st);
+            if (need_cen) rc = launch_fix_rows(xc, xh, Bc, D, D, w.xf, w.xe, w.xx, st, P.mean, need_raw ? w.xfr : nullptr, need_raw ? w.xer : nullptr);
+            else rc = launch_fix_rows(xc, xh, Bc, D, D, w.xfr, w.xer, nullptr, st);
             if (rc) return rc;
             if (prof) prof->end(CAT_XX);
         }
@@ -464,7 +476,7 @@ int run_encode(const float *x, long B, const void *prepared, float lscale, int N
             MCQ_LAUNCH_CHECK();
         } else {
             if (prof) prof->begin();
-            rc = launch_logits(w.xf, w.xe, Bc, P, N, K, D, lscale,
+            rc = launch_logits(w.xfr, w.xer, Bc, P, N, K, D, lscale,
                                (flags & MCQ_ENCODE_LSCALE_FROM_PREPARED) ? P.scales + 1 : nullptr,
                                logits_out ? logits_out + lo * N * K : nullptr, w.idx, st);
             if (rc) return rc;
@@ -599,20 +611,24 @@ static int prepare_impl(const float *centers, float cscale_exp, const float *sca
     const int Dp = round_up16(D);
     const unsigned grid = (unsigned)((rows + 3) / 4);
     hipLaunchKernelGGL(k_prepare_rows, dim3(grid), dim3(256), 0, st, centers, cscale_exp, 1, rows, D, Dp,
-                       reinterpret_cast<float *>(b + l.offC), reinterpret_cast<float *>(b + l.offQ), scales_dev,
+                       reinterpret_cast<float *>(b + l.offC), static_cast<float *>(nullptr) /* Q: of the centered rows, below */, scales_dev,
                        (scales_dev || raw_cs) ? reinterpret_cast<float *>(b + l.offScales) : static_cast<float *>(nullptr), raw_cs,
                        raw_ls, speed, scales_out2);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     if (!weight) return 0;      // decode only: the scaled centers are all mcq_decode reads (mcq_prepared_decode_bytes)
     const float *C = reinterpret_cast<const float *>(b + l.offC);
+    float *cmean = reinterpret_cast<float *>(b + l.offCMean);
     hipLaunchKernelGGL(k_centers_mean, dim3((unsigned)(Dp / 16)), dim3(1024), 0, st, C, N, K, Dp,
-                       reinterpret_cast<float *>(b + l.offMean));
+                       reinterpret_cast<float *>(b + l.offMean), cmean);
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     // the scaled centers and the classifier rows as limb planes (the tables of the fixed-point products), one launch; the
     // bias rides along
-    int rc = launch_fix_rows2(fix_rows_args(C, 0, rows, Dp, Dp, reinterpret_cast<int8_t *>(b + l.offCf), reinterpret_cast<int *>(b + l.offCe), nullptr),
+    // (the centers enter every table of the search with their codebook's mean taken out -- oracle "TABLE FORM", centering; their
+    // sums of squares Q come out of the same pass)
+    int rc = launch_fix_rows2(fix_rows_args(C, 0, rows, Dp, Dp, reinterpret_cast<int8_t *>(b + l.offCf), reinterpret_cast<int *>(b + l.offCe),
+                                            reinterpret_cast<float *>(b + l.offQ), nullptr, nullptr, cmean, K, Dp),
                               fix_rows_args(weight, 0, rows, D, D, reinterpret_cast<int8_t *>(b + l.offWf), reinterpret_cast<int *>(b + l.offWe),
                                             nullptr, bias, reinterpret_cast<float *>(b + l.offBias)), st);
     if (rc) return rc;

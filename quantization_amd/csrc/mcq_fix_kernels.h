@@ -60,6 +60,14 @@ struct FixRowsArgs {
     float *xx;
     const float *bias_src;
     float *bias_dst;
+    // centering (oracle "TABLE FORM": every table of the search is formed from rows / frames with the codebook means taken
+    // out): row r is written as src[r] - sub[(r / sub_per) * sub_ld] (one fp32 subtraction per element; sub_per == 0: every
+    // row takes sub[0 .. D)); planes / exps / xx receive the CENTERED row.  planes_raw / exps_raw (optional) receive the
+    // limbs of the row as it is: the logits product reads the frame itself (:277-279).
+    const float *sub;
+    long sub_per, sub_ld;
+    int8_t *planes_raw;
+    int *exps_raw;
 };
 
 template <int RW>
@@ -67,14 +75,14 @@ __device__ __forceinline__ void fix_rows_body(const FixRowsArgs &a, unsigned bid
     const float *__restrict__ src = a.src;
     const int xh = a.xh, D = a.D, Dq = a.Dq;
     const long R = a.R, Rp = a.Rp, ld = a.ld;
-    int8_t *__restrict__ planes = a.planes;
-    int *__restrict__ exps = a.exps;
     float *__restrict__ xx = a.xx;
     const float *__restrict__ bias_src = a.bias_src;
     float *__restrict__ bias_dst = a.bias_dst;
+    const float *__restrict__ sub = a.sub;
+    const bool two = (sub != nullptr) && (a.planes_raw != nullptr);      // both the centered and the raw limbs
     constexpr int RPW = RW / 4;
     __shared__ __attribute__((aligned(16))) unsigned tile[128 * RW * 4];      // [plane of the block][row][4 words]
-    __shared__ int es[RW];
+    __shared__ int es[2][RW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long row0 = (long)bid * RW;
     if (bias_src && tid < RW && row0 + tid < R) bias_dst[row0 + tid] = bias_src[row0 + tid];
@@ -89,81 +97,112 @@ __device__ __forceinline__ void fix_rows_body(const FixRowsArgs &a, unsigned bid
             if (4 * q + c < D) v[c] = xh ? (float)srch[row * ld + 4 * q + c] : src[row * ld + 4 * q + c];
         return v;
     };
+    // what is taken out of group q of a row (zeros past D and for the padding rows, which stay zero rows)
+    const bool sub_vec = sub && ((a.sub_ld & 3) == 0) && ((D & 3) == 0) && ((reinterpret_cast<uintptr_t>(sub) & 15) == 0);
+    auto sub4 = [&](long row, int q) -> f32x4 {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (!sub || row >= R || 4 * q >= D) return v;
+        const float *sp = sub + (a.sub_per ? (row / a.sub_per) * a.sub_ld : 0);
+        if (sub_vec) return *reinterpret_cast<const f32x4 *>(sp + 4 * q);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (4 * q + c < D) v[c] = sp[4 * q + c];
+        return v;
+    };
     const bool cached = (RW == 4) && D <= 1024;      // (16-row workgroups measured slower with the rows held, 0.126 vs 0.083 ms, and slower than 4-row ones either way)
     f32x4 cache[RW == 4 ? RPW : 1][4];
 #pragma unroll
     for (int rr = 0; rr < RPW; ++rr) {
         const long row = row0 + RPW * wave + rr;
-        float m = 0.f, pe = 0.f;
+        float m = 0.f, pe = 0.f, mr = 0.f;
         if (cached) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) cache[RW == 4 ? rr : 0][j] = load4(row, lane + 64 * j);
+            for (int j = 0; j < 4; ++j) cache[RW == 4 ? rr : 0][j] = load4(row, lane + 64 * j);      // (the row as it is; the mean comes off where it is used)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 raw = cache[RW == 4 ? rr : 0][j];
+                const f32x4 v = sub ? raw - sub4(row, lane + 64 * j) : raw;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    m = fmaxf(m, fabsf(cache[RW == 4 ? rr : 0][j][c]));
-                    pe = fmaf(cache[RW == 4 ? rr : 0][j][c], cache[RW == 4 ? rr : 0][j][c], pe);      // (groups past D are zeros: fmaf(0, 0, pe) == pe)
+                    m = fmaxf(m, fabsf(v[c]));
+                    pe = fmaf(v[c], v[c], pe);      // (groups past D are zeros: fmaf(0, 0, pe) == pe)
+                    mr = fmaxf(mr, fabsf(raw[c]));
                 }
+            }
         } else {
             for (int q = lane; q < (D + 3) / 4; q += 64) {
-                const f32x4 v = load4(row, q);
+                const f32x4 raw = load4(row, q);
+                const f32x4 v = sub ? raw - sub4(row, q) : raw;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     m = fmaxf(m, fabsf(v[c]));
                     pe = fmaf(v[c], v[c], pe);
+                    mr = fmaxf(mr, fabsf(raw[c]));
                 }
             }
         }
         for (int s = 32; s >= 1; s >>= 1) m = fmaxf(m, __shfl_xor(m, s, 64));
+        if (two)
+            for (int s = 32; s >= 1; s >>= 1) mr = fmaxf(mr, __shfl_xor(mr, s, 64));
         if (xx) pe = wave_sum_butterfly(pe);
         if (lane == 0) {
             const int be = (int)((__float_as_uint(m) >> 23) & 0xff);
             const int e = (be < 1 ? 1 : be) - 126;
-            es[RPW * wave + rr] = e;
-            if (row < Rp) exps[row] = e;
+            es[0][RPW * wave + rr] = e;
+            if (row < Rp) a.exps[row] = e;
             if (xx && row < R) xx[row] = pe;
+            if (two) {
+                const int ber = (int)((__float_as_uint(mr) >> 23) & 0xff);
+                const int er = (ber < 1 ? 1 : ber) - 126;
+                es[1][RPW * wave + rr] = er;
+                if (row < Rp) a.exps_raw[row] = er;
+            }
         }
     }
     __syncthreads();
-    for (int c0 = 0; c0 < Dq; c0 += 512) {
-        const int ncol = (Dq - c0 < 512) ? Dq - c0 : 512;          // columns of this block (a multiple of 128)
+    for (int set = 0; set < (two ? 2 : 1); ++set) {      // 0: the (centered) row, 1: the row as it is
+        int8_t *__restrict__ planes = set ? a.planes_raw : a.planes;
+        for (int c0 = 0; c0 < Dq; c0 += 512) {
+            const int ncol = (Dq - c0 < 512) ? Dq - c0 : 512;          // columns of this block (a multiple of 128)
 #pragma unroll
-        for (int rr = 0; rr < RPW; ++rr) {
-            const int rl = RPW * wave + rr;
-            const int e = es[rl];
+            for (int rr = 0; rr < RPW; ++rr) {
+                const int rl = RPW * wave + rr;
+                const int e = es[set][rl];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int q = lane + 64 * j;
-                if (q >= ncol / 4) continue;
-                const f32x4 v = cached ? cache[RW == 4 ? rr : 0][((c0 >> 9) * 2 + j) & 3] : load4(row0 + rl, c0 / 4 + q);
-                unsigned w[4] = {0u, 0u, 0u, 0u};
+                for (int j = 0; j < 2; ++j) {
+                    const int q = lane + 64 * j;
+                    if (q >= ncol / 4) continue;
+                    f32x4 v;
+                    v = cached ? cache[RW == 4 ? rr : 0][((c0 >> 9) * 2 + j) & 3] : load4(row0 + rl, c0 / 4 + q);
+                    if (sub && set == 0) v = v - sub4(row0 + rl, c0 / 4 + q);
+                    unsigned w[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    int r = fix_q(v[c], e);
+                    for (int c = 0; c < 4; ++c) {
+                        int r = fix_q(v[c], e);
 #pragma unroll
-                    for (int i = 3; i >= 1; --i) {
-                        const int l = (int)(int8_t)(r & 0xff);
-                        w[i] |= (unsigned)(l & 0xff) << (8 * c);
-                        r = (r - l) >> 8;
+                        for (int i = 3; i >= 1; --i) {
+                            const int l = (int)(int8_t)(r & 0xff);
+                            w[i] |= (unsigned)(l & 0xff) << (8 * c);
+                            r = (r - l) >> 8;
+                        }
+                        w[0] |= (unsigned)(r & 0xff) << (8 * c);
                     }
-                    w[0] |= (unsigned)(r & 0xff) << (8 * c);
-                }
-                const int chunk = q >> 2, word = q & 3;
+                    const int chunk = q >> 2, word = q & 3;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) tile[((chunk * 4 + i) * RW + rl) * 4 + word] = w[i];
+                    for (int i = 0; i < 4; ++i) tile[((chunk * 4 + i) * RW + rl) * 4 + word] = w[i];
+                }
             }
-        }
-        __syncthreads();
-        const int nplanes = ncol / 16 * 4;
-        for (int p = tid / RW; p < nplanes; p += 256 / RW) {
-            const int rl = tid % RW;
-            if (row0 + rl < Rp) {
-                const i32x4 v = *reinterpret_cast<const i32x4 *>(&tile[(p * RW + rl) * 4]);
-                *reinterpret_cast<i32x4 *>(planes + (((long)(c0 / 16) * 4 + p) * Rp + row0 + rl) * 16) = v;
+            __syncthreads();
+            const int nplanes = ncol / 16 * 4;
+            for (int p = tid / RW; p < nplanes; p += 256 / RW) {
+                const int rl = tid % RW;
+                if (row0 + rl < Rp) {
+                    const i32x4 v = *reinterpret_cast<const i32x4 *>(&tile[(p * RW + rl) * 4]);
+                    *reinterpret_cast<i32x4 *>(planes + (((long)(c0 / 16) * 4 + p) * Rp + row0 + rl) * 16) = v;
+                }
             }
+            __syncthreads();
         }
-        __syncthreads();
     }
 }
 

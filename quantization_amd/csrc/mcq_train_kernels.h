@@ -292,7 +292,8 @@ __global__ void k_scales(const float *__restrict__ centers_scale, const float *_
 // the entries: a quarter is added k ascending, the quarters as (q0 + q1) + (q2 + q3); wave 0 adds the codebook means, n
 // ascending.
 __global__ void __launch_bounds__(1024)
-k_centers_mean(const float *__restrict__ C /*[N][K][Dp]*/, int N, int K, int Dp, float *__restrict__ mean /*[Dp]*/) {
+k_centers_mean(const float *__restrict__ C /*[N][K][Dp]*/, int N, int K, int Dp, float *__restrict__ mean /*[Dp]*/,
+               float *__restrict__ cmean /*[N][Dp]: the codebooks' own means mu_n, or nullptr*/) {
     __shared__ float part[64][16];      // [codebook][column]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, kq = lane >> 4;
@@ -310,7 +311,10 @@ k_centers_mean(const float *__restrict__ C /*[N][K][Dp]*/, int N, int K, int Dp,
         }
         s = s + __shfl_xor(s, 16, 64);
         s = s + __shfl_xor(s, 32, 64);
-        if (kq == 0) part[n][c] = s / (float)K;
+        if (kq == 0) {
+            part[n][c] = s / (float)K;
+            if (cmean) cmean[(size_t)n * Dp + d] = s / (float)K;
+        }
     }
     __syncthreads();
     if (threadIdx.x < 16) {

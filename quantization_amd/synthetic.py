@@ -27,6 +27,26 @@ def make_gaussian(seed: int, B: int, D: int) -> np.ndarray:
     return np.random.RandomState(seed).standard_normal((B, D)).astype(np.float32)
 
 
+def make_kind(kind: str, seed: int, B: int, D: int) -> np.ndarray:
+    """Frames of a named distribution (the `x_kind` of a fixture).  Beyond the zero-mean unit-scale sets: frames with a
+    large common offset ("mean10", "mean100"), one dominant feature ("outlier300": feature 0 scaled by 300) and heavy
+    tails ("student2": Student-t with two degrees of freedom) -- what log-mel / self-supervised features look like and
+    where the table form's cancellation terms are largest."""
+    if kind == "gaussian":
+        return make_gaussian(seed, B, D)
+    if kind == "make_x":
+        return make_x(seed, B, D)
+    if kind in ("mean10", "mean100"):
+        return (make_x(seed, B, D) + np.float32(10.0 if kind == "mean10" else 100.0)).astype(np.float32)
+    if kind == "outlier300":
+        x = make_x(seed, B, D)
+        x[:, 0] = (x[:, 0] * np.float32(300.0)).astype(np.float32)
+        return x
+    if kind == "student2":
+        return np.random.RandomState(seed).standard_t(2.0, size=(B, D)).astype(np.float32)
+    raise ValueError(kind)
+
+
 def synthetic_state(seed: int, D: int, K: int, N: int, centers_scale=0.02, logits_scale=-0.01):
     """A seeded quantizer state with a sensible initial guess: to_logits scores a
     codeword by alpha * (x.c - |c|^2 / 2), i.e. nearest-codeword per codebook."""

@@ -32,8 +32,7 @@ def load(name):
     else:
         state = gen.synthetic_state(int(fx["state_seed"]), D, K, N)
         assert gen.checksum(state["centers"]) == float(fx["centers_checksum"]), "regenerated state differs"
-    kind = str(fx["x_kind"])
-    x = gen.make_gaussian(int(fx["x_seed"]), B, D) if kind == "gaussian" else gen.make_x(int(fx["x_seed"]), B, D)
+    x = gen.make_kind(str(fx["x_kind"]), int(fx["x_seed"]), B, D)
     assert gen.checksum(x) == float(fx["x_checksum"]), "regenerated input differs from the fixture's"
     fx.update(D=D, K=K, N=N, B=B, state=state, x=x)
     fx["iters"] = sorted(int(k[len("codes_it"):]) for k in fx if k.startswith("codes_it"))
@@ -49,6 +48,10 @@ def check_codes(fx, it, codes, what):
     hard = bad & (margin >= NEAR_TIE)
     assert not hard.any(), (f"{what}: {int(hard.sum())} vectors differ from the reference with a clear margin, "
                             f"first at {np.flatnonzero(hard)[:5]}")
-    # near-tie differences must stay rare, or the comparison means nothing
-    assert bad.sum() <= max(2, 0.0005 * len(ref)), f"{what}: {int(bad.sum())} near-tie differences of {len(ref)}"
+    # near-tie differences must stay rare, or the comparison means nothing.  Where the fixture holds the reference's OWN
+    # reorder noise (its codes against those of its feature-permuted run, make_golden.py::permuted_reference) that is the
+    # yardstick: no more than two vectors above it; otherwise a flat 0.05 %
+    key = f"reorder_noise_it{it}"
+    limit = int(fx[key]) + 2 if key in fx else max(2, 0.0005 * len(ref))
+    assert bad.sum() <= limit, f"{what}: {int(bad.sum())} near-tie differences of {len(ref)} (limit {limit})"
     return int(bad.sum())

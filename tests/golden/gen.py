@@ -7,4 +7,4 @@ _ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__
 if _ROOT not in sys.path:
     sys.path.insert(0, _ROOT)
 
-from quantization_amd.synthetic import checksum, make_gaussian, make_x, synthetic_state  # noqa: E402,F401
+from quantization_amd.synthetic import checksum, make_gaussian, make_kind, make_x, synthetic_state  # noqa: E402,F401

@@ -144,10 +144,29 @@ def np_state(q):
     return {k: v.detach().cpu().numpy().copy() for k, v in q.state_dict().items()}
 
 
-def encode_cases(q, sd, x, iters_list, out):
+def permuted_reference(sd, x, D, K, N, seed=4242):
+    """The reference itself on the SAME problem with the feature axis permuted (inputs, centers and classifier columns alike):
+    mathematically the same search, a different fp32 summation order inside torch's GEMMs.  How many of its codes move is
+    the reference's own reorder noise -- the yardstick for near-tie differences of any other implementation."""
+    perm = np.random.RandomState(seed).permutation(D)
+    sdp = dict(sd)
+    sdp["centers"] = np.ascontiguousarray(sd["centers"][:, :, perm])
+    sdp["to_logits.weight"] = np.ascontiguousarray(sd["to_logits.weight"][:, perm])
+    return ref_quantizer(sdp, D, K, N), np.ascontiguousarray(x[:, perm])
+
+
+def encode_cases(q, sd, x, iters_list, out, reorder=False):
+    qp = xp = None
+    if reorder:
+        D, K, N = int(out["D"]), int(out["K"]), int(out["N"])
+        qp, xp = permuted_reference(sd, x, D, K, N)
     for it in iters_list:
         codes = ref_encode(q, x, it, as_bytes=False)
         out[f"codes_it{it}"] = codes.astype(np.uint8)
+        if reorder:
+            cp = ref_encode(qp, xp, it, as_bytes=False)
+            out[f"reorder_noise_it{it}"] = int((cp != codes).any(axis=1).sum())
+            print(f"   iters={it}: reference vs its own feature-permuted run: {out[f'reorder_noise_it{it}']} vectors differ")
         c64, margin = search_fp64(sd, x, it)
         out[f"margin_it{it}"] = margin.astype(np.float32)
         nm = int((c64 != codes).any(axis=1).sum())
@@ -163,7 +182,8 @@ def decode_cases(q, codes, out):
     out["decode_rowsumsq"] = (y.astype(np.float64) ** 2).sum(axis=1)
 
 
-def gen_trained(name, D, bytes_per_frame, p1, p2, batch, seed, n_test):
+def gen_trained(name, D, bytes_per_frame, p1, p2, batch, seed, n_test, x_kind="make_x", iters_list=(0, 1, 2, 5), reorder=False,
+                keep=("p1", "p2")):
     """A short CPU training run of the reference trainer; captures the phase-one
     (K=16) and final (K=256) quantizers and their codes on held-out frames."""
     torch.manual_seed(seed)
@@ -175,19 +195,24 @@ def gen_trained(name, D, bytes_per_frame, p1, p2, batch, seed, n_test):
     while not trainer.done():
         if trainer.cur_iter == p1 and phase1 is None:
             phase1 = np_state(trainer.quantizer)   # still K=16: the switch happens at the end of this step
-        trainer.step(torch.from_numpy(gen.make_x(1000 * seed + it, batch, D)))
+        trainer.step(torch.from_numpy(gen.make_kind(x_kind, 1000 * seed + it, batch, D)))
         it += 1
+        if it % 50 == 0:
+            print(f"   [{name}] step {it}", flush=True)
     final = np_state(trainer.get_quantizer())
-    x = gen.make_x(777 + seed, n_test, D)
+    x = gen.make_kind(x_kind, 777 + seed, n_test, D)
     for tag, sd, K, N in (("p1", phase1, 16, 2 * bytes_per_frame), ("p2", final, 256, bytes_per_frame)):
+        if tag not in keep:
+            continue
         q = ref_quantizer(sd, D, K, N)
-        out = {"D": D, "K": K, "N": N, "x_seed": 777 + seed, "x_kind": "make_x", "B": n_test,
+        out = {"D": D, "K": K, "N": N, "x_seed": 777 + seed, "x_kind": x_kind, "B": n_test,
                "x_checksum": gen.checksum(x)}
         for k, v in sd.items():
             out["state." + k] = v
         print(f"[{name}_{tag}] D={D} K={K} N={N}")
-        encode_cases(q, sd, x, [0, 1, 2, 5], out)
-        decode_cases(q, out["codes_it5"], out)
+        encode_cases(q, sd, x, list(iters_list), out, reorder=reorder)
+        decode_cases(q, out["codes_it%d" % iters_list[-1]], out)
+        assert iters_list[-1] == 5
         with torch.no_grad():
             yb = q.decode(torch.from_numpy(out["bytes_it5"])).numpy()
             yc = q.decode(torch.from_numpy(out["codes_it5"].astype(np.int64))).numpy()
@@ -233,6 +258,24 @@ def main(which):
         # the reference's Quantizer accepts; lists of 64 at the two top levels
         gen_synth("synth_d24_k32_n64", 24, 32, 64, 96, 27, 28, [0, 1, 2])
         gen_synth("synth_d16_k256_n64", 16, 256, 64, 48, 29, 30, [0, 1, 2])
+    if which in ("all", "stress"):
+        # Round 4 ("what's weak" 1): states TRAINED BY THE REFERENCE on frames that are not zero-mean unit-scale
+        # Gaussians -- a common offset, one dominant feature, heavy tails -- where the table form's cancellation terms are
+        # largest, each with the reference's own reorder noise beside the fp64 margins
+        gen_trained("stress_mean10_d64_b8", D=64, bytes_per_frame=8, p1=120, p2=120, batch=256, seed=11, n_test=2048,
+                    x_kind="mean10", iters_list=(0, 1, 5), reorder=True)
+        gen_trained("stress_mean10_d256_b4", D=256, bytes_per_frame=4, p1=100, p2=100, batch=256, seed=12, n_test=2048,
+                    x_kind="mean10", iters_list=(0, 1, 5), reorder=True, keep=("p2",))
+        gen_trained("stress_outlier300_d64_b4", D=64, bytes_per_frame=4, p1=120, p2=120, batch=256, seed=13, n_test=2048,
+                    x_kind="outlier300", iters_list=(0, 1, 5), reorder=True)
+        gen_trained("stress_student2_d64_b4", D=64, bytes_per_frame=4, p1=120, p2=120, batch=256, seed=14, n_test=2048,
+                    x_kind="student2", iters_list=(0, 1, 5), reorder=True, keep=("p2",))
+        gen_trained("stress_mean100_d64_b4", D=64, bytes_per_frame=4, p1=120, p2=120, batch=256, seed=15, n_test=2048,
+                    x_kind="mean100", iters_list=(0, 1, 5), reorder=True, keep=("p2",))
+    if which in ("all", "d512"):
+        # a state trained by the reference at the BASELINE dim (config B / E shape): 200 + 200 iterations of 256 frames
+        gen_trained("trained_d512_b8", D=512, bytes_per_frame=8, p1=200, p2=200, batch=256, seed=16, n_test=2048,
+                    x_kind="make_x", iters_list=(0, 1, 5), reorder=True, keep=("p2",))
     if which in ("all", "configs"):
         # BASELINE.json config shapes (A, B, D) with seeded synthetic states
         gen_synth("config_a_d256_n4", 256, 256, 4, 1024, 101, 102, [0, 1, 5])
