@@ -57,35 +57,38 @@ def reference_flops_per_vector(D, N, K, iters):
     return 2.0 * D * N * K + iters * per_pass
 
 
+PEAK_L2_GBPS = 34500.0         # MI355X_MICROARCH.md, L2 (per XCD 4 MiB): ~34.5 TB/s aggregate L2 -> L1
+
+
 def kernel_work(B, D, N, K):
-    """Per launch of each kernel category of mcq_profile_encode (in its order): (name, launches per encode as
-    'once' | 'pass', multiply-adds x 2 of the product it forms, algorithmic HBM bytes, table bytes).  The two products (logits,
-    x.C) are the only matrix-core work: exact fixed-point products, ten i8 MFMA limb products per multiply-add.  A
-    table kernel's HBM bytes are what it must exchange with memory (per-vector inputs, lists and tables written);
-    its table bytes are the 4-byte Gram entries / Gram row segments it reads, which an XCD's L2 serves (the Gram matrix is
-    resident state: 16 MB at 8 x 256)."""
+    """Per launch of each category mcq_profile_encode reports (keys = mcq_profile_category_name): multiply-adds x 2 of the
+    product it forms, algorithmic HBM bytes, table bytes.  The two products (logits, x.C) are the only matrix-core work: exact
+    fixed-point products, ten i8 MFMA limb products per multiply-add.  A table kernel's HBM bytes are what it must exchange
+    with memory (per-vector inputs, lists and tables written and read back); its table bytes are the 4-byte Gram entries /
+    Gram row segments it reads, which an XCD's L2 serves (the Gram matrix is resident state: 16 MB at 8 x 256)."""
     gemm = 2.0 * D * N * K * B
     kc = [k_cutoff(K, 1 << v) for v in range(6)]
     leaf = (kc[0] * kc[0] + 2 * kc[0] + 1) * 4.0           # one full leaf table's Gram reads (x 0.3 below: the lazy
     # level-1 tables read ~ 85 of the 289 entries, DESIGN.md section 4)
     lists0 = 2 * kc[0] * 5.0                               # two level-0 lists read (entry + score)
     dq = (D + 127) // 128 * 128
-    cats = [("logits_product_argmax", "once", gemm, B * (dq * 4.0 + N), 0.0),
-            ("frames_to_limbs", "once", 0.0, B * (D * 4.0 + dq * 4.0 + 8), 0.0),
-            ("stage0_tables", "pass", 0.0, B * N * (K * 4.0 + kc[0] * 5.0 + 5), B * N * N * K * 4.0),
-            ("xc_product", "once", gemm, B * (dq * 4.0 + N * K * 4.0), 0.0),
-            ("combine_level0", "pass", 0.0, B * (N / 2) * (lists0 + kc[1] * 6.0), B * (N / 2) * leaf),
-            ("combine_level1", "pass", 0.0, B * (N / 4) * (2 * lists0 + 2 * kc[1] * 6.0 + kc[2] * 6.0), B * (N / 4) * 4 * leaf * 0.3),
-            ("tables_level1", "pass", 0.0, B * 4 * (N / 8) * (2 * lists0 + 2 * kc[1] * 6.0 + kc[1] * kc[1] * 4.0), B * 4 * (N / 8) * 4 * leaf * 0.3),
-            ("combine_level2", "pass", 0.0, B * (N / 8) * (4 * kc[1] * kc[1] * 4.0 + 2 * kc[2] * 6.0 + kc[3] * 6.0), 0.0),
-            ("tables_upper_levels", "pass", 0.0, B * max(N // 16, 0) * 16 * kc[1] * kc[1] * 4.0, B * max(N // 16, 0) * 16 * 4 * leaf * 0.3),
-            ("combine_upper_levels", "pass", 0.0, B * max(N // 16, 0) * 16 * kc[1] * kc[1] * 4.0, 0.0),
-            ("residual_energies", "pass", 0.0, B * (N + N * 4.0 + 8), B * (N * N + N) * 4.0)]       # E, R from the tables
-    present = 5 if N >= 2 else 4
-    present = 6 if N >= 4 else present
-    present = 8 if N >= 8 else present
-    present = 10 if N >= 16 else present
-    return [c if (i < present or i == 10) else ("unused_%d" % i, "pass", 0.0, 0.0, 0.0) for i, c in enumerate(cats)]
+    pair1 = (B * (N / 4) * (2 * lists0 + 2 * kc[1] * 6.0 + kc[2] * 6.0), B * (N / 4) * 4 * leaf * 0.3)
+    tab1 = (B * 4 * (N / 8) * (2 * lists0 + 2 * kc[1] * 6.0 + kc[1] * kc[1] * 4.0), B * 4 * (N / 8) * 4 * leaf * 0.3)
+    return {
+        "logits_product_argmax": (gemm, B * (dq * 4.0 + N), 0.0),
+        "frames_to_limbs": (0.0, B * (D * 4.0 + 2 * dq * 4.0 + 12), 0.0),        # frames read, two sets of limb planes written
+        "stage0_tables": (0.0, B * N * (K * 4.0 + kc[0] * 5.0 + 5), B * N * N * K * 4.0),
+        "xc_product": (gemm, B * (dq * 4.0 + N * K * 4.0), 0.0),
+        "combine_level0": (0.0, B * (N / 2) * (lists0 + kc[1] * 6.0), B * (N / 2) * leaf),
+        "combine_level1": (0.0,) + pair1,
+        "tables_level1": (0.0,) + tab1,
+        "level1_combines_and_tables": (0.0, pair1[0] + tab1[0], pair1[1] + tab1[1]),
+        "combine_level2": (0.0, B * (N / 8) * (4 * kc[1] * kc[1] * 4.0 + 2 * kc[2] * 6.0 + kc[3] * 6.0) + B * (N + N * 4.0 + 8), B * (N * N + N) * 4.0),
+        "tables_upper_levels": (0.0, B * max(N // 16, 0) * 16 * kc[1] * kc[1] * 4.0, B * max(N // 16, 0) * 16 * 4 * leaf * 0.3),
+        "combine_upper_levels": (0.0, B * max(N // 16, 0) * 16 * kc[1] * kc[1] * 4.0, 0.0),
+        "residual_energies": (0.0, B * (N + N * 4.0 + 8), B * (N * N + N) * 4.0),       # E, R from the tables
+        "encode_tail": (0.0, B * N * 2.0, 0.0),
+    }
 
 
 def load_quantizer(state, D, K, N, dev):
@@ -295,101 +298,117 @@ def main():
     if (D, N, K) == (512, 8, 256) and not args.no_secondary:      # (--no-secondary: every launch has the headline shape)
         parity["vs_reference_fixture"] = fixture_parity(q, dev, iters)
 
-    # ---- per-kernel HIP-event timing on the launch stream (same inputs, same process)
+    # ---- per-kernel HIP-event timing on the launch stream (same inputs, same process): mcq_profile_encode enqueues exactly
+    # what Quantizer.encode enqueues, with an event pair round every launch
     L = _lib.lib()
     with torch.no_grad():          # inference flavour of the derived state (host-side scale factors)
         blob = q._prepared()
     ws = q._workspace(B, dev)
-    ms = (ctypes.c_float * 32)()
-    acc = np.zeros(32)
+    CAP = 32
+    ms = (ctypes.c_float * CAP)()
+    cnt = (ctypes.c_int * CAP)()
+    acc, launches = np.zeros(CAP), np.zeros(CAP, np.int64)
     reps = 3
     st = torch.cuda.current_stream(dev).cuda_stream
+    ncat = 0
     for _ in range(0 if args.no_profile else reps):
         ncat = L.mcq_profile_encode(x.data_ptr(), B, blob.data_ptr(), q._lscale_exp, N, K, D, iters, ws.data_ptr(),
-                                    ws.numel(), st, ms, 32)
+                                    ws.numel(), st, ms, cnt, CAP)
         assert ncat > 0, ncat
         acc[:ncat] += np.array(ms[:ncat])
+        launches[:ncat] = np.array(cnt[:ncat])
     acc /= reps
-    acc = np.maximum(acc, 1e-9)
-    cats = kernel_work(B, D, N, K)
+    work = kernel_work(B, D, N, K)
     kernels = {}
-    for i, (name, when, fl, by, tb) in enumerate(cats):
-        if name.startswith("unused_"):
+    for i in range(ncat):
+        if launches[i] == 0:
             continue
-        launches = 1 if when == "once" else iters
-        avg_ms = acc[i] / launches
-        kernels[name] = {"launches_per_encode": launches, "avg_ms": round(float(avg_ms), 4),
+        name = L.mcq_profile_category_name(i).decode()
+        fl, by, tb = work[name]
+        avg_ms = max(acc[i], 1e-9) / launches[i]
+        kernels[name] = {"launches_per_encode": int(launches[i]), "avg_ms": round(float(avg_ms), 4),
                          "ms_per_encode": round(float(acc[i]), 3)}
         if fl > 0:
             tf_ = fl / (avg_ms * 1e-3) / 1e12
             kernels[name].update(gflop_per_launch=round(fl / 1e9, 2), f32_equivalent_tflops=round(tf_, 2),
-                                 f32_equivalent_frac_of_f32_mfma_peak=round(tf_ / PEAK_F32_MFMA_TFLOPS, 4),
                                  i8_tops=round(LIMB_PRODUCTS * tf_, 1), frac_of_i8_mfma_peak=round(LIMB_PRODUCTS * tf_ / PEAK_I8_MFMA_TOPS, 4),
                                  hbm_gbyte_per_launch=round(by / 1e9, 3))
         else:
             kernels[name].update(hbm_gbyte_per_launch=round(by / 1e9, 3), hbm_gbytes_per_s=round(by / (avg_ms * 1e-3) / 1e9, 1))
             if tb > 0:
                 kernels[name].update(table_gbyte_per_launch=round(tb / 1e9, 3), table_gbytes_per_s_from_l2=round(tb / (avg_ms * 1e-3) / 1e9, 1))
-    dom = max((i for i in range(len(cats)) if not cats[i][0].startswith("unused_")), key=lambda i: acc[i])
-    dom_name, dom_when, dom_fl, dom_by, dom_tb = cats[dom]
-    dom_ms = acc[dom] / (1 if dom_when == "once" else iters)
-    # HBM-side traffic of the dominant kernel: from the committed rocprofv3 --pmc passes of this same
-    # workload (counters cannot be collected from inside the timed process); null for other shapes / kernels
-    traffic, traffic_note = None, None
-    import glob as _glob
-    pmc_files = sorted(_glob.glob(os.path.join(ROOT, "profiles", "r??_pmc_traffic.json")))     # the newest round's passes
-    pmc_file = pmc_files[-1] if pmc_files else ""
-    if (D, N, K, B, iters) == (512, 8, 256, 65536, 5) and pmc_file:
-        pmc = json.load(open(pmc_file))
-        if dom_name in pmc:
-            traffic = pmc[dom_name]["traffic_bytes"]
-            traffic_note = ("bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 of kernel %s, profiles/%s"
-                            % (pmc[dom_name]["kernel"], os.path.basename(pmc_file)))
-    if dom_fl > 0:
-        achieved = LIMB_PRODUCTS * dom_fl / (dom_ms * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 1), "peak": PEAK_I8_MFMA_TOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_I8_MFMA_TOPS, 4), "traffic": traffic,
-                    "traffic_note": traffic_note, "gop_per_launch": round(LIMB_PRODUCTS * dom_fl / 1e9, 2),
-                    "avg_launch_ms": round(float(dom_ms), 4),
-                    "note": "i8 MFMA operations (ten limb products per multiply-add of the exact fixed-point product) against "
-                            "the dense i8 peak; unit reads TOP/s"}
-    else:
-        achieved = dom_by / (dom_ms * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": PEAK_HBM_GBPS,
-                    "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBPS, 4), "traffic": traffic,
-                    "traffic_note": traffic_note, "gbyte_per_launch": round(dom_by / 1e9, 3),
-                    "avg_launch_ms": round(float(dom_ms), 4),
-                    "table_gbyte_per_launch": round(dom_tb / 1e9, 3),
-                    "table_gbytes_per_s_from_l2": round(dom_tb / (dom_ms * 1e-3) / 1e9, 1),
-                    "note": "a table kernel: no FLOPs to price.  `achieved` prices the bytes it must exchange with HBM (per-vector "
-                            "inputs, lists written); what bounds it is the L2 -> L1 fabric that carries the Gram row segments "
-                            "(table_*: measured ceiling 17-25 TB/s for such pieces, DESIGN.md section 5).  The two matrix-core products "
-                            "(logits, x.C) are in `kernels` with their fraction of the i8-MFMA peak"}
-        if dom_name == "stage0_tables":
-            # the yardstick of SURVEY.md 8(d) for the same launch: the matmul FLOPs of the reference's stage-0 GEMM
-            # (quantization.py:413-416, 2*D*N*K per vector and pass) that this kernel replaces by table reads
-            ref_fl = 2.0 * D * N * K * B
-            roofline["reference_algorithm"] = {
-                "gflop_per_launch": round(ref_fl / 1e9, 2), "tflops": round(ref_fl / (dom_ms * 1e-3) / 1e12, 1),
-                "frac_of_f32_mfma_peak": round(ref_fl / (dom_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                "note": "FLOPs of the reference's stage-0 matmul for the vectors of one launch / this launch's duration / "
-                        "157.3 TFLOP/s (SURVEY.md 8d prices encode against the fp32-MFMA peak); above 1 because the table "
-                        "form reads these inner products from the Gram matrix instead of executing them"}
+    kernels_sum_ms = round(float(sum(v["ms_per_encode"] for v in kernels.values())), 3)
+    # the dominant kernel = the category with the largest time per encode (what rocprofv3 --stats puts on top)
+    roofline = None
+    if kernels:
+        dom_name = max(kernels, key=lambda n: kernels[n]["ms_per_encode"])
+        dom_fl, dom_by, dom_tb = work[dom_name]
+        dom_ms = kernels[dom_name]["avg_ms"]
+        # HBM-side traffic of that kernel: the committed rocprofv3 --pmc passes of this same workload and launch sequence
+        # (counters cannot be collected from inside the timed process); null for other shapes
+        traffic, traffic_note, l2_req_bytes = None, None, None
+        import glob as _glob
+        pmc_files = sorted(_glob.glob(os.path.join(ROOT, "profiles", "r??_pmc_traffic.json")))     # the newest round's passes
+        pmc_file = pmc_files[-1] if pmc_files else ""
+        if (D, N, K, B, iters) == (512, 8, 256, 65536, 5) and pmc_file:
+            pmc = json.load(open(pmc_file))
+            if dom_name in pmc:
+                traffic = pmc[dom_name]["traffic_bytes"]
+                l2_req_bytes = pmc[dom_name].get("l2_read_request_bytes")
+                traffic_note = ("bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 of kernel %s, profiles/%s (a separate "
+                                "--pmc run of this command; not a counter of the timed run)" % (pmc[dom_name]["kernel"], os.path.basename(pmc_file)))
+        if dom_fl > 0:
+            achieved = LIMB_PRODUCTS * dom_fl / (dom_ms * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 1), "peak": PEAK_I8_MFMA_TOPS,
+                        "unit": "TFLOP/s", "frac": round(achieved / PEAK_I8_MFMA_TOPS, 4), "traffic": traffic,
+                        "traffic_note": traffic_note, "gop_per_launch": round(LIMB_PRODUCTS * dom_fl / 1e9, 2),
+                        "avg_launch_ms": round(float(dom_ms), 4),
+                        "note": "i8 MFMA operations (ten limb products per multiply-add of the exact fixed-point product) against "
+                                "the dense i8 peak; unit reads TOP/s"}
+        else:
+            achieved = dom_by / (dom_ms * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": PEAK_HBM_GBPS,
+                        "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBPS, 4), "traffic": traffic,
+                        "traffic_note": traffic_note, "gbyte_per_launch": round(dom_by / 1e9, 3),
+                        "avg_launch_ms": round(float(dom_ms), 4),
+                        "l2": {"useful_table_gbyte_per_launch": round(dom_tb / 1e9, 3),
+                               "useful_gbytes_per_s": round(dom_tb / (dom_ms * 1e-3) / 1e9, 1),
+                               "l2_frac_useful": round(dom_tb / (dom_ms * 1e-3) / 1e9 / PEAK_L2_GBPS, 4),
+                               "line_gbyte_per_launch": None if l2_req_bytes is None else round(l2_req_bytes / 1e9, 3),
+                               "l2_frac_lines": None if l2_req_bytes is None else round(l2_req_bytes / (dom_ms * 1e-3) / 1e9 / PEAK_L2_GBPS, 4),
+                               "peak_gb_per_s": PEAK_L2_GBPS,
+                               "note": "what bounds a table kernel: 4-byte Gram entries gathered from the XCD's L2; every gather "
+                                       "that misses the L1 moves a 128-byte line (TCP_TCC_READ_REQ x 128 B of the same --pmc "
+                                       "passes = line_*), so the L2 -> L1 path carries 10-15x the useful bytes"},
+                        "note": "a table kernel: no FLOPs to price.  `achieved` prices the bytes it must exchange with HBM (per-vector "
+                                "inputs, lists and tables written and read back) against the HBM peak; `l2` prices what actually "
+                                "bounds it.  The two matrix-core products (logits, x.C) are in `kernels` with their fraction of the "
+                                "i8-MFMA peak"}
 
     fpv = reference_flops_per_vector(D, N, K, iters)
     exec_fpv = 2 * 2.0 * D * N * K          # the logits and x.C products only (each multiply-add = ten i8 limb products)
+    _w = kernel_work(B, D, N, K)
+    _pass_names = ("stage0_tables", "combine_level0", "level1_combines_and_tables", "combine_level2", "tables_upper_levels") if N >= 8 \
+        else ("stage0_tables", "combine_level0", "combine_level1")
+    executed_floor_ms = round((LIMB_PRODUCTS * exec_fpv * B / (PEAK_I8_MFMA_TOPS * 1e12) +
+                               iters * sum(_w[n_][2] + (_w[n_][1] if n_ == "stage0_tables" else 0.0) for n_ in _pass_names) / (PEAK_L2_GBPS * 1e9)) * 1e3, 3)
     value = world * B * args.steps / dt
     out = {
         "metric": "vectors encoded/sec at dim=512, 8 codebooks; uint8 codes bit-exact vs ref",
         "value": round(value, 1), "unit": "vectors/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32 (products: exact 30-bit fixed point on the i8 MFMA)", "data": "synthetic",
         "config": {"workload": f"Quantizer.encode, dim={D}, bytes_per_frame={N}, codebook_size={K}, "
                                f"refine_indexes_iters={iters}, batch={B} fp32 Gaussian vectors per GPU "
                                f"(BASELINE.json configs[1]), seeded synthetic codebooks",
                    "global_batch": world * B, "parallelism": f"batch-sharded x{world}, no collective"},
         "parity": parity,
-        "whole_encode": {"reference_flop_per_vector": fpv, "executed_product_flop_per_vector": exec_fpv,
+        "whole_encode": {"kernels_sum_ms": kernels_sum_ms,
+                         "executed_floor_ms": executed_floor_ms, "frac_of_floor": round(executed_floor_ms / (dt / args.steps * 1e3), 4),
+                         "executed_floor_note": "products: 2 x 2*D*N*K multiply-adds x 10 limb products per vector at the dense i8 peak; "
+                                                "table passes: the useful Gram / x.C bytes of the five table kernels at the L2 peak "
+                                                "(34.5 TB/s); what an encode of this ALGORITHM costs at the chip's peaks",
+                         "reference_flop_per_vector": fpv, "executed_product_flop_per_vector": exec_fpv,
                          "executed_i8_mfma_op_per_vector": LIMB_PRODUCTS * exec_fpv,
                          "reference_tflops": round(value / world * fpv / 1e12, 2),
                          "frac_of_f32_mfma_peak": round(value / world * fpv / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),

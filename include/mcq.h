@@ -49,7 +49,11 @@ extern "C" {
 #define MCQ_EUNSUPPORTED (-2) /* outside the supported (K, N) domain             */
 #define MCQ_EWORKSPACE (-3) /* workspace smaller than mcq_encode_workspace_bytes */
 
-#define MCQ_ABI_VERSION 5   /* 5: mcq_prepared_decode_bytes, 64 codebooks for every codebook size, and (additions) mcq_prepare_params,
+#define MCQ_ABI_VERSION 6   /* 6: the tables of the search are formed from CENTERED rows and frames (`prepared` also holds the codebooks' own
+                               means, Q and the Gram matrix are those of C[n][k] - mu_n; the encode workspace holds two sets of frame
+                               planes: sizes changed, signatures did not), mcq_profile_encode times the shipped launch sequence and
+                               reports per-category launch counts, mcq_profile_category_name is new;
+                               5: mcq_prepared_decode_bytes, 64 codebooks for every codebook size, and (additions) mcq_prepare_params,
                                mcq_logits_refine_codes, mcq_loss_head_tail; 4: fixed-point products: `prepared` holds limb planes of the centers and the classifier
                                (mcq_prepared_bytes changed), workspaces hold those of the frames (the workspace sizes
                                depend on D), mcq_logits takes a workspace, mcq_logits_workspace_bytes is new */
@@ -61,11 +65,11 @@ int mcq_padded_dim(int D);
 /* ---- derived state -------------------------------------------------------
  * Replaces Quantizer.get_centers() (quantization/quantization.py:77-79, recomputed
  * on every call there) and the parameter reads of Quantizer._logits (:277-279).
- * `prepared` receives: scaled centers C[N][K][Dp] = cscale_exp * centers, their
- * sum of squares Q[N][K] (:411), the centers and the rows of to_logits.weight as 8-bit limb
- * planes with their row exponents (the operands of the fixed-point products), the bias, and
- * -- when weight is given -- the Gram matrix G[N*K][N*K] of the scaled centers (16 MB at
- * 8 x 256; what the refinement passes read).
+ * `prepared` receives: scaled centers C[N][K][Dp] = cscale_exp * centers (what decode sums), the codebooks' own means
+ * mu_n = mean_k C[n][k] and their sum (= get_data_mean(), :67-75), and -- when weight is given -- what the search reads:
+ * the CENTERED rows C[n][k] - mu_n as 8-bit limb planes with their row exponents, their sums of squares Q[N][K] (:411),
+ * the rows of to_logits.weight as limb planes, the bias, and the Gram matrix G[N*K][N*K] of the centered rows (16 MB at
+ * 8 x 256; what the refinement passes read).  The search is invariant under this shift (oracle/mcq_oracle.c, "CENTERING").
  * cscale_exp / lscale_exp = exp(10*centers_scale) / exp(10*logits_scale), formed
  * by the caller in fp32 exactly as the reference does (:78, :278).
  * weight/bias may be NULL when only decode is needed: `prepared` then receives the scaled centers
@@ -280,12 +284,14 @@ int mcq_test_select(const float *scores, int cases, int per_lane, int cnt, float
  * thread (for bench.py's per-kernel HIP-event timing); returns the count.      */
 int mcq_last_encode_launches(void);
 
-/* Times one refinement pass's kernels separately with HIP events on `stream`
- * (synchronises; bench/profiling only).  ms_out[0..n) receives milliseconds for
- * {logits_argmax, residual, stage0_gemm, prune0, pair stages...}; returns n.   */
+/* Measurement tool (bench.py): runs ONE encode exactly as mcq_encode enqueues it -- the same launches, nothing switched off --
+ * with a pair of HIP events on `stream` round every launch; synchronises and allocates the output of that encode.
+ * ms_out[c] / launches_out[c] (c < cap) receive the summed milliseconds and the number of timed intervals of category c,
+ * mcq_profile_category_name(c) its name (NULL past the last one).  Returns the number of categories, or an error code.   */
 int mcq_profile_encode(const float *x, long B, const void *prepared, float lscale_exp, int N, int K,
                        int D, int refine_iters, void *workspace, size_t workspace_bytes, void *stream,
-                       float *ms_out, int ms_cap);
+                       float *ms_out, int *launches_out, int cap);
+const char *mcq_profile_category_name(int category);
 
 #ifdef __cplusplus
 }

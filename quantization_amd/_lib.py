@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("MCQ_LIB_PATH") or os.path.join(_HERE, "lib", "libmcq_
 # every symbol include/mcq.h declares
 SYMBOLS = (
     "mcq_abi_version", "mcq_padded_dim", "mcq_prepared_bytes", "mcq_prepared_decode_bytes", "mcq_prepared_mean_offset", "mcq_prepare", "mcq_prepare_dev", "mcq_prepare_params", "mcq_encode_workspace_bytes",
-    "mcq_encode", "mcq_encode_ex", "mcq_refine_indexes", "mcq_decode", "mcq_decode_backward", "mcq_logits", "mcq_logits_workspace_bytes", "mcq_last_encode_launches", "mcq_test_select", "mcq_profile_encode",
+    "mcq_encode", "mcq_encode_ex", "mcq_refine_indexes", "mcq_decode", "mcq_decode_backward", "mcq_logits", "mcq_logits_workspace_bytes", "mcq_last_encode_launches", "mcq_test_select", "mcq_profile_encode", "mcq_profile_category_name",
     "mcq_logits_argmax", "mcq_logits_refine", "mcq_logits_refine_codes", "mcq_loss_workspace_bytes", "mcq_loss_fwd", "mcq_loss_bwd", "mcq_recon_fwd", "mcq_loss_tail",
     "mcq_jcl_prefix_fwd", "mcq_jcl_prefix_bwd", "mcq_scatter_rows", "mcq_decode_backward_u8",
     "mcq_weight_grad", "mcq_weight_grad_workspace_bytes", "mcq_adam_step", "mcq_loss_head", "mcq_loss_head_tail", "mcq_scales_exp",
@@ -119,8 +119,10 @@ def lib():
     L.mcq_grad_tail.argtypes = [vp, i64, vp, vp, f32, vp, i64, f32, vp, vp, vp]
     L.mcq_last_encode_launches.restype = i32
     L.mcq_profile_encode.restype = i32
-    L.mcq_profile_encode.argtypes = [vp, i64, vp, f32, i32, i32, i32, i32, vp, sz, vp, ctypes.POINTER(f32), i32]
-    assert L.mcq_abi_version() == 5
+    L.mcq_profile_encode.argtypes = [vp, i64, vp, f32, i32, i32, i32, i32, vp, sz, vp, ctypes.POINTER(f32), ctypes.POINTER(i32), i32]
+    L.mcq_profile_category_name.restype = ctypes.c_char_p
+    L.mcq_profile_category_name.argtypes = [i32]
+    assert L.mcq_abi_version() == 6
     _lib = L
     return L
 

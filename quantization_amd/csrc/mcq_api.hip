@@ -352,9 +352,25 @@ int launch_tf_comb(int kh, int kc, const float *E, const TfLists &L, long B, int
     return MCQ_EUNSUPPORTED;
 }
 
-// profiling categories (mcq_profile_encode): once per call 0, 1, 3; per pass the rest
+// profiling categories (mcq_profile_encode): one per KIND OF LAUNCH of the shipped sequence -- the profiler records events round
+// the launches an encode makes and changes none of them
 enum { CAT_LOGITS = 0, CAT_XX = 1, CAT_STAGE0 = 2, CAT_XC = 3, CAT_LEVEL0 = 4, CAT_LEVEL1 = 5, CAT_TABLES = 6, CAT_COMBINE = 7,
-       CAT_ER = 10 };
+       CAT_TABLES_UP = 8, CAT_COMBINE_UP = 9, CAT_ER = 10, CAT_LEVEL1_FUSED = 11, CAT_TAIL = 12, CAT_COUNT = 13 };
+const char *const kCatNames[CAT_COUNT] = {
+    "logits_product_argmax",      // k_fgemm<FG_LOGITS>
+    "frames_to_limbs",            // k_fix_rows
+    "stage0_tables",              // k_tf_stage0 / k_tf_stage0_k16
+    "xc_product",                 // k_fgemm<FG_STORE>
+    "combine_level0",             // k_tf_pair0
+    "combine_level1",             // k_tf_pair1 (4 codebooks: the last combine)
+    "tables_level1",              // k_tf_table1 (more than 16 codebooks)
+    "combine_level2",             // k_tf_comb at level 2 (8 codebooks: the last combine, which also forms E / R of the next pass)
+    "tables_upper_levels",        // k_tf_table1 / k_tf_up above level 2
+    "combine_upper_levels",       // k_tf_comb / k_tf_comb3 above level 2
+    "residual_energies",          // k_tf_gram_terms + k_tf_er (first pass of a call; later passes: inside the last combine)
+    "level1_combines_and_tables", // k_tf_level1: the level-1 combines and the cousin tables of level 2 in one launch
+    "encode_tail",                // k_finalize / k_import_indexes / k_compact
+};
 
 // the combines of one refinement pass; lists of K >= 32 hold 16, 16, 32, 32, 64 candidates, of K == 16: 8, 8, 16, 16, 32, 32
 int run_tf_combines(const float *G, const uint8_t *idx_cur, uint8_t *idx_new, const Workspace &w, const TfLists &L, long B, int N,
@@ -373,7 +389,7 @@ int run_tf_combines(const float *G, const uint8_t *idx_cur, uint8_t *idx_new, co
     }
     // the level-1 combines and the cousin tables of level 2 share a launch (k_tf_level1): same workgroup-to-XCD mapping as the two
     // launches, one boundary and one tail less (5.95 -> 5.86 ms per encode of 65,536 vectors, 0.55 -> 0.51 ms at 4,096)
-    const bool fuse_l1 = (N >= 8) && (prof == nullptr);      // (mcq_profile_encode times the two kinds of workgroups as two launches)
+    const bool fuse_l1 = (N >= 8);
     // 16 codebooks: the 16 cousin tables of level 3 ride along (into tabs[1]).  With 256-entry codebooks at 65,536 vectors
     // that launch is 0.93 ms long and the merge bought nothing (23.99 / 23.92 against 23.90 / 24.0 ms per encode); a trainer
     // step of the first phase (16 x 16 codebooks, 4,096 vectors) saves a 29 us launch per pass
@@ -384,9 +400,11 @@ int run_tf_combines(const float *G, const uint8_t *idx_cur, uint8_t *idx_new, co
         const unsigned pair_blocks = (unsigned)(B * (N / 4)), tab_blocks = (unsigned)(B * ntab1);
         const int ntab3 = fuse_l3 ? 16 : 1, per3 = fuse_l3 ? 4 : 1;
         const dim3 grid(pair_blocks + tab_blocks + (fuse_l3 ? (unsigned)(B * ntab3) : 0u));
+        if (prof) prof->begin();
         if (small) hipLaunchKernelGGL((k_tf_level1<8, 8>), grid, dim3(64), 0, st, G, idx_cur, w.E, L, B, N, K, keep, ntab1, per1, w.tabs[0], nact, pair_blocks, tab_blocks, ntab3, per3, w.tabs[1]);
         else hipLaunchKernelGGL((k_tf_level1<16, 16>), grid, dim3(64), 0, st, G, idx_cur, w.E, L, B, N, K, keep, ntab1, per1, w.tabs[0], nact, pair_blocks, tab_blocks, ntab3, per3, w.tabs[1]);
         MCQ_LAUNCH_CHECK();
+        if (prof) prof->end(CAT_LEVEL1_FUSED);
     } else if (N >= 4) {   // level 1: pairs of codebooks
         const int keep = (N == 4) ? 1 : L.kc[2];
         uint8_t *fin = (N == 4) ? idx_new : nullptr;
@@ -403,32 +421,36 @@ int run_tf_combines(const float *G, const uint8_t *idx_cur, uint8_t *idx_new, co
         const int keep = last ? 1 : L.kc[v + 1];
         uint8_t *fin = last ? idx_new : nullptr;
         const int per1 = 1 << (v - 1), ntab1 = groups * per1 * per1;
-        if (prof) prof->begin();
+        const int cat_tab = (v == 2) ? CAT_TABLES : CAT_TABLES_UP, cat_comb = (v == 2) ? CAT_COMBINE : CAT_COMBINE_UP;
         if (!(fuse_l1 && v == 2) && !(fuse_l3 && v == 3)) {     // (these tables came with the level-1 combines)
+            if (prof) prof->begin();
             if (small) hipLaunchKernelGGL((k_tf_table1<8, 8>), dim3((unsigned)(B * ntab1)), dim3(64), 0, st, G, idx_cur, L, B, N, K, ntab1, per1, w.tabs[0], nact);
             else hipLaunchKernelGGL((k_tf_table1<16, 16>), dim3((unsigned)(B * ntab1)), dim3(64), 0, st, G, idx_cur, L, B, N, K, ntab1, per1, w.tabs[0], nact);
             MCQ_LAUNCH_CHECK();
+            if (prof) prof->end(cat_tab);
         }
         if (N == 16 && v == 3) {       // two groups of eight: levels 2 and 3 in one kernel, tables in LDS
-            if (prof) { prof->end(CAT_TABLES + 2); prof->begin(); }
+            if (prof) prof->begin();
             const float *t3 = fuse_l3 ? w.tabs[1] : w.tabs[0];
             if (small) hipLaunchKernelGGL((k_tf_comb3<8, 16, 16>), dim3((unsigned)B), dim3(256), 0, st, idx_cur, w.E, L, B, N, t3, idx_new, nact);
             else hipLaunchKernelGGL((k_tf_comb3<16, 32, 32>), dim3((unsigned)B), dim3(256), 0, st, idx_cur, w.E, L, B, N, t3, idx_new, nact);
             MCQ_LAUNCH_CHECK();
-            if (prof) prof->end(CAT_COMBINE + 2);
+            if (prof) prof->end(cat_comb);
             continue;
         }
         int cur = 0;
         for (int u = 2; u < v; ++u) {
             const int per = 1 << (v - u), ntab = groups * per * per;
+            if (prof) prof->begin();
             const int rc = launch_tf_up(L.kc[u - 1], L.kc[u], L, B, N, u, ntab, per, w.tabs[cur], w.tabs[cur ^ 1], nact, st);
             if (rc) return rc;
+            if (prof) prof->end(cat_tab);
             cur ^= 1;
         }
-        if (prof) { prof->end(v == 2 ? CAT_TABLES : CAT_TABLES + 2); prof->begin(); }
+        if (prof) prof->begin();
         const int rc = launch_tf_comb(L.kc[v - 1], L.kc[v], w.E, L, B, N, v, keep, w.tabs[cur], fin, nact, st);
         if (rc) return rc;
-        if (prof) prof->end(v == 2 ? CAT_COMBINE : CAT_COMBINE + 2);
+        if (prof) prof->end(cat_comb);
     }
     return 0;
 }
@@ -499,16 +521,17 @@ int run_encode(const float *x, long B, const void *prepared, float lscale, int N
         bool wrote_direct = false;
         // E / R of pass it + 1 can be formed by the wave that emits the indexes of pass it (tf_emit), which saves that pass
         // its two E / R launches: 4, 8 or 16 codebooks, no compaction of the vectors between the passes, not under the profiler
-        const bool er_in_emit = !skip && prof == nullptr && (N == 4 || N == 8 || N == 16);
+        const bool er_in_emit = !skip && (N == 4 || N == 8 || N == 16);
         bool er_ready = false;
         for (int it = 0; it < iters; ++it) {
-            if (prof) prof->begin();
             if (!er_ready) {
+                if (prof) prof->begin();
                 rc = launch_tf_er(N, P.G, w.XC, idx_cur, w.xx, Bc, K, w.E, w.R, w.gterms, nact, map_cur, st);
                 if (rc) return rc;
+                if (prof) prof->end(CAT_ER);
             }
             er_ready = false;
-            if (prof) { prof->end(CAT_ER); prof->begin(); }
+            if (prof) prof->begin();
             rc = launch_tf_stage0(K, N, P.G, w.XC, idx_cur, w.R, P.Q, Bc, (N == 1) ? 1 : w.tf.kc[0], w.tf.ent, w.tf.S[0],
                                   (N == 1) ? idx_new : nullptr, nact, map_cur, st);
             if (rc) return rc;
@@ -520,7 +543,7 @@ int run_encode(const float *x, long B, const void *prepared, float lscale, int N
                     L.erG = P.G; L.erXC = w.XC; L.erxx = w.xx; L.erE = w.E; L.erR = w.R; L.erK = K;
                     er_ready = true;
                 }
-                const bool direct_out = (it + 1 == iters) && !skip && pack == 1 && prof == nullptr;
+                const bool direct_out = (it + 1 == iters) && !skip && pack == 1;
                 if (direct_out) {
                     L.out_i64 = out_i64 ? out_i64 + lo * N : nullptr;
                     L.out_u8 = out_u8 ? out_u8 + lo * N : (codes_also ? codes_also + lo * N : nullptr);
@@ -531,9 +554,11 @@ int run_encode(const float *x, long B, const void *prepared, float lscale, int N
             }
             if (skip) {
                 const int last = (it + 1 == iters) ? 1 : 0;
+                if (prof) prof->begin();
                 hipLaunchKernelGGL(k_compact, dim3((unsigned)((Bc + 255) / 256)), dim3(256), 0, st, idx_cur, idx_new,
                                    map_cur, nact, Bc, N, last, w.final_idx, idx_pk, map_nxt, w.cnt + it);
                 MCQ_LAUNCH_CHECK();
+                if (prof) prof->end(CAT_TAIL);
                 // rotate: the packed list becomes the current one
                 uint8_t *t = idx_cur; idx_cur = idx_pk; idx_pk = t;
                 int *old_map = const_cast<int *>(map_cur);
@@ -545,10 +570,12 @@ int run_encode(const float *x, long B, const void *prepared, float lscale, int N
         if (wrote_direct) continue;
         const uint8_t *result = (skip && iters > 0) ? w.final_idx : w.idx;
         const long outn = (out_i64 != nullptr) ? Bc * N : Bc * (N / pack);
+        if (prof) prof->begin();
         hipLaunchKernelGGL(k_finalize, dim3((unsigned)((outn + 255) / 256)), dim3(256), 0, st, result, Bc, N, pack,
                            out_u8 ? out_u8 + lo * (N / pack) : nullptr, out_i64 ? out_i64 + lo * N : nullptr,
                            codes_also ? codes_also + lo * N : nullptr);
         MCQ_LAUNCH_CHECK();
+        if (prof) prof->end(CAT_TAIL);
     }
     return 0;
 }
@@ -1179,32 +1206,33 @@ int mcq_test_select(const float *scores, int cases, int per_lane, int cnt, float
     return e == hipSuccess ? 0 : (int)e;
 }
 
+const char *mcq_profile_category_name(int category) {
+    return (category >= 0 && category < CAT_COUNT) ? kCatNames[category] : nullptr;
+}
+
 int mcq_profile_encode(const float *x, long B, const void *prepared, float lscale_exp, int N, int K, int D,
                        int refine_iters, void *workspace, size_t workspace_bytes, void *stream, float *ms_out,
-                       int ms_cap) {
+                       int *launches_out, int cap) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     Prof prof;
     prof.stream = st;
-    // results go to the head of S0's neighbour: reuse the tail of the workspace as a dummy output
     const size_t need = (size_t)B * N;
-    uint8_t *dummy = nullptr;
+    uint8_t *dummy = nullptr;                 // the codes of the profiled encode (this entry point is a measurement tool: it allocates)
     if (hipMalloc(reinterpret_cast<void **>(&dummy), need ? need : 1) != hipSuccess) return MCQ_EINVAL;
     int rc = run_encode(x, B, prepared, lscale_exp, N, K, D, refine_iters, dummy, nullptr, workspace, workspace_bytes,
                         st, &prof);
     (void)hipStreamSynchronize(st);
-    int ncat = 0;
     if (rc == 0) {
-        for (int c : prof.cat) ncat = c + 1 > ncat ? c + 1 : ncat;
-        for (int i = 0; i < ms_cap; ++i) ms_out[i] = 0.f;
+        for (int i = 0; i < cap; ++i) { ms_out[i] = 0.f; if (launches_out) launches_out[i] = 0; }
         for (size_t i = 0; i < prof.cat.size(); ++i) {
             float ms = 0.f;
             (void)hipEventElapsedTime(&ms, prof.ev[2 * i], prof.ev[2 * i + 1]);
-            if (prof.cat[i] < ms_cap) ms_out[prof.cat[i]] += ms;
+            if (prof.cat[i] < cap) { ms_out[prof.cat[i]] += ms; if (launches_out) launches_out[prof.cat[i]] += 1; }
         }
     }
     for (hipEvent_t e : prof.ev) (void)hipEventDestroy(e);
     (void)hipFree(dummy);
-    return rc == 0 ? ncat : rc;
+    return rc == 0 ? CAT_COUNT : rc;
 }
 
 }  // extern "C"
