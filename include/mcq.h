@@ -284,8 +284,9 @@ int mcq_test_select(const float *scores, int cases, int per_lane, int cnt, float
  * thread (for bench.py's per-kernel HIP-event timing); returns the count.      */
 int mcq_last_encode_launches(void);
 
-/* Measurement tool (bench.py): runs ONE encode exactly as mcq_encode enqueues it -- the same launches, nothing switched off --
- * with a pair of HIP events on `stream` round every launch; synchronises and allocates the output of that encode.
+/* Measurement tool (bench.py): runs the encode exactly as mcq_encode enqueues it -- the same launches, nothing switched off --
+ * once per category of launch, with HIP events on `stream` round the launches of that category only (events round every launch of
+ * one encode stretch it by a tenth); synchronises and allocates the output of those encodes.
  * ms_out[c] / launches_out[c] (c < cap) receive the summed milliseconds and the number of timed intervals of category c,
  * mcq_profile_category_name(c) its name (NULL past the last one).  Returns the number of categories, or an error code.   */
 int mcq_profile_encode(const float *x, long B, const void *prepared, float lscale_exp, int N, int K,
