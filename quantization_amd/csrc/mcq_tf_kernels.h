@@ -469,7 +469,11 @@ __device__ __forceinline__ void tf_table1(const float *__restrict__ G, const uin
     const int G1 = N >> 1;
     const uint8_t *px = L.pos[1] + ((b * G1 + X) * KC) * 2, *py = L.pos[1] + ((b * G1 + Y) * KC) * 2;
     if constexpr (KCH == 16 && KC == 16) {
-        constexpr int LS = MH + 64;                      // per leaf table: 256 entries + 33 border values
+        // per leaf table: 16 rows of 17 floats (an odd row stride: the quarter-wave reads below -- up to sixteen rows, a few
+        // columns -- spread over all 32 banks; with rows of 16 they met in 2 x 16, SQ_LDS_BANK_CONFLICT 26 M cycles per launch)
+        // + 33 border values
+        constexpr int RS = KCH + 1, BO = KCH * RS;
+        constexpr int LS = BO + 64;
         int *cent = reinterpret_cast<int *>(leaf + 4 * LS);   // [4][16] compact list -> codebook entry
         int *crank = cent + 64;                               // [4][16] candidate -> compact rank of its leaf
         const int NK = N * K;
@@ -544,16 +548,16 @@ __device__ __forceinline__ void tf_table1(const float *__restrict__ G, const uin
         }
 #pragma unroll
         for (int tb = 0; tb < 4; ++tb)
-            if (lane <= na_[tb] + nc_[tb]) leaf[tb * LS + MH + lane] = bv[tb];
+            if (lane <= na_[tb] + nc_[tb]) leaf[tb * LS + BO + lane] = bv[tb];
         wave_lds_fence();
 #pragma unroll
         for (int tb = 0; tb < 4; ++tb) {
             float *lt = leaf + tb * LS;
-            const float wv = lt[MH + na_[tb] + nc_[tb]];
+            const float wv = lt[BO + na_[tb] + nc_[tb]];
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int e = rr[tb][it];
-                if (e >= 0) lt[e] = ((g[tb][it] - lt[MH + (e >> 4)]) - lt[MH + na_[tb] + (e & 15)]) + wv;
+                if (e >= 0) lt[e + (e >> 4)] = ((g[tb][it] - lt[BO + (e >> 4)]) - lt[BO + na_[tb] + (e & 15)]) + wv;      // row ra at 17 ra
             }
         }
         wave_lds_fence();
@@ -562,8 +566,8 @@ __device__ __forceinline__ void tf_table1(const float *__restrict__ G, const uin
 #pragma unroll
         for (int v = 0; v < VPL; ++v) {
             const int rj0 = crank[32 + j0 + v], rj1 = crank[48 + j0 + v];
-            t[v] = ((leaf[ri0 * 16 + rj0] + leaf[LS + ri0 * 16 + rj1]) + leaf[2 * LS + ri1 * 16 + rj0]) +
-                   leaf[3 * LS + ri1 * 16 + rj1];
+            t[v] = ((leaf[ri0 * RS + rj0] + leaf[LS + ri0 * RS + rj1]) + leaf[2 * LS + ri1 * RS + rj0]) +
+                   leaf[3 * LS + ri1 * RS + rj1];
         }
         return;
     } else if constexpr (KCH * KCH == 64) {
@@ -601,10 +605,11 @@ __device__ __forceinline__ void tf_table1(const float *__restrict__ G, const uin
                 const uint32_t bc = (bl >= KCH && bl < 2 * KCH) ? colm + (uint32_t)e_brd[2 + c] : colm + (uint32_t)oldq[2 + c];
                 bv[a * 2 + c] = G[(br << nksh) + bc];
             }
+        constexpr int RS = KCH + 1, TS = KCH * RS;      // rows of 9 floats (odd stride: see the lists of 16)
 #pragma unroll
         for (int tb = 0; tb < 4; ++tb) {
             const float u = shfl_f(bv[tb], i), w = shfl_f(bv[tb], 2 * KCH), vj = shfl_f(bv[tb], KCH + j);
-            leaf[tb * MH + lane] = ((g[tb] - u) - vj) + w;          // the expression of tf_leaf
+            leaf[tb * TS + i * RS + j] = ((g[tb] - u) - vj) + w;          // the expression of tf_leaf
         }
         wave_lds_fence();
         const int ii = (VPL * lane) / KC, j0 = (VPL * lane) % KC;
@@ -612,8 +617,8 @@ __device__ __forceinline__ void tf_table1(const float *__restrict__ G, const uin
 #pragma unroll
         for (int v = 0; v < VPL; ++v) {
             const int jj0 = py[2 * (j0 + v)], jj1 = py[2 * (j0 + v) + 1];
-            t[v] = ((leaf[i0 * KCH + jj0] + leaf[MH + i0 * KCH + jj1]) + leaf[2 * MH + i1 * KCH + jj0]) +
-                   leaf[3 * MH + i1 * KCH + jj1];
+            t[v] = ((leaf[i0 * RS + jj0] + leaf[TS + i0 * RS + jj1]) + leaf[2 * TS + i1 * RS + jj0]) +
+                   leaf[3 * TS + i1 * RS + jj1];
         }
     } else {
 #pragma unroll
@@ -639,7 +644,7 @@ __device__ __forceinline__ void tf_table1(const float *__restrict__ G, const uin
     }
 }
 
-constexpr int tf_leaf_lds_floats(int KCH) { return 4 * (KCH * KCH + 64) + 128; }
+constexpr int tf_leaf_lds_floats(int KCH) { return 4 * (KCH * (KCH + 1) + 64) + 128; }
 
 // combine of level 1: siblings X = 2g, Y = 2g + 1 (pairs of codebooks).  One wave per (b, g).
 template <int KCH, int KC>
@@ -734,13 +739,18 @@ k_tf_level1(const float *__restrict__ G, const uint8_t *__restrict__ idx, const 
     else tf_table1_body<KCH, KC>(blockIdx.x - pair_blocks - tab_blocks, leaf, G, idx, L, B, N, K, ntab2, per2, tabs2, nact);   // (16 codebooks: the tables of level 3 as well)
 }
 
-// copy COUNT tables of M floats each from global memory to LDS (wave-cooperative).  The loads go out in batches of up to
-// eight per lane before the first LDS write: written as a plain loop the compiler issued load, wait, write per
-// iteration -- a memory round trip per 1 KB.
-template <int M, int COUNT>
+// copy COUNT tables of KH x KH floats each from global memory (rows of KH) to LDS (rows of KH + 1: the odd row stride keeps the
+// score loops' reads -- many rows, few columns per instruction -- off each other's banks; k_tf_comb<16,32> spent 5.4 extra LDS
+// cycles per read on them with rows of 16).  Wave-cooperative; the loads go out in batches of up to eight per lane before the
+// first LDS write: written as a plain loop the compiler issued load, wait, write per iteration -- a memory round trip per 1 KB.
+template <int KH>
+constexpr int tf_tab_stride() { return KH * (KH + 1); }      // floats per table in LDS
+
+template <int KH, int COUNT>
 __device__ __forceinline__ void tf_load_tables(const float *__restrict__ src, float *dst) {
+    constexpr int M = KH * KH, RS = KH + 1, TS = tf_tab_stride<KH>();
     const int lane = lane_id();
-    if constexpr ((COUNT * M) % 256 == 0) {
+    if constexpr ((COUNT * M) % 256 == 0 && KH % 4 == 0) {
         constexpr int IT = COUNT * M / 256;               // float4 per lane
         constexpr int BATCH = IT < 8 ? IT : 8;
 #pragma unroll
@@ -751,7 +761,12 @@ __device__ __forceinline__ void tf_load_tables(const float *__restrict__ src, fl
                 if (i0 + i < IT) r[i] = reinterpret_cast<const f32x4 *>(src)[lane + 64 * (i0 + i)];
 #pragma unroll
             for (int i = 0; i < BATCH; ++i)
-                if (i0 + i < IT) reinterpret_cast<f32x4 *>(dst)[lane + 64 * (i0 + i)] = r[i];
+                if (i0 + i < IT) {
+                    const int e = 4 * (lane + 64 * (i0 + i));      // element of the COUNT tables: table e / M, row, four columns
+                    float *d = dst + (e / M) * TS + ((e % M) / KH) * RS + (e % KH);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) d[c] = r[i][c];
+                }
         }
     } else {
         constexpr int TOT = COUNT * M;                    // (64-entry tables: K == 16)
@@ -760,8 +775,10 @@ __device__ __forceinline__ void tf_load_tables(const float *__restrict__ src, fl
 #pragma unroll
         for (int i = 0; i < IT; ++i) r[i] = (lane + 64 * i < TOT) ? src[lane + 64 * i] : 0.f;
 #pragma unroll
-        for (int i = 0; i < IT; ++i)
-            if (lane + 64 * i < TOT) dst[lane + 64 * i] = r[i];
+        for (int i = 0; i < IT; ++i) {
+            const int e = lane + 64 * i;
+            if (e < TOT) dst[(e / M) * TS + ((e % M) / KH) * RS + (e % KH)] = r[i];
+        }
     }
 }
 
@@ -778,7 +795,7 @@ __device__ __forceinline__ void tf_up(const float *t00, const float *t01, const 
 #pragma unroll
     for (int v = 0; v < VPL; ++v) {
         const int jj0 = py[2 * (j0 + v)], jj1 = py[2 * (j0 + v) + 1];
-        t[v] = ((t00[i0 * KH + jj0] + t01[i0 * KH + jj1]) + t10[i1 * KH + jj0]) + t11[i1 * KH + jj1];
+        t[v] = ((t00[i0 * (KH + 1) + jj0] + t01[i0 * (KH + 1) + jj1]) + t10[i1 * (KH + 1) + jj0]) + t11[i1 * (KH + 1) + jj1];      // (rows of KH + 1: tf_load_tables)
     }
 }
 
@@ -789,8 +806,8 @@ template <int KH, int KC>
 __global__ void __launch_bounds__(64)
 k_tf_up(TfLists L, long B, int N, int u, int ntab, int per, const float *__restrict__ tabs_in, float *__restrict__ tabs_out,
         const int *__restrict__ nact) {
-    constexpr int VPL = KC * KC / 64, MH = KH * KH;
-    __shared__ __attribute__((aligned(16))) float th[4 * MH];
+    constexpr int VPL = KC * KC / 64, MH = KH * KH, TS = tf_tab_stride<KH>();
+    __shared__ __attribute__((aligned(16))) float th[4 * TS];
     if (nact) B = *nact;
     const int t = (int)(blockIdx.x & (unsigned)(ntab - 1));
     const long b = (long)(blockIdx.x >> __builtin_ctz((unsigned)ntab));
@@ -806,10 +823,10 @@ k_tf_up(TfLists L, long B, int N, int u, int ntab, int per, const float *__restr
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-            tf_load_tables<MH, 1>(tabs_in + (cbase + (size_t)(2 * a + i) * (2 * per) + (2 * c + j)) * MH, th + (2 * i + j) * MH);
+            tf_load_tables<KH, 1>(tabs_in + (cbase + (size_t)(2 * a + i) * (2 * per) + (2 * c + j)) * MH, th + (2 * i + j) * TS);
     wave_lds_fence();
     float tv[VPL];
-    tf_up<KH, KC>(th, th + MH, th + 2 * MH, th + 3 * MH, L.pos[u] + ((b * Gu + X) * KC) * 2, L.pos[u] + ((b * Gu + Y) * KC) * 2, tv);
+    tf_up<KH, KC>(th, th + TS, th + 2 * TS, th + 3 * TS, L.pos[u] + ((b * Gu + X) * KC) * 2, L.pos[u] + ((b * Gu + Y) * KC) * 2, tv);
     float *dst = tabs_out + ((size_t)(b * ntab + t) * (KC * KC) + VPL * lane);
 #pragma unroll
     for (int v = 0; v < VPL; ++v) dst[v] = tv[v];
@@ -823,11 +840,11 @@ template <int KH, int KC>
 __global__ void __launch_bounds__(64)
 k_tf_comb(const float *__restrict__ E, TfLists L, long B, int N, int v, int keep, const float *__restrict__ tabs,
           uint8_t *__restrict__ idx_final, const int *__restrict__ nact) {
-    constexpr int MH = KH * KH;
+    constexpr int MH = KH * KH, RS = KH + 1, TS = tf_tab_stride<KH>();
     constexpr int VPL = (KC * KC / 64 <= 16) ? KC * KC / 64 : 16;
     constexpr int CHUNKS = KC * KC / (64 * VPL);
     // (the selection's scratch reuses the tables' LDS: see k_tf_pair1)
-    constexpr int LDSF = (4 * MH * 4 >= kSelectLdsU64 * 8) ? 4 * MH : kSelectLdsU64 * 2;
+    constexpr int LDSF = (4 * TS * 4 >= kSelectLdsU64 * 8) ? 4 * TS : kSelectLdsU64 * 2;
     __shared__ __attribute__((aligned(16))) float th[LDSF];
     u64 *scratch = reinterpret_cast<u64 *>(th);
     // (the chunked selection of 64 x 64 pairs runs while the tables are still being read: its scratch is its own)
@@ -840,7 +857,7 @@ k_tf_comb(const float *__restrict__ E, TfLists L, long B, int N, int v, int keep
     if (b >= B) return;
     const int lane = lane_id();
     const int P = 2 * h, Q = P + 1, Gv = N >> v;
-    tf_load_tables<MH, 4>(tabs + ((size_t)b * Gout + h) * 4 * MH, th);
+    tf_load_tables<KH, 4>(tabs + ((size_t)b * Gout + h) * 4 * MH, th);
     const float Eb = E[b];
     const uint8_t *px = L.pos[v] + ((b * Gv + P) * KC) * 2, *py = L.pos[v] + ((b * Gv + Q) * KC) * 2;
     const float *Sx = L.S[v] + (b * Gv + P) * KC, *Sy = L.S[v] + (b * Gv + Q) * KC;
@@ -849,7 +866,7 @@ k_tf_comb(const float *__restrict__ E, TfLists L, long B, int N, int v, int keep
         const int i = (VPL * lane) / KC, j0 = (VPL * lane) % KC;
         const float se = Sx[i];
         float t[VPL];
-        tf_up<KH, KC>(th, th + MH, th + 2 * MH, th + 3 * MH, px, py, t);
+        tf_up<KH, KC>(th, th + TS, th + 2 * TS, th + 3 * TS, px, py, t);
         float sv[VPL];
         int sp[VPL];
 #pragma unroll
@@ -878,7 +895,7 @@ k_tf_comb(const float *__restrict__ E, TfLists L, long B, int N, int v, int keep
 #pragma unroll
             for (int u = 0; u < VPL; ++u) {
                 const int jj0 = py[2 * (j0 + u)], jj1 = py[2 * (j0 + u) + 1];
-                const float t = ((th[i0 * KH + jj0] + th[MH + i0 * KH + jj1]) + th[2 * MH + i1 * KH + jj0]) + th[3 * MH + i1 * KH + jj1];
+                const float t = ((th[i0 * RS + jj0] + th[TS + i0 * RS + jj1]) + th[2 * TS + i1 * RS + jj0]) + th[3 * TS + i1 * RS + jj1];
                 sv[u] = ((se + Sy[j0 + u]) - Eb) + 2.0f * t;
                 sp[u] = p0 + u;
             }
@@ -902,7 +919,7 @@ k_tf_comb(const float *__restrict__ E, TfLists L, long B, int N, int v, int keep
 #pragma unroll
             for (int u = 0; u < VPL; ++u) {
                 const int jj0 = py[2 * (j0 + u)], jj1 = py[2 * (j0 + u) + 1];
-                const float t = ((th[i0 * KH + jj0] + th[MH + i0 * KH + jj1]) + th[2 * MH + i1 * KH + jj0]) + th[3 * MH + i1 * KH + jj1];
+                const float t = ((th[i0 * RS + jj0] + th[TS + i0 * RS + jj1]) + th[2 * TS + i1 * RS + jj0]) + th[3 * TS + i1 * RS + jj1];
                 lexmin(bv, bp, ((se + Sy[j0 + u]) - Eb) + 2.0f * t, p0 + u);
             }
         }
@@ -922,10 +939,11 @@ template <int KC1, int KC2, int KC3>
 __global__ void __launch_bounds__(256)
 k_tf_comb3(const uint8_t *__restrict__ idx, const float *__restrict__ E, TfLists L, long B, int N,
            const float *__restrict__ tabs, uint8_t *__restrict__ idx_final, const int *__restrict__ nact) {
-    constexpr int VPL2 = KC2 * KC2 / 64, M1 = KC1 * KC1, M2 = KC2 * KC2;
+    constexpr int VPL2 = KC2 * KC2 / 64, M1 = KC1 * KC1;
     constexpr int PW = KC3 * KC3 / 4, VPLW = PW / 64;          // candidate pairs per wave, per lane
-    __shared__ __attribute__((aligned(16))) float t1[16 * M1];
-    __shared__ __attribute__((aligned(16))) float t2[4 * M2];
+    constexpr int RS1 = KC1 + 1, TS1 = tf_tab_stride<KC1>(), RS2 = KC2 + 1, TS2 = KC2 * RS2;      // rows of an odd length: tf_load_tables
+    __shared__ __attribute__((aligned(16))) float t1[16 * TS1];
+    __shared__ __attribute__((aligned(16))) float t2[4 * TS2];
     __shared__ float wv[4];
     __shared__ int wp[4];
     (void)idx;
@@ -961,20 +979,20 @@ k_tf_comb3(const uint8_t *__restrict__ idx, const float *__restrict__ E, TfLists
     }
     const float sx3 = Sx[i3];
     const float Eb = E[b];
-    tf_load_tables<M1, 4>(tabs + ((size_t)b * 16 + 4 * w) * M1, t1 + 4 * w * M1);
+    tf_load_tables<KC1, 4>(tabs + ((size_t)b * 16 + 4 * w) * M1, t1 + 4 * w * TS1);
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
     {
         const int X0 = 2 * xc, Y0 = 2 * yc;      // Y0 relative to 4
-        const float *t00 = t1 + (4 * X0 + Y0) * M1, *t01 = t1 + (4 * X0 + Y0 + 1) * M1, *t10 = t1 + (4 * (X0 + 1) + Y0) * M1,
-                    *t11 = t1 + (4 * (X0 + 1) + Y0 + 1) * M1;
+        const float *t00 = t1 + (4 * X0 + Y0) * TS1, *t01 = t1 + (4 * X0 + Y0 + 1) * TS1, *t10 = t1 + (4 * (X0 + 1) + Y0) * TS1,
+                    *t11 = t1 + (4 * (X0 + 1) + Y0 + 1) * TS1;
         const int i0 = (int)(pxw2 & 0xffu), i1 = (int)(pxw2 >> 8);
-        float *dst = t2 + w * M2 + VPL2 * lane;
+        float *dst = t2 + w * TS2 + i2 * RS2 + j2;          // (a lane's VPL2 columns lie in one row: VPL2 divides KC2)
 #pragma unroll
         for (int v = 0; v < VPL2; ++v) {
             const uint32_t wj = pyw2[v >> 1] >> (16 * (v & 1));
             const int jj0 = (int)(wj & 0xffu), jj1 = (int)((wj >> 8) & 0xffu);
-            dst[v] = ((t00[i0 * KC1 + jj0] + t01[i0 * KC1 + jj1]) + t10[i1 * KC1 + jj0]) + t11[i1 * KC1 + jj1];
+            dst[v] = ((t00[i0 * RS1 + jj0] + t01[i0 * RS1 + jj1]) + t10[i1 * RS1 + jj0]) + t11[i1 * RS1 + jj1];
         }
     }
     __syncthreads();
@@ -985,7 +1003,7 @@ k_tf_comb3(const uint8_t *__restrict__ idx, const float *__restrict__ E, TfLists
 #pragma unroll
         for (int v = 0; v < VPLW; ++v) {
             const int jj0 = (int)(pyw3[v] & 0xffu), jj1 = (int)(pyw3[v] >> 8);
-            const float t = ((t2[i0 * KC2 + jj0] + t2[M2 + i0 * KC2 + jj1]) + t2[2 * M2 + i1 * KC2 + jj0]) + t2[3 * M2 + i1 * KC2 + jj1];
+            const float t = ((t2[i0 * RS2 + jj0] + t2[TS2 + i0 * RS2 + jj1]) + t2[2 * TS2 + i1 * RS2 + jj0]) + t2[3 * TS2 + i1 * RS2 + jj1];
             lexmin(bv, bp, ((sx3 + sy3[v]) - Eb) + 2.0f * t, p0 + v);
         }
     }
