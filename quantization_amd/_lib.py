@@ -7,8 +7,11 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# MCQ_LIB_PATH: another build of the same library (A/B timing of kernel variants on one box; tools/ only)
-LIB_PATH = os.environ.get("MCQ_LIB_PATH") or os.path.join(_HERE, "lib", "libmcq_hip.so")
+# Another build of the same library for same-box A/B timing of kernel variants (tools/ab_lib.sh): honoured only when the process
+# opts in with MCQ_ALLOW_LIB_PATH=1 beside MCQ_LIB_PATH, so that a deployed process never loads a library an inherited
+# environment variable names.
+_ALT = os.environ.get("MCQ_LIB_PATH") if os.environ.get("MCQ_ALLOW_LIB_PATH") == "1" else None
+LIB_PATH = _ALT or os.path.join(_HERE, "lib", "libmcq_hip.so")
 
 # every symbol include/mcq.h declares
 SYMBOLS = (

@@ -51,6 +51,11 @@ PreparedLayout prepared_layout(int N, int K, int D) {
     l.offCMean = align256(l.offMean + Dp * 4);    // the codebooks' own means mu_n, float[N][Dp] (mean = mu_0 + mu_1 + ...)
     l.offG = align256(l.offCMean + (size_t)N * Dp * 4);   // Gram matrix G[nk][nk] of the CENTERED rows C[n][k] - mu_n
     l.total = align256(l.offG + nk * nk * 4);
+    // k_fgemm's epilogue DMA-copies 128 bias floats per row tile without a bound check: rows past N*K of the last tile read what
+    // FOLLOWS the bias (scale factors, means, the Gram matrix: finite floats inside this blob; such rows belong to no codebook and
+    // their values are never stored).  The layout guarantees those bytes exist:
+    static_assert(kFixTile == 128, "");
+    if (l.total < l.offBias + (nk + kFixTile) * 4) l.total = align256(l.offBias + (nk + kFixTile) * 4);
     return l;
 }
 

@@ -151,8 +151,8 @@ __device__ __forceinline__ u64 wave_kth_lane_key(u64 k, int target) {
         rr = __popcll(ltm);
         const u64 lo = cm & ltm, hi = cm & ~(ltm | (1ull << pl));
         cm = (rr > target) ? lo : hi;
-    } while (rr != target);
-    return kp;
+    } while (rr != target && cm != 0);      // (cm == 0 before the target is met: only with equal keys, which callers never build)
+    return rr == target ? kp : kKeyMax;
 }
 
 template <int VPL>

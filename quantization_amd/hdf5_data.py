@@ -14,6 +14,7 @@ count is int(...) of the same expression, so small archives work; for archives t
 identical (same order of datasets, same np.random.shuffle call on the same matrix).
 """
 import logging
+import mmap
 import struct
 from typing import Dict, List, Tuple
 
@@ -32,8 +33,8 @@ class MiniHdf5File:
     """Read-only view of the datasets of the ROOT group of an HDF5 file (see the module docstring for the subset)."""
 
     def __init__(self, filename: str):
-        with open(filename, "rb") as f:
-            self.buf = f.read()
+        with open(filename, "rb") as f:      # mapped, not read: a dataset is only paged in when it is copied out
+            self.buf = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
         b = self.buf
         base = -1
         off = 0
@@ -100,7 +101,7 @@ class MiniHdf5File:
         return self._addr(self._off(p + 8 + 2 * self.L))
 
     def _name(self, heap_data: int, off: int) -> str:
-        e = self.buf.index(b"\0", heap_data + off)
+        e = self.buf.find(b"\0", heap_data + off)
         return self.buf[heap_data + off:e].decode("utf-8")
 
     def _group_entries(self, btree: int, heap_data: int, out: List[Tuple[str, int]]):
@@ -153,7 +154,8 @@ class MiniHdf5File:
             raise Hdf5FormatError(f"element type class {cls} of {size} bytes is not supported by the built-in reader")
         return np.dtype(order + kind if size > 1 else kind)
 
-    def read(self, name: str) -> np.ndarray:
+    def _describe(self, name: str):
+        """(shape, element type, offset of the data layout message) of a dataset, from its object header alone."""
         b = self.buf
         shape, dtype, layout = None, None, None
         for mtype, data, _size in self._messages(self.datasets()[name]):
@@ -169,6 +171,14 @@ class MiniHdf5File:
                 raise Hdf5FormatError(f"dataset {name!r} uses a filter pipeline (compression); install h5py to read it")
         if shape is None or dtype is None or layout is None:
             raise Hdf5FormatError(f"{name!r} is not a simple dataset")
+        return shape, dtype, layout
+
+    def shape(self, name: str) -> Tuple[int, ...]:
+        return self._describe(name)[0]
+
+    def read(self, name: str) -> np.ndarray:
+        b = self.buf
+        shape, dtype, layout = self._describe(name)
         count = int(np.prod(shape, dtype=np.int64)) if shape else 1
         if b[layout] != 3:
             raise Hdf5FormatError(f"data layout message version {b[layout]} not supported")
@@ -217,56 +227,50 @@ class MiniHdf5File:
             q += key + self.O
 
 
-def _open(filename: str):
-    """(keys in the archive's iteration order, shape(key), array(key)) through h5py when it is there, else MiniHdf5File."""
-    try:
-        import h5py  # noqa: F401
-    except ImportError:
-        mf = MiniHdf5File(filename)
-        cache = {}
+class _Archive:
+    """The datasets of an archive in its iteration order: through h5py when it is importable, else MiniHdf5File."""
 
-        def arr(k):
-            if k not in cache:
-                cache.clear()                           # one dataset alive at a time
-                cache[k] = mf.read(k)
-            return cache[k]
-        return mf.keys(), (lambda k: arr(k).shape), arr
-    hf = h5py.File(filename, "r")
-    return list(hf.keys()), (lambda k: hf[k].shape), (lambda k: hf[k][:])
+    def __init__(self, filename: str):
+        try:
+            import h5py
+            self._h5, self._mini = h5py.File(filename, "r"), None
+            self.names = list(self._h5.keys())
+        except ImportError:
+            self._h5, self._mini = None, MiniHdf5File(filename)
+            self.names = self._mini.keys()
+
+    def shape(self, name: str) -> Tuple[int, ...]:
+        return tuple(self._h5[name].shape) if self._h5 is not None else self._mini.shape(name)
+
+    def rows(self, name: str, dim: int) -> np.ndarray:
+        """the dataset as a (frames, dim) matrix"""
+        a = self._h5[name][:] if self._h5 is not None else self._mini.read(name)
+        return np.ascontiguousarray(a).reshape(-1, dim)
 
 
 def read_hdf5_data(filename: str) -> Tuple[torch.Tensor, torch.Tensor]:
-    """(train, valid): CPU float16 tensors (tot_train_frames, dim) and (tot_valid_frames, dim) with shuffled rows; valid is
-    5 % of the frames, at most 10,000.  quantization.py:746-820 (shuffle: numpy's global RNG, as there)."""
+    """(train, valid) as the reference's helper of the same name returns them (quantization.py:746-820): all datasets of the
+    archive stacked into one float16 matrix of frames, its rows shuffled with numpy's GLOBAL generator (so a caller's
+    np.random.seed gives the reference's split), the first 5 % of the shuffled rows -- 10,000 at most -- as `valid`, the rest as
+    `train`.  Both are CPU tensors viewing that one matrix."""
     logging.info(f"Opening file {filename}")
-    keys, shape_of, array_of = _open(filename)
-    tot_frames, dim = 0, -1
-    for key in keys:                                                        # quantization.py:786-794
-        shape = list(shape_of(key))
-        if dim == -1:
-            dim = shape[-1]
-        else:
-            assert dim == shape[-1], "Dataset must have consistent dimension (last element of shape"
-        num_frames = 1
-        for i in shape[:-1]:
-            num_frames *= i
-        tot_frames += num_frames
-    logging.info(f"read_data: tot_frames = {tot_frames}")
-    ans = np.empty((tot_frames, dim), dtype=np.float16)
-    cur_pos = 0
-    for key in keys:                                                        # :797-803
-        array = np.ascontiguousarray(array_of(key)).reshape(-1, dim)
-        num_frames = array.shape[0]
-        ans[cur_pos:cur_pos + num_frames, :] = array
-        cur_pos += num_frames
-    assert cur_pos == tot_frames
-    np.random.shuffle(ans)                                                  # :806
-    ans_torch = torch.from_numpy(ans)
-    valid_proportion = 0.05
-    valid_frames = valid_proportion * tot_frames
-    if valid_frames > 10000:
-        valid_frames = 10000
-    valid_frames = int(valid_frames)             # (the reference slices with the float: module docstring)
-    train_frames = tot_frames - valid_frames
-    logging.info(f"read_data: train_frames={train_frames}, valid_frames={valid_frames}")
-    return ans_torch[valid_frames:tot_frames], ans_torch[:valid_frames]
+    archive = _Archive(filename)
+    # one pass over the headers: how many frames each dataset brings (everything but the last axis), one common feature dimension
+    shapes = [archive.shape(name) for name in archive.names]
+    dims = {sh[-1] for sh in shapes}
+    assert len(dims) <= 1, "Dataset must have consistent dimension (last element of shape"
+    dim = dims.pop() if dims else -1
+    counts = [int(np.prod(sh[:-1], dtype=np.int64)) for sh in shapes]
+    starts = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    total = int(starts[-1])
+    logging.info(f"read_data: tot_frames = {total}")
+    frames = np.empty((total, dim), dtype=np.float16)
+    for name, lo, n in zip(archive.names, starts[:-1], counts):             # second pass: the data, dataset after dataset
+        block = archive.rows(name, dim)
+        assert block.shape[0] == n, (name, block.shape, n)
+        frames[lo:lo + n] = block
+    np.random.shuffle(frames)
+    n_valid = min(int(0.05 * total), 10000)      # (the reference slices with the float itself: module docstring)
+    logging.info(f"read_data: train_frames={total - n_valid}, valid_frames={n_valid}")
+    rows = torch.from_numpy(frames)
+    return rows[n_valid:], rows[:n_valid]

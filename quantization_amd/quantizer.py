@@ -116,17 +116,22 @@ class Quantizer(nn.Module):
         return st
 
     # the scale factors of the CURRENT derived state (set by _prepared, dropped with it)
+    def _current_prep(self):
+        if self._prep is None:      # (after invalidate_cache / load_state_dict / unpickling: _prepared() has to run first)
+            raise RuntimeError("no derived state: call Quantizer._prepared() before reading its scale factors")
+        return self._prep
+
     @property
     def _scale_flags(self) -> int:
-        return self._prep.scale_flags
+        return self._current_prep().scale_flags
 
     @property
     def _lscale_exp(self) -> float:
-        return self._prep.lscale_exp
+        return self._current_prep().lscale_exp
 
     @property
     def _cscale_exp(self) -> float:
-        return self._prep.cscale_exp
+        return self._current_prep().cscale_exp
 
     @property
     def _scales_dev(self):

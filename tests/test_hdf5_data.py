@@ -44,7 +44,17 @@ def test_read_hdf5_data_from_a_file(monkeypatch):
 def test_split_equals_the_reference(monkeypatch):
     exp = json.load(open(os.path.join(G, "hdf5_split_expected.json")))
     sets = synthetic_archive()
-    monkeypatch.setattr(hdf5_data, "_open", lambda fn: (list(sets.keys()), (lambda k: sets[k].shape), (lambda k: sets[k])))
+    class FakeArchive:                      # the datasets handed over in memory: the test is about stack / shuffle / split
+        def __init__(self, fn):
+            self.names = list(sets.keys())
+
+        def shape(self, k):
+            return sets[k].shape
+
+        def rows(self, k, dim):
+            return np.ascontiguousarray(sets[k]).reshape(-1, dim)
+
+    monkeypatch.setattr(hdf5_data, "_Archive", FakeArchive)
     np.random.seed(exp["seed"])
     train, valid = read_hdf5_data("in-memory")
     assert list(train.shape) == exp["train_shape"] and list(valid.shape) == exp["valid_shape"]
@@ -55,7 +65,17 @@ def test_split_equals_the_reference(monkeypatch):
 
 def test_inconsistent_dim_asserts(monkeypatch):
     sets = {"a": np.zeros((4, 8), np.float16), "b": np.zeros((4, 6), np.float16)}
-    monkeypatch.setattr(hdf5_data, "_open", lambda fn: (list(sets.keys()), (lambda k: sets[k].shape), (lambda k: sets[k])))
+    class FakeArchive:                      # the datasets handed over in memory: the test is about stack / shuffle / split
+        def __init__(self, fn):
+            self.names = list(sets.keys())
+
+        def shape(self, k):
+            return sets[k].shape
+
+        def rows(self, k, dim):
+            return np.ascontiguousarray(sets[k]).reshape(-1, dim)
+
+    monkeypatch.setattr(hdf5_data, "_Archive", FakeArchive)
     with pytest.raises(AssertionError):                 # quantization.py:792
         read_hdf5_data("in-memory")
 

@@ -1,5 +1,5 @@
 """encode time of the trainer's first-phase shape (16 x 16 codebooks, dim 512) at a trainer batch and at 65,536 vectors;
-MCQ_LIB_PATH=... python tools/ab_k16.py"""
+MCQ_ALLOW_LIB_PATH=1 MCQ_LIB_PATH=... python tools/ab_k16.py"""
 import os
 import sys
 

@@ -1,5 +1,5 @@
 """ms per QuantizerTrainer.step in both phases (bench.py's trainer_leg) -- run once per library build by tools/ab_lib.sh-style
-loops: MCQ_LIB_PATH=... python tools/ab_trainer.py [batch] [iters]"""
+loops: MCQ_ALLOW_LIB_PATH=1 MCQ_LIB_PATH=... python tools/ab_trainer.py [batch] [iters]"""
 import os
 import sys
 
