@@ -174,3 +174,44 @@ def test_reduction_none_and_autocast():
     tot.backward()
     assert all(torch.equal(a.detach(), b.detach()) for a, b in zip(la, lb))
     assert all(torch.equal(ga[k], p.grad) for k, p in q.named_parameters())
+
+
+@pytest.mark.gpu
+def test_downstream_scenario_follows_the_reference():
+    """The reference's downstream scenario (test_train_hdf5.py:79-134) at a size the CPU reference trains in seconds: a Quantizer
+    TRAINED BY THE REFERENCE encodes seeded frames on the MI355X, a JointCodebookLoss learns to predict the codes from the frames
+    (Adam, lr 1e-3, StepLR as in that script).  tests/golden/make_golden_downstream.py ran the same 300 steps with the reference
+    on CPU from the same initial predictor: the loss curves must coincide -- step 0 (identical parameters, the codes of 512
+    frames) to 1e-5, every step to 1 %, the last 20 steps' mean to 0.3 %."""
+    from quantization_amd import JointCodebookLoss, Quantizer
+    from golden import gen
+    fx = np.load(os.path.join(HERE, "golden", "downstream_d64_b4.npz"))
+    D, NB, B, steps = int(fx["D"]), int(fx["bytes"]), int(fx["B"]), int(fx["steps"])
+    dev = torch.device("cuda:0")
+    q = Quantizer(D, 256, NB)
+    q.load_state_dict({k[len("quantizer."):]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("quantizer.")})
+    q = q.to(dev)
+    predictor = JointCodebookLoss(predictor_channels=D, num_codebooks=NB)
+    predictor.load_state_dict({k[len("predictor_init."):]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("predictor_init.")})
+    predictor = predictor.to(dev)
+    optim = torch.optim.Adam(predictor.parameters(), lr=0.001, betas=(0.9, 0.98), eps=1e-9, weight_decay=1.0e-06)
+    scheduler = torch.optim.lr_scheduler.StepLR(optim, step_size=2000, gamma=0.5)
+    losses = []
+    for s in range(steps):
+        x = torch.from_numpy(gen.make_x(int(fx["data_seed"]) + s, B, D)).to(dev)
+        with torch.no_grad():
+            encoding = q.encode(x)
+        assert encoding.dtype == torch.uint8 and tuple(encoding.shape) == (B, NB)
+        loss = predictor(x, encoding) / x.shape[0]
+        losses.append(float(loss.detach()))
+        loss.backward()
+        optim.step()
+        optim.zero_grad()
+        scheduler.step()
+    losses, ref = np.array(losses), fx["losses"]
+    rel = np.abs(losses - ref) / ref
+    print("downstream scenario: first %.4f (reference %.4f), last-20 mean %.4f (%.4f), largest relative deviation %.2e"
+          % (losses[0], ref[0], losses[-20:].mean(), ref[-20:].mean(), rel.max()))
+    assert rel[0] <= 1e-5 and rel.max() <= 1e-2, (rel[0], rel.max())
+    assert abs(losses[-20:].mean() - ref[-20:].mean()) <= 3e-3 * ref[-20:].mean()
+    assert losses[-20:].mean() < 0.45 * losses[0]                   # it learned to predict the codes
