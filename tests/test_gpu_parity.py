@@ -621,3 +621,23 @@ def test_decode_only_state_is_small_and_a_later_search_rebuilds():
     for n in range(1, N):
         acc = acc + ref[:, n]
     assert torch.equal(y0, acc) and tuple(c.shape) == (300, N)
+
+
+def test_config_e_phase_one_state_bit_exact_vs_oracle():
+    """The quantizer the REFERENCE's trainer starts BASELINE config E with (16 codebooks of 16 entries at dim 512: the initial
+    state of tests/golden/trainer_config_e_d512_b8.npz) on a config-E batch of 4,096 frames: codes for 0, 1 and 2 passes -- what a
+    training step asks for -- bit-exact against the oracle, as int64 and as packed bytes."""
+    import os
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "trainer_config_e_d512_b8.npz"))
+    state = {k[len("init."):]: fx[k] for k in fx.files if k.startswith("init.") and k != "init.id_buf"}
+    D, K, N = 512, 16, 16
+    assert state["centers"].shape == (N, K, D)
+    q = load_quantizer(state, D, K, N)
+    o = oracle_of(state)
+    x = gen.make_x(int(fx["data_seed"]), 4096, D)
+    xg = torch.from_numpy(x).cuda()
+    for it in (0, 1, 2):
+        want = o.compute_indexes(x, it)
+        got = q.encode(xg, it, as_bytes=False).cpu().numpy()
+        assert np.array_equal(got, want), (it, int((got != want).any(axis=1).sum()))
+    assert np.array_equal(q.encode(xg, 2).cpu().numpy(), o.encode(x, 2))
