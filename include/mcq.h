@@ -49,9 +49,10 @@ extern "C" {
 #define MCQ_EUNSUPPORTED (-2) /* outside the supported (K, N) domain             */
 #define MCQ_EWORKSPACE (-3) /* workspace smaller than mcq_encode_workspace_bytes */
 
-#define MCQ_ABI_VERSION 6   /* 6: the tables of the search are formed from CENTERED rows and frames (`prepared` also holds the codebooks' own
-                               means, Q and the Gram matrix are those of C[n][k] - mu_n; the encode workspace holds two sets of frame
-                               planes: sizes changed, signatures did not), mcq_profile_encode times the shipped launch sequence and
+#define MCQ_ABI_VERSION 6   /* 6: the products of the path are formed from CENTERED rows and frames (`prepared` also holds the codebooks' own
+                               means and the classifier rows' products with the data mean, Q and the Gram matrix are those of
+                               C[n][k] - mu_n, the frame planes of the workspace those of x - mean: sizes changed, signatures did
+                               not), mcq_profile_encode times the shipped launch sequence and
                                reports per-category launch counts, mcq_profile_category_name is new;
                                5: mcq_prepared_decode_bytes, 64 codebooks for every codebook size, and (additions) mcq_prepare_params,
                                mcq_logits_refine_codes, mcq_loss_head_tail; 4: fixed-point products: `prepared` holds limb planes of the centers and the classifier
@@ -68,8 +69,10 @@ int mcq_padded_dim(int D);
  * `prepared` receives: scaled centers C[N][K][Dp] = cscale_exp * centers (what decode sums), the codebooks' own means
  * mu_n = mean_k C[n][k] and their sum (= get_data_mean(), :67-75), and -- when weight is given -- what the search reads:
  * the CENTERED rows C[n][k] - mu_n as 8-bit limb planes with their row exponents, their sums of squares Q[N][K] (:411),
- * the rows of to_logits.weight as limb planes, the bias, and the Gram matrix G[N*K][N*K] of the centered rows (16 MB at
- * 8 x 256; what the refinement passes read).  The search is invariant under this shift (oracle/mcq_oracle.c, "CENTERING").
+ * the rows of to_logits.weight as limb planes and their products with the data mean (the frames of both products are centered: a
+ * logit is ((fixdot(x - mean, W_r) + fixdot(mean, W_r)) * lscale) + bias_r), the bias, and the Gram matrix G[N*K][N*K] of the
+ * centered rows (16 MB at 8 x 256; what the refinement passes read).  The search is invariant under this shift
+ * (oracle/mcq_oracle.c, "CENTERING").
  * cscale_exp / lscale_exp = exp(10*centers_scale) / exp(10*logits_scale), formed
  * by the caller in fp32 exactly as the reference does (:78, :278).
  * weight/bias may be NULL when only decode is needed: `prepared` then receives the scaled centers

@@ -47,7 +47,9 @@
  * reference on frames with a common offset of 10 the uncentered form differs from the reference on 5-7 of 2,048 near-tie
  * vectors, the centered form on 0-1, which is the reference's own reorder noise (its codes against those of its
  * feature-permuted run: 1).  Gate run over all 25 fixtures: 16 -> 4 near-tie differences, 0 with a clear margin either way
- * (DESIGN.md section 2).  The logits (:277-279) and decode (:131-148) use x and C as they are.
+ * (DESIGN.md section 2).  The logits (:277-279) are formed from the centered frame as well, with what the shift takes out of
+ * them added back exactly once per row (frame_logits: the same gate result; one set of frame limbs serves both products);
+ * decode (:131-148) uses C as it is.
  *
  * TABLE FORM of the refinement pass.  The reference recomputes, per vector and pass, inner products that are
  * linear in codebook rows (:403-416, :533-535); here they are READ from two tables (SURVEY.md section 7 "hard
@@ -94,6 +96,7 @@ typedef struct {
     float *G;      /* [N*K][N*K]   fixdot(Cc[r], Cc[c]); built on first use */
     float *Cc;     /* [N][K][Dp]   centered rows C[n][k] - mu_n (the operands of every table of the search) */
     float *mu;     /* [Dp]         sum_n mu_n: what a frame is centered by                 */
+    float *wmu;    /* [N*K]        fixdot(mu, W[r]): what centering the frame takes out of a logit */
 } mcq_oracle;
 
 static int g_center = -1;     /* experiment switch MCQ_ORACLE_CENTER (default on) */
@@ -211,13 +214,21 @@ mcq_oracle *mcq_oracle_create(const float *centers, float cscale_exp, const floa
         o->bias = (float *)malloc(nk * sizeof(float));
         memcpy(o->bias, bias, nk * sizeof(float));
         fix_rows(W, nk, D, Dp, o->Wl, o->We);
+        o->wmu = (float *)malloc(nk * sizeof(float));
+        {
+            int8_t *ml = (int8_t *)malloc((size_t)4 * Dp);
+            int me;
+            fix_rows(o->mu, 1, Dp, Dp, ml, &me);
+            for (size_t r = 0; r < nk; r++) o->wmu[r] = fixdot(ml, me, o->Wl + r * 4 * Dp, o->We[r], Dp);
+            free(ml);
+        }
     }
     return o;
 }
 
 void mcq_oracle_free(mcq_oracle *o) {
     if (!o) return;
-    free(o->C); free(o->Cl); free(o->Ce); free(o->Q); free(o->Wl); free(o->We); free(o->bias); free(o->G); free(o->Cc); free(o->mu); free(o);
+    free(o->C); free(o->Cl); free(o->Ce); free(o->Q); free(o->Wl); free(o->We); free(o->bias); free(o->G); free(o->Cc); free(o->mu); free(o->wmu); free(o);
 }
 
 /* copy of the scaled centers (N,K,D) and their sumsq, for tests */
@@ -287,14 +298,8 @@ static void scratch_alloc(scratch *s, int N, int K, int Dp) {
 
 static void scratch_free(scratch *s) { free(s->xpad); free(s->S); free(s->pos); }
 
-/* the frame as fixed point: limbs [4][Dp] and its exponent (shared by the logits and the x.C products) */
-static int frame_limbs(const mcq_oracle *o, const float *x, int8_t *xl) {
-    int e;
-    fix_rows(x, 1, o->D, o->Dp, xl, &e);
-    return e;
-}
-
-/* the frame the tables of the search see: x - mu (zero padded), as fixed point; xcen_out (optional) receives the floats */
+/* the frame every product of the path sees: x - mu (zero padded), as fixed point (limbs [4][Dp] and the exponent); xcen receives
+ * the floats */
 static int frame_limbs_centered(const mcq_oracle *o, const float *x, int8_t *xl, float *xcen) {
     int e;
     for (int d = 0; d < o->Dp; d++) xcen[d] = (d < o->D) ? x[d] - o->mu[d] : 0.0f;
@@ -302,11 +307,12 @@ static int frame_limbs_centered(const mcq_oracle *o, const float *x, int8_t *xl,
     return e;
 }
 
-/* logits (:277-279) of one frame: (fixdot(x, W[r]) * exp(logits_scale)) + bias[r] */
+/* logits (:277-279) of one frame, from the CENTERED frame: x . W[r] = (x - mu) . W[r] + mu . W[r], so
+ * ((fixdot(x - mu, W[r]) + wmu[r]) * exp(logits_scale)) + bias[r] with wmu[r] = fixdot(mu, W[r]) (per state) */
 static void frame_logits(const mcq_oracle *o, const int8_t *xl, int xe, float *out) {
     const size_t nk = (size_t)o->N * o->K;
     for (size_t r = 0; r < nk; r++)
-        out[r] = fixdot(xl, xe, o->Wl + r * 4 * o->Dp, o->We[r], o->Dp) * o->lscale + o->bias[r];
+        out[r] = (fixdot(xl, xe, o->Wl + r * 4 * o->Dp, o->We[r], o->Dp) + o->wmu[r]) * o->lscale + o->bias[r];
 }
 
 /* A.1: initial indexes from the logits (:297-301) */
@@ -565,9 +571,9 @@ int mcq_oracle_compute_indexes(const mcq_oracle *o, const float *x, long B, int 
 #pragma omp for schedule(dynamic, 8)
         for (long b = 0; b < B; b++) {
             uint8_t *id = idx + (size_t)b * N;
-            const int xe = frame_limbs(o, x + (size_t)b * D, xl);
+            const int xe = frame_limbs_centered(o, x + (size_t)b * D, xl, s.xpad);
             init_indexes(o, xl, xe, id, acc);
-            if (iters > 0) compute_xc(o, xl, frame_limbs_centered(o, x + (size_t)b * D, xl, s.xpad), xc);
+            if (iters > 0) compute_xc(o, xl, xe, xc);
             for (int it = 0; it < iters; it++) refine_any(o, x + (size_t)b * D, xc, id, &s, NULL);
         }
         free(acc); free(xl); free(xc); scratch_free(&s);
@@ -622,12 +628,13 @@ int mcq_oracle_logits(const mcq_oracle *o, const float *x, long B, float *logits
 #pragma omp parallel
     {
         int8_t *xl = (int8_t *)malloc((size_t)4 * o->Dp);
+        float *xcen = (float *)malloc(sizeof(float) * o->Dp);
 #pragma omp for schedule(static)
         for (long b = 0; b < B; b++) {
-            const int xe = frame_limbs(o, x + (size_t)b * o->D, xl);
+            const int xe = frame_limbs_centered(o, x + (size_t)b * o->D, xl, xcen);
             frame_logits(o, xl, xe, logits + (size_t)b * nk);
         }
-        free(xl);
+        free(xl); free(xcen);
     }
     return 0;
 }

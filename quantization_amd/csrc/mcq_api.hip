@@ -26,13 +26,13 @@ int k_cutoff(int K, int L) {
 }
 
 struct Prepared {
-    const float *C, *Q, *bias, *scales, *G, *mean;
+    const float *C, *Q, *bias, *scales, *G, *mean, *wmu;
     const int8_t *Cf, *Wf;      // limb planes of the scaled centers / of to_logits.weight (mcq_fix_kernels.h)
     const int *Ce, *We;         // their row exponents
 };
 
 struct PreparedLayout {
-    size_t offC, offQ, offCf, offCe, offWf, offWe, offBias, offScales, offMean, offCMean, offG, total;
+    size_t offC, offQ, offCf, offCe, offWf, offWe, offWmu, offBias, offScales, offMean, offCMean, offG, total;
 };
 
 PreparedLayout prepared_layout(int N, int K, int D) {
@@ -45,7 +45,8 @@ PreparedLayout prepared_layout(int N, int K, int D) {
     l.offCe = align256(l.offCf + planes);
     l.offWf = align256(l.offCe + exps);
     l.offWe = align256(l.offWf + planes);
-    l.offBias = align256(l.offWe + exps);
+    l.offWmu = align256(l.offWe + exps);          // fixdot(data mean, W[r]), float[nk] (the logits product reads centered frames)
+    l.offBias = align256(l.offWmu + nk * 4);
     l.offScales = align256(l.offBias + nk * 4);   // float[2] {cscale_exp, lscale_exp} (mcq_prepare_dev)
     l.offMean = align256(l.offScales + 8);        // get_data_mean() of the scaled centers, float[Dp]
     l.offCMean = align256(l.offMean + Dp * 4);    // the codebooks' own means mu_n, float[N][Dp] (mean = mu_0 + mu_1 + ...)
@@ -65,6 +66,7 @@ Prepared prepared_view(const void *p, int N, int K, int D) {
     return Prepared{reinterpret_cast<const float *>(b + l.offC), reinterpret_cast<const float *>(b + l.offQ),
                     reinterpret_cast<const float *>(b + l.offBias), reinterpret_cast<const float *>(b + l.offScales),
                     reinterpret_cast<const float *>(b + l.offG), reinterpret_cast<const float *>(b + l.offMean),
+                    reinterpret_cast<const float *>(b + l.offWmu),
                     reinterpret_cast<const int8_t *>(b + l.offCf), reinterpret_cast<const int8_t *>(b + l.offWf),
                     reinterpret_cast<const int *>(b + l.offCe), reinterpret_cast<const int *>(b + l.offWe)};
 }
@@ -74,10 +76,8 @@ struct Workspace {
     int *map[2], *cnt;
     float *E, *R, *xx, *XC;                   // per vector: |x_err|^2, |x_err - old_n|^2, |x|^2, x.C products
     float *gterms;                            // per vector: the N*N Gram entries G[o_m][o_m2] of the current indexes
-    int8_t *xf;                               // limb planes of the CENTERED frames of a chunk (x - mean: the x.C product)
+    int8_t *xf;                               // limb planes of the CENTERED frames of a chunk (x - mean: both products read them)
     int *xe;                                  // and their row exponents
-    int8_t *xfr;                              // limb planes of the frames as they are (the logits product)
-    int *xer;
     float *tabs[2];                           // group tables of two consecutive levels (ping-pong)
     TfLists tf;                               // candidate lists of every level
 };
@@ -103,10 +103,10 @@ size_t workspace_per_vector(int N, int K, int D) {
     // idx x4, maps, E, xx, R, XC, lists (entries / positions / scores: <= 16 + 2*16 + 4*16 bytes per codebook and level), tabs x2,
     // the frame as limb planes + its exponent, the N*N Gram terms of E / R
     return 4 * (size_t)N + 8 + 8 + 4 * (size_t)N + 4 * (size_t)N * K + (size_t)tf_levels(N) * N * (16 + 2 * 16 + 4 * 16) + 64 +
-           2 * 4 * tf_tab_floats(N, K) + 2 * (4 * (size_t)fix_round_cols(D) + 4) + 4 * (size_t)N * N;
+           2 * 4 * tf_tab_floats(N, K) + 4 * (size_t)fix_round_cols(D) + 4 + 4 * (size_t)N * N;
 }
 // alignment of the carved arrays + the rows the limb planes are padded by (to a multiple of 128)
-size_t workspace_slack(int D) { return 52 * 256 + 2 * (size_t)kFixTile * (4 * (size_t)fix_round_cols(D) + 4); }
+size_t workspace_slack(int D) { return 48 * 256 + (size_t)kFixTile * (4 * (size_t)fix_round_cols(D) + 4); }
 
 // default chunk: 65,536 vectors, fewer when a vector's share of the workspace is large (N >= 32), so that the workspace
 // mcq_encode_workspace_bytes asks for stays near 2 GB
@@ -135,8 +135,6 @@ Workspace carve(void *ws, long Bc, int N, int K, int D) {
     w.XC = reinterpret_cast<float *>(take((size_t)Bc * N * K * 4));
     w.xf = reinterpret_cast<int8_t *>(take(fix_plane_bytes(Bc, D)));
     w.xe = reinterpret_cast<int *>(take((size_t)fix_round_rows(Bc) * 4));
-    w.xfr = reinterpret_cast<int8_t *>(take(fix_plane_bytes(Bc, D)));
-    w.xer = reinterpret_cast<int *>(take((size_t)fix_round_rows(Bc) * 4));
     const int nlev = tf_levels(N);
     w.tf.ent = nullptr;
     w.tf.out_i64 = nullptr;
@@ -210,16 +208,15 @@ thread_local int g_last_launches = 0;
 // rows -> limb planes + exponents (+ |row|^2): the operands of every product of the path
 FixRowsArgs fix_rows_args(const float *src, int xh, long R, int D, long ld, int8_t *planes, int *exps, float *xx,
                           const float *bias_src = nullptr, float *bias_dst = nullptr, const float *sub = nullptr,
-                          long sub_per = 0, long sub_ld = 0, int8_t *planes_raw = nullptr, int *exps_raw = nullptr) {
+                          long sub_per = 0, long sub_ld = 0, const float *dot_vec = nullptr, float *dot_out = nullptr) {
     return FixRowsArgs{src, xh, R, fix_round_rows(R), D, ld, fix_round_cols(D), planes, exps, xx, bias_src, bias_dst,
-                       sub, sub_per, sub_ld, planes_raw, exps_raw};
+                       sub, sub_per, sub_ld, dot_vec, dot_out};
 }
 
-// sub != nullptr: the rows are centered by sub[0 .. D) (the frames of the search: x - mean); planes_raw / exps_raw then
-// receive the limbs of the rows as they are
+// sub != nullptr: the rows are centered by sub[0 .. D) (the frames of the search and of the logits: x - mean)
 int launch_fix_rows(const float *src, int xh, long R, int D, long ld, int8_t *planes, int *exps, float *xx, hipStream_t st,
-                    const float *sub = nullptr, int8_t *planes_raw = nullptr, int *exps_raw = nullptr) {
-    const FixRowsArgs a = fix_rows_args(src, xh, R, D, ld, planes, exps, xx, nullptr, nullptr, sub, 0, 0, planes_raw, exps_raw);
+                    const float *sub = nullptr) {
+    const FixRowsArgs a = fix_rows_args(src, xh, R, D, ld, planes, exps, xx, nullptr, nullptr, sub, 0, 0);
     // four rows per workgroup, one per wave (16 rows per workgroup and 256-byte runs into the planes measured slower:
     // 0.086 vs 0.071 ms at 65,536 x 512)
     hipLaunchKernelGGL(k_fix_rows<4>, dim3((unsigned)(a.Rp / 4)), dim3(256), 0, st, a);
@@ -280,7 +277,7 @@ int launch_logits(const int8_t *xf, const int *xe, long B, const Prepared &P, in
     g.B = xf; g.eb = xe; g.RB = fix_round_rows(B); g.N = B;
     g.Dq = fix_round_cols(D);
     g.walk_rows = 1;
-    g.bias = P.bias; g.lscale = lscale; g.lscale_ptr = lscale_ptr;
+    g.bias = P.bias; g.wmu = P.wmu; g.lscale = lscale; g.lscale_ptr = lscale_ptr;
     g.logits = logits; g.ldo = nk; g.idx = idx; g.K = K; g.ncb = N;
     return launch_fgemm<FG_LOGITS>(g, st);
 }
@@ -501,12 +498,10 @@ int run_encode(const float *x, long B, const void *prepared, float lscale, int N
         const float *xc = xh ? reinterpret_cast<const float *>(reinterpret_cast<const uint16_t *>(x) + lo * D) : x + lo * D;
         int rc;
         // the frames as limb planes (and |x|^2), once per call: both products of the call read them
-        // (the logits product reads the frames as they are, the x.C product the centered ones, x - mean; |x - mean|^2 rides along)
-        const bool need_raw = (init_idx == nullptr), need_cen = (iters > 0);
-        if (need_raw || need_cen) {
+        // the frames as limb planes, centered (x - mean: both products of the call read them; |x - mean|^2 rides along)
+        if (init_idx == nullptr || iters > 0) {
             if (prof) prof->begin(CAT_XX);
-            if (need_cen) rc = launch_fix_rows(xc, xh, Bc, D, D, w.xf, w.xe, w.xx, st, P.mean, need_raw ? w.xfr : nullptr, need_raw ? w.xer : nullptr);
-            else rc = launch_fix_rows(xc, xh, Bc, D, D, w.xfr, w.xer, nullptr, st);
+            rc = launch_fix_rows(xc, xh, Bc, D, D, w.xf, w.xe, w.xx, st, P.mean);
             if (rc) return rc;
             if (prof) prof->end(CAT_XX);
         }
@@ -516,7 +511,7 @@ int run_encode(const float *x, long B, const void *prepared, float lscale, int N
             MCQ_LAUNCH_CHECK();
         } else {
             if (prof) prof->begin(CAT_LOGITS);
-            rc = launch_logits(w.xfr, w.xer, Bc, P, N, K, D, lscale,
+            rc = launch_logits(w.xf, w.xe, Bc, P, N, K, D, lscale,
                                (flags & MCQ_ENCODE_LSCALE_FROM_PREPARED) ? P.scales + 1 : nullptr,
                                logits_out ? logits_out + lo * N * K : nullptr, w.idx, st);
             if (rc) return rc;
@@ -675,7 +670,8 @@ static int prepare_impl(const float *centers, float cscale_exp, const float *sca
     int rc = launch_fix_rows2(fix_rows_args(C, 0, rows, Dp, Dp, reinterpret_cast<int8_t *>(b + l.offCf), reinterpret_cast<int *>(b + l.offCe),
                                             reinterpret_cast<float *>(b + l.offQ), nullptr, nullptr, cmean, K, Dp),
                               fix_rows_args(weight, 0, rows, D, D, reinterpret_cast<int8_t *>(b + l.offWf), reinterpret_cast<int *>(b + l.offWe),
-                                            nullptr, bias, reinterpret_cast<float *>(b + l.offBias)), st);
+                                            nullptr, bias, reinterpret_cast<float *>(b + l.offBias), nullptr, 0, 0,
+                                            reinterpret_cast<const float *>(b + l.offMean), reinterpret_cast<float *>(b + l.offWmu)), st);
     if (rc) return rc;
     {
         // Gram matrix of the scaled centers: the x.C product with the centers themselves as the frames
@@ -952,7 +948,7 @@ int mcq_logits(const float *x, long B, const void *prepared, float lscale_exp, i
     hipStream_t st = static_cast<hipStream_t>(stream);
     const Prepared P = prepared_view(prepared, N, K, D);
     const LogitsWs w = logits_ws(workspace, B, N, D);
-    int rc = launch_fix_rows(x, 0, B, D, D, w.xf, w.xe, nullptr, st);
+    int rc = launch_fix_rows(x, 0, B, D, D, w.xf, w.xe, nullptr, st, P.mean);      // (the logits product reads centered frames: FixGemm::wmu)
     if (rc) return rc;
     return launch_logits(w.xf, w.xe, B, P, N, K, D, lscale_exp, nullptr, out, nullptr, st);
 }
@@ -969,7 +965,7 @@ int mcq_logits_argmax(const float *x, long B, const void *prepared, float lscale
     hipStream_t st = static_cast<hipStream_t>(stream);
     const Prepared P = prepared_view(prepared, N, K, D);
     const LogitsWs w = logits_ws(workspace, B, N, D);
-    int rc = launch_fix_rows(x, (flags & MCQ_ENCODE_X_FP16) ? 1 : 0, B, D, D, w.xf, w.xe, nullptr, st);
+    int rc = launch_fix_rows(x, (flags & MCQ_ENCODE_X_FP16) ? 1 : 0, B, D, D, w.xf, w.xe, nullptr, st, P.mean);
     if (rc) return rc;
     rc = launch_logits(w.xf, w.xe, B, P, N, K, D, lscale_exp,
                        (flags & MCQ_ENCODE_LSCALE_FROM_PREPARED) ? P.scales + 1 : nullptr, logits_out, w.idx8, st);

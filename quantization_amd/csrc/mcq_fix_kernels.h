@@ -60,14 +60,15 @@ struct FixRowsArgs {
     float *xx;
     const float *bias_src;
     float *bias_dst;
-    // centering (oracle "TABLE FORM": every table of the search is formed from rows / frames with the codebook means taken
+    // centering (oracle "CENTERING": every table of the search is formed from rows / frames with the codebook means taken
     // out): row r is written as src[r] - sub[(r / sub_per) * sub_ld] (one fp32 subtraction per element; sub_per == 0: every
-    // row takes sub[0 .. D)); planes / exps / xx receive the CENTERED row.  planes_raw / exps_raw (optional) receive the
-    // limbs of the row as it is: the logits product reads the frame itself (:277-279).
+    // row takes sub[0 .. D)); planes / exps / xx receive the CENTERED row.
     const float *sub;
     long sub_per, sub_ld;
-    int8_t *planes_raw;
-    int *exps_raw;
+    // optional: dot_out[r] = fixdot(row r, dot_vec[0 .. D)) -- the exact fixed-point product of the path, formed from the limbs this
+    // kernel has in its registers anyway (the classifier rows against the data mean: what centering the frame takes out of a logit)
+    const float *dot_vec;
+    float *dot_out;
 };
 
 template <int RW>
@@ -79,10 +80,10 @@ __device__ __forceinline__ void fix_rows_body(const FixRowsArgs &a, unsigned bid
     const float *__restrict__ bias_src = a.bias_src;
     float *__restrict__ bias_dst = a.bias_dst;
     const float *__restrict__ sub = a.sub;
-    const bool two = (sub != nullptr) && (a.planes_raw != nullptr);      // both the centered and the raw limbs
+    int8_t *__restrict__ planes = a.planes;
     constexpr int RPW = RW / 4;
     __shared__ __attribute__((aligned(16))) unsigned tile[128 * RW * 4];      // [plane of the block][row][4 words]
-    __shared__ int es[2][RW];
+    __shared__ int es[RW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long row0 = (long)bid * RW;
     if (bias_src && tid < RW && row0 + tid < R) bias_dst[row0 + tid] = bias_src[row0 + tid];
@@ -97,38 +98,53 @@ __device__ __forceinline__ void fix_rows_body(const FixRowsArgs &a, unsigned bid
             if (4 * q + c < D) v[c] = xh ? (float)srch[row * ld + 4 * q + c] : src[row * ld + 4 * q + c];
         return v;
     };
-    // what is taken out of group q of a row (zeros past D and for the padding rows, which stay zero rows)
-    const bool sub_vec = sub && ((a.sub_ld & 3) == 0) && ((D & 3) == 0) && ((reinterpret_cast<uintptr_t>(sub) & 15) == 0);
-    auto sub4 = [&](long row, int q) -> f32x4 {
+    // group q of a D-vector (zeros past D): what is taken out of a row (`sub`; nothing for the padding rows, which stay zero rows)
+    // or what the rows are multiplied with (`dot_vec`)
+    auto vec4 = [&](const float *p, int q) -> f32x4 {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (!sub || row >= R || 4 * q >= D) return v;
-        const float *sp = sub + (a.sub_per ? (row / a.sub_per) * a.sub_ld : 0);
-        if (sub_vec) return *reinterpret_cast<const f32x4 *>(sp + 4 * q);
+        if (4 * q >= D) return v;
+        if (((D & 3) == 0) && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) return *reinterpret_cast<const f32x4 *>(p + 4 * q);
 #pragma unroll
         for (int c = 0; c < 4; ++c)
-            if (4 * q + c < D) v[c] = sp[4 * q + c];
+            if (4 * q + c < D) v[c] = p[4 * q + c];
         return v;
     };
+    auto sub4 = [&](long row, int q) -> f32x4 {
+        if (!sub || row >= R) return f32x4{0.f, 0.f, 0.f, 0.f};
+        return vec4(sub + (a.sub_per ? (row / a.sub_per) * a.sub_ld : 0), q);
+    };
+    // the exponent of dot_vec (every wave forms it: max |.| over the vector)
+    int ev = 0;
+    if (a.dot_vec) {
+        float mv = 0.f;
+        for (int q = lane; q < (D + 3) / 4; q += 64) {
+            const f32x4 v = vec4(a.dot_vec, q);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) mv = fmaxf(mv, fabsf(v[c]));
+        }
+        for (int s = 32; s >= 1; s >>= 1) mv = fmaxf(mv, __shfl_xor(mv, s, 64));
+        const int be = (int)((__float_as_uint(mv) >> 23) & 0xff);
+        ev = (be < 1 ? 1 : be) - 126;
+    }
     const bool cached = (RW == 4) && D <= 1024;      // (16-row workgroups measured slower with the rows held, 0.126 vs 0.083 ms, and slower than 4-row ones either way)
     f32x4 cache[RW == 4 ? RPW : 1][4];
 #pragma unroll
     for (int rr = 0; rr < RPW; ++rr) {
         const long row = row0 + RPW * wave + rr;
-        float m = 0.f, pe = 0.f, mr = 0.f;
+        float m = 0.f, pe = 0.f;
         if (cached) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) cache[RW == 4 ? rr : 0][j] = load4(row, lane + 64 * j);      // (the row as it is; the mean comes off where it is used)
-#pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const f32x4 raw = cache[RW == 4 ? rr : 0][j];
-                const f32x4 v = sub ? raw - sub4(row, lane + 64 * j) : raw;
+                const f32x4 raw = load4(row, lane + 64 * j);
+                cache[RW == 4 ? rr : 0][j] = sub ? raw - sub4(row, lane + 64 * j) : raw;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    m = fmaxf(m, fabsf(v[c]));
-                    pe = fmaf(v[c], v[c], pe);      // (groups past D are zeros: fmaf(0, 0, pe) == pe)
-                    mr = fmaxf(mr, fabsf(raw[c]));
+                    m = fmaxf(m, fabsf(cache[RW == 4 ? rr : 0][j][c]));
+                    pe = fmaf(cache[RW == 4 ? rr : 0][j][c], cache[RW == 4 ? rr : 0][j][c], pe);      // (groups past D are zeros: fmaf(0, 0, pe) == pe)
                 }
-            }
         } else {
             for (int q = lane; q < (D + 3) / 4; q += 64) {
                 const f32x4 raw = load4(row, q);
@@ -137,71 +153,97 @@ __device__ __forceinline__ void fix_rows_body(const FixRowsArgs &a, unsigned bid
                 for (int c = 0; c < 4; ++c) {
                     m = fmaxf(m, fabsf(v[c]));
                     pe = fmaf(v[c], v[c], pe);
-                    mr = fmaxf(mr, fabsf(raw[c]));
                 }
             }
         }
         for (int s = 32; s >= 1; s >>= 1) m = fmaxf(m, __shfl_xor(m, s, 64));
-        if (two)
-            for (int s = 32; s >= 1; s >>= 1) mr = fmaxf(mr, __shfl_xor(mr, s, 64));
         if (xx) pe = wave_sum_butterfly(pe);
         if (lane == 0) {
             const int be = (int)((__float_as_uint(m) >> 23) & 0xff);
             const int e = (be < 1 ? 1 : be) - 126;
-            es[0][RPW * wave + rr] = e;
+            es[RPW * wave + rr] = e;
             if (row < Rp) a.exps[row] = e;
             if (xx && row < R) xx[row] = pe;
-            if (two) {
-                const int ber = (int)((__float_as_uint(mr) >> 23) & 0xff);
-                const int er = (ber < 1 ? 1 : ber) - 126;
-                es[1][RPW * wave + rr] = er;
-                if (row < Rp) a.exps_raw[row] = er;
-            }
         }
     }
     __syncthreads();
-    for (int set = 0; set < (two ? 2 : 1); ++set) {      // 0: the (centered) row, 1: the row as it is
-        int8_t *__restrict__ planes = set ? a.planes_raw : a.planes;
-        for (int c0 = 0; c0 < Dq; c0 += 512) {
-            const int ncol = (Dq - c0 < 512) ? Dq - c0 : 512;          // columns of this block (a multiple of 128)
+    int T[RPW][4];      // limb-product sums of the rows against dot_vec (oracle: fixdot), this lane's columns
 #pragma unroll
-            for (int rr = 0; rr < RPW; ++rr) {
-                const int rl = RPW * wave + rr;
-                const int e = es[set][rl];
+    for (int rr = 0; rr < RPW; ++rr)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int q = lane + 64 * j;
-                    if (q >= ncol / 4) continue;
-                    f32x4 v;
-                    v = cached ? cache[RW == 4 ? rr : 0][((c0 >> 9) * 2 + j) & 3] : load4(row0 + rl, c0 / 4 + q);
-                    if (sub && set == 0) v = v - sub4(row0 + rl, c0 / 4 + q);
-                    unsigned w[4] = {0u, 0u, 0u, 0u};
+        for (int i = 0; i < 4; ++i) T[rr][i] = 0;
+    auto limbs4 = [&](const f32x4 &v, int e, unsigned (&w)[4]) {      // four columns -> one word per limb (most significant first)
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        int r = fix_q(v[c], e);
+        for (int i = 0; i < 4; ++i) w[i] = 0u;
 #pragma unroll
-                        for (int i = 3; i >= 1; --i) {
-                            const int l = (int)(int8_t)(r & 0xff);
-                            w[i] |= (unsigned)(l & 0xff) << (8 * c);
-                            r = (r - l) >> 8;
-                        }
-                        w[0] |= (unsigned)(r & 0xff) << (8 * c);
-                    }
-                    const int chunk = q >> 2, word = q & 3;
+        for (int c = 0; c < 4; ++c) {
+            int r = fix_q(v[c], e);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) tile[((chunk * 4 + i) * RW + rl) * 4 + word] = w[i];
-                }
+            for (int i = 3; i >= 1; --i) {
+                const int l = (int)(int8_t)(r & 0xff);
+                w[i] |= (unsigned)(l & 0xff) << (8 * c);
+                r = (r - l) >> 8;
             }
-            __syncthreads();
-            const int nplanes = ncol / 16 * 4;
-            for (int p = tid / RW; p < nplanes; p += 256 / RW) {
-                const int rl = tid % RW;
-                if (row0 + rl < Rp) {
-                    const i32x4 v = *reinterpret_cast<const i32x4 *>(&tile[(p * RW + rl) * 4]);
-                    *reinterpret_cast<i32x4 *>(planes + (((long)(c0 / 16) * 4 + p) * Rp + row0 + rl) * 16) = v;
+            w[0] |= (unsigned)(r & 0xff) << (8 * c);
+        }
+    };
+    for (int c0 = 0; c0 < Dq; c0 += 512) {
+        const int ncol = (Dq - c0 < 512) ? Dq - c0 : 512;          // columns of this block (a multiple of 128)
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int rl = RPW * wave + rr;
+            const int e = es[rl];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int q = lane + 64 * j;
+                if (q >= ncol / 4) continue;
+                f32x4 v;
+                if (cached) v = cache[RW == 4 ? rr : 0][((c0 >> 9) * 2 + j) & 3];
+                else v = sub ? load4(row0 + rl, c0 / 4 + q) - sub4(row0 + rl, c0 / 4 + q) : load4(row0 + rl, c0 / 4 + q);
+                unsigned w[4];
+                limbs4(v, e, w);
+                if (a.dot_vec) {
+                    unsigned mw[4];
+                    limbs4(vec4(a.dot_vec, c0 / 4 + q), ev, mw);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int jj = 0; i + jj < 4; ++jj) T[rr][i + jj] = __builtin_amdgcn_sdot4((int)w[i], (int)mw[jj], T[rr][i + jj], false);
                 }
+                const int chunk = q >> 2, word = q & 3;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) tile[((chunk * 4 + i) * RW + rl) * 4 + word] = w[i];
             }
-            __syncthreads();
+        }
+        __syncthreads();
+        const int nplanes = ncol / 16 * 4;
+        for (int p = tid / RW; p < nplanes; p += 256 / RW) {
+            const int rl = tid % RW;
+            if (row0 + rl < Rp) {
+                const i32x4 v = *reinterpret_cast<const i32x4 *>(&tile[(p * RW + rl) * 4]);
+                *reinterpret_cast<i32x4 *>(planes + (((long)(c0 / 16) * 4 + p) * Rp + row0 + rl) * 16) = v;
+            }
+        }
+        __syncthreads();
+    }
+    if (a.dot_vec) {
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+            int t4[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int t = T[rr][i];
+                for (int s = 32; s >= 1; s >>= 1) t += __shfl_xor(t, s, 64);      // exact integers: no order to speak of
+                t4[i] = t;
+            }
+            const long row = row0 + RPW * wave + rr;
+            if (lane == 0 && row < R) {
+                float tt = (float)t4[3];
+                tt = __builtin_fmaf((float)t4[2], 256.0f, tt);
+                tt = __builtin_fmaf((float)t4[1], 65536.0f, tt);
+                tt = __builtin_fmaf((float)t4[0], 16777216.0f, tt);
+                a.dot_out[row] = ldexpf(tt, es[RPW * wave + rr] + ev - 36);
+            }
         }
     }
 }
@@ -232,8 +274,10 @@ struct FixGemm {
     float *out;
     long ldo;
     // FG_LOGITS: rows are (codebook, entry) pairs, columns are frames; value = fixdot * lscale + bias[row];
+    //            (value = (fixdot + wmu[row]) * lscale + bias[row]: see wmu)
     //            logits[col * ldo + row] = value when logits != nullptr; idx[col * ncb + codebook] = first arg max
     const float *bias;
+    const float *wmu;              // fixdot(data mean, W[row]): the frames of this product are centered (x - mean), the logit is (t + wmu) * lscale + bias
     const float *lscale_ptr;       // device scalar, or nullptr: lscale
     float lscale;
     float *logits;
@@ -298,15 +342,17 @@ k_fgemm(const FixGemm g) {
             : [vo] "v"(voff), [p] "s"(pg), [d] "s"(d)
             : "memory");
     };
-    // the tile's row exponents ea (waves 0, 1), column exponents eb (2, 3) and, for the logits, row biases (4, 5) -> info:
-    // 64 words per piece; [0..127] ea, [128..255] eb, [256..383] bias, [384..] arg-max exchange.  (Rows past M read whatever
-    // follows the bias inside `prepared`: they never reach an output.)
+    // the tile's row exponents ea (waves 0, 1), column exponents eb (2, 3) and, for the logits, row biases (4, 5) and the rows'
+    // products with the data mean (6, 7) -> info: 64 words per piece; [0..127] ea, [128..255] eb, [256..383] bias, [384..639]
+    // arg-max exchange, [640..767] wmu.  (Rows past M read whatever follows the bias / wmu inside `prepared`: they never reach an
+    // output.)
     auto issue_info = [&](long m0, long n0) {
-        if (wu < (MODE == FG_LOGITS ? 6 : 4)) {
+        if (wu < (MODE == FG_LOGITS ? 8 : 4)) {
             const void *src = wu < 2 ? static_cast<const void *>(g.ea + m0 + 64 * wu)
                                      : (wu < 4 ? static_cast<const void *>(g.eb + n0 + 64 * (wu - 2))
-                                               : static_cast<const void *>(g.bias + m0 + 64 * (wu - 4)));
-            const unsigned d = (unsigned)(size_t)smem + kFixInfo + 256 * wu;
+                                               : (wu < 6 ? static_cast<const void *>(g.bias + m0 + 64 * (wu - 4))
+                                                         : static_cast<const void *>(g.wmu + m0 + 64 * (wu - 6))));
+            const unsigned d = (unsigned)(size_t)smem + kFixInfo + 256 * (wu < 6 ? wu : wu + 4);
             asm volatile(
                 "s_mov_b32 m0, %[d]\n\ts_nop 0\n\t"
                 "global_load_lds_dword %[vo], %[p]\n\t"
@@ -428,36 +474,31 @@ k_fgemm(const FixGemm g) {
             // per lane: one column (frame), rows 64 wm + 32 ta + 8 (v >> 2) + 4 kh + (v & 3), ascending in (ta, v)
             float bv[4];          // best of the 16-row group (ta, v >> 3), this lane's 8 rows of it
             int bk[4];
-            f32x4 br[2][4];
-#pragma unroll
-            for (int ta = 0; ta < 2; ++ta)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) br[ta][q] = *reinterpret_cast<const f32x4 *>(&infof[256 + rbase + 32 * ta + 8 * q]);
             const long col = n0 + cbase;
-            f32x4 q4[2][4];
+            float *lrow = g.logits ? g.logits + col * g.ldo + m0 + rbase : nullptr;
+            // the two 32-row halves one after the other, each with its own biases / mean products read where they are used: with
+            // all 32 rows' worth held from the top of the epilogue (32 + 32 registers beside the 128 accumulators, the next
+            // tile's first fragments and the exponents) the kernel ran out of its 256 registers (24 spilled, 0.56 -> 0.74 ms)
 #pragma unroll
-            for (int ta = 0; ta < 2; ++ta)
+            for (int ta = 0; ta < 2; ++ta) {
 #pragma unroll
                 for (int v4 = 0; v4 < 4; ++v4) {
+                    const f32x4 br4 = *reinterpret_cast<const f32x4 *>(&infof[256 + rbase + 32 * ta + 8 * v4]);
+                    const f32x4 wm4 = *reinterpret_cast<const f32x4 *>(&infof[640 + rbase + 32 * ta + 8 * v4]);
+                    f32x4 q4;
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         const int v = 4 * v4 + c;
                         const int rl = rbase + 32 * ta + 8 * v4 + c;
-                        const float val = __fadd_rn(__fmul_rn(value(ta, v, er[ta][v4][c] + ecol), ls), br[ta][v4][c]);
-                        q4[ta][v4][c] = val;
+                        const float val = __fadd_rn(__fmul_rn(__fadd_rn(value(ta, v, er[ta][v4][c] + ecol), wm4[c]), ls), br4[c]);
+                        q4[c] = val;
                         const int gi = 2 * ta + (v4 >> 1);
                         if ((v4 & 1) == 0 && c == 0) { bv[gi] = val; bk[gi] = rl; }
                         else if (val > bv[gi]) { bv[gi] = val; bk[gi] = rl; }
                     }
+                    if (lrow && (full || (col < g.N && 32 * ta + 8 * v4 < rows_left)))
+                        *reinterpret_cast<f32x4 *>(lrow + 32 * ta + 8 * v4) = q4;
                 }
-            if (g.logits) {
-                float *lrow = g.logits + col * g.ldo + m0 + rbase;
-#pragma unroll
-                for (int ta = 0; ta < 2; ++ta)
-#pragma unroll
-                    for (int v4 = 0; v4 < 4; ++v4)
-                        if (full || (col < g.N && 32 * ta + 8 * v4 < rows_left))
-                            *reinterpret_cast<f32x4 *>(lrow + 32 * ta + 8 * v4) = q4[ta][v4];
             }
             if (g.idx) {
                 // a value beats another when it is larger, or equal with the lower row

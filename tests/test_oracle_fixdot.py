@@ -51,7 +51,9 @@ def _fixdot(a, b):
 def test_fixdot_error_bound(D, K, N, wide):
     rs = np.random.RandomState(D + K)
     centers, W, bias = _state(rs, N, K, D, wide)
-    o = OracleQuantizer(centers, 0.0, W, np.zeros_like(bias), 0.0)       # scale factors exp(0) = 1, no bias: raw products
+    # scale factors exp(0) = 1, no bias, all-zero centers (the data mean the logits' frames are centered by is then 0 and what the
+    # centering takes out, fixdot(mean, W[r]), is 0 as well): the logits are the raw products
+    o = OracleQuantizer(np.zeros_like(centers), 0.0, W, np.zeros_like(bias), 0.0)
     x = rs.standard_normal((24, D)).astype(np.float32)
     if wide:
         x *= np.exp(rs.uniform(-6, 6, size=x.shape)).astype(np.float32)
@@ -73,7 +75,7 @@ def test_fixdot_matches_the_written_definition():
     D, K, N = 45, 16, 2
     centers, W, bias = _state(rs, N, K, D, wide=True)
     W[3] = 0.0                                   # an all-zero row: exponent -125, product 0
-    o = OracleQuantizer(centers, 0.0, W, np.zeros_like(bias), 0.0)
+    o = OracleQuantizer(np.zeros_like(centers), 0.0, W, np.zeros_like(bias), 0.0)      # (zero mean: logits = raw products)
     x = rs.standard_normal((5, D)).astype(np.float32)
     x[1] *= 1e-30                                # tiny rows scale exactly
     x[2] *= 1e+20
