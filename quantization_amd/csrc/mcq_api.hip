@@ -360,8 +360,13 @@ int launch_tf_up(int kh, int kc, const TfLists &L, long B, int N, int u, int nta
 int launch_tf_comb(int kh, int kc, const float *E, const TfLists &L, long B, int N, int v, int keep, const float *tabs,
                    uint8_t *fin, const int *nact, hipStream_t st) {
     const dim3 grid((unsigned)(B * (N >> (v + 1)))), block(64);
-#define MCQ_COMB_CASE(A, C) \
-    if (kh == A && kc == C) { hipLaunchKernelGGL((k_tf_comb<A, C>), grid, block, 0, st, E, L, B, N, v, keep, tabs, fin, nact); MCQ_LAUNCH_CHECK(); return 0; }
+#define MCQ_COMB_CASE(A, C)                                                                                                        \
+    if (kh == A && kc == C) {                                                                                                     \
+        if (fin) hipLaunchKernelGGL((k_tf_comb<A, C, true>), grid, block, 0, st, E, L, B, N, v, keep, tabs, fin, nact);           \
+        else hipLaunchKernelGGL((k_tf_comb<A, C, false>), grid, block, 0, st, E, L, B, N, v, keep, tabs, fin, nact);              \
+        MCQ_LAUNCH_CHECK();                                                                                                       \
+        return 0;                                                                                                                 \
+    }
     MCQ_COMB_CASE(16, 32) MCQ_COMB_CASE(32, 32) MCQ_COMB_CASE(32, 64) MCQ_COMB_CASE(64, 64) MCQ_COMB_CASE(8, 16) MCQ_COMB_CASE(16, 16)
 #undef MCQ_COMB_CASE
     return MCQ_EUNSUPPORTED;

@@ -473,9 +473,9 @@ __device__ __forceinline__ void tf_table1(const float *__restrict__ G, const uin
         // columns -- spread over all 32 banks; with rows of 16 they met in 2 x 16, SQ_LDS_BANK_CONFLICT 26 M cycles per launch)
         // + 33 border values
         constexpr int RS = KCH + 1, BO = KCH * RS;
-        constexpr int LS = BO + 64;
-        int *cent = reinterpret_cast<int *>(leaf + 4 * LS);   // [4][16] compact list -> codebook entry
-        int *crank = cent + 64;                               // [4][16] candidate -> compact rank of its leaf
+        constexpr int LS = BO + 36;                           // (33 border values; 5,056 bytes per wave in all: 32 waves per CU)
+        uint8_t *cent = reinterpret_cast<uint8_t *>(leaf + 4 * LS);   // [4][16] compact list -> codebook entry
+        uint8_t *crank = cent + 64;                                   // [4][16] candidate -> compact rank of its leaf
         const int NK = N * K;
         const int nksh = __builtin_ctz((unsigned)NK);
         // quarter w of the wave = one of the four halves' lists: 0, 1 = the halves of X, 2, 3 = those of Y
@@ -496,8 +496,8 @@ __device__ __forceinline__ void tf_table1(const float *__restrict__ G, const uin
         m |= (uint32_t)dpp_i<0x122>((int)m);
         m |= (uint32_t)dpp_i<0x124>((int)m);
         m |= (uint32_t)dpp_i<0x128>((int)m);
-        crank[lane] = __popc(m & ((1u << mypos) - 1u));
-        if ((m >> c) & 1u) cent[w * 16 + __popc(m & ((1u << c) - 1u))] = myent;
+        crank[lane] = (uint8_t)__popc(m & ((1u << mypos) - 1u));
+        if ((m >> c) & 1u) cent[w * 16 + __popc(m & ((1u << c) - 1u))] = (uint8_t)myent;
         uint32_t mq[4];
         mq[0] = (uint32_t)__builtin_amdgcn_readlane((int)m, 0);
         mq[1] = (uint32_t)__builtin_amdgcn_readlane((int)m, 16);
@@ -644,7 +644,7 @@ __device__ __forceinline__ void tf_table1(const float *__restrict__ G, const uin
     }
 }
 
-constexpr int tf_leaf_lds_floats(int KCH) { return 4 * (KCH * (KCH + 1) + 64) + 128; }
+constexpr int tf_leaf_lds_floats(int KCH) { return 4 * (KCH * (KCH + 1) + 36) + 32; }
 
 // combine of level 1: siblings X = 2g, Y = 2g + 1 (pairs of codebooks).  One wave per (b, g).
 template <int KCH, int KC>
@@ -836,7 +836,10 @@ k_tf_up(TfLists L, long B, int N, int u, int ntab, int per, const float *__restr
 // Siblings P = 2h, Q = 2h + 1 of level v (lists of KC): the four level-(v-1) tables of their halves come from tabs
 // ([b][h][2][2][KH*KH]).  One wave per (b, h).  KC == 64 (4,096 pairs: only ever the last combine) streams the scores
 // through a running arg-min instead of holding them.
-template <int KH, int KC>
+// LAST: the combine that leaves one group (idx_final != nullptr, keep == 1) as an instantiation of its own -- the winner is a
+// running arg-min over the scores, no score array and no selection: 86 registers -> the 8 waves per SIMD of the other pass kernels
+// (k_tf_comb<16,32> is the last launch of every pass of 8 codebooks).
+template <int KH, int KC, bool LAST>
 __global__ void __launch_bounds__(64)
 k_tf_comb(const float *__restrict__ E, TfLists L, long B, int N, int v, int keep, const float *__restrict__ tabs,
           uint8_t *__restrict__ idx_final, const int *__restrict__ nact) {
@@ -862,7 +865,7 @@ k_tf_comb(const float *__restrict__ E, TfLists L, long B, int N, int v, int keep
     const uint8_t *px = L.pos[v] + ((b * Gv + P) * KC) * 2, *py = L.pos[v] + ((b * Gv + Q) * KC) * 2;
     const float *Sx = L.S[v] + (b * Gv + P) * KC, *Sy = L.S[v] + (b * Gv + Q) * KC;
     wave_lds_fence();
-    if constexpr (CHUNKS == 1) {
+    if constexpr (CHUNKS == 1 && !LAST) {
         const int i = (VPL * lane) / KC, j0 = (VPL * lane) % KC;
         const float se = Sx[i];
         float t[VPL];
@@ -876,7 +879,7 @@ k_tf_comb(const float *__restrict__ E, TfLists L, long B, int N, int v, int keep
         }
         wave_lds_fence();
         tf_finish<VPL>(sv, sp, keep, KC, scratch, L, v + 1, b, N, h, idx_final);
-    } else if (idx_final == nullptr) {
+    } else if (!LAST) {
         // 4,096 pairs that are NOT the last combine (64 codebooks of more than 16 entries: 64 of them go on): the 64 smallest
         // of every chunk of 1,024, then the 64 smallest of those 4 x 64 -- the same set and order as one selection over
         // all of them (keys are unique)
