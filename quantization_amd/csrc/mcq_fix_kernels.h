@@ -71,7 +71,7 @@ struct FixRowsArgs {
     float *dot_out;
 };
 
-template <int RW>
+template <int RW, bool DOT>      // DOT: also the rows' fixed-point products with a.dot_vec (the classifier rows of mcq_prepare)
 __device__ __forceinline__ void fix_rows_body(const FixRowsArgs &a, unsigned bid) {
     const float *__restrict__ src = a.src;
     const int xh = a.xh, D = a.D, Dq = a.Dq;
@@ -115,7 +115,7 @@ __device__ __forceinline__ void fix_rows_body(const FixRowsArgs &a, unsigned bid
     };
     // the exponent of dot_vec (every wave forms it: max |.| over the vector)
     int ev = 0;
-    if (a.dot_vec) {
+    if (DOT && a.dot_vec) {
         float mv = 0.f;
         for (int q = lane; q < (D + 3) / 4; q += 64) {
             const f32x4 v = vec4(a.dot_vec, q);
@@ -133,11 +133,15 @@ __device__ __forceinline__ void fix_rows_body(const FixRowsArgs &a, unsigned bid
         const long row = row0 + RPW * wave + rr;
         float m = 0.f, pe = 0.f;
         if (cached) {
+            // (the row and what is taken out of it are requested together, then subtracted: written as load - load per group the
+            // compiler waited for each pair in turn, 61 -> 71 us per 65,536 frames)
+            f32x4 raw[4], sv4[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const f32x4 raw = load4(row, lane + 64 * j);
-                cache[RW == 4 ? rr : 0][j] = sub ? raw - sub4(row, lane + 64 * j) : raw;
-            }
+            for (int j = 0; j < 4; ++j) raw[j] = load4(row, lane + 64 * j);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sv4[j] = sub4(row, lane + 64 * j);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cache[RW == 4 ? rr : 0][j] = sub ? raw[j] - sv4[j] : raw[j];
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -202,7 +206,7 @@ __device__ __forceinline__ void fix_rows_body(const FixRowsArgs &a, unsigned bid
                 else v = sub ? load4(row0 + rl, c0 / 4 + q) - sub4(row0 + rl, c0 / 4 + q) : load4(row0 + rl, c0 / 4 + q);
                 unsigned w[4];
                 limbs4(v, e, w);
-                if (a.dot_vec) {
+                if (DOT && a.dot_vec) {
                     unsigned mw[4];
                     limbs4(vec4(a.dot_vec, c0 / 4 + q), ev, mw);
 #pragma unroll
@@ -226,7 +230,7 @@ __device__ __forceinline__ void fix_rows_body(const FixRowsArgs &a, unsigned bid
         }
         __syncthreads();
     }
-    if (a.dot_vec) {
+    if (DOT && a.dot_vec) {
 #pragma unroll
         for (int rr = 0; rr < RPW; ++rr) {
             int t4[4];
@@ -249,13 +253,13 @@ __device__ __forceinline__ void fix_rows_body(const FixRowsArgs &a, unsigned bid
 }
 
 template <int RW>
-__global__ void __launch_bounds__(256) k_fix_rows(const FixRowsArgs a) { fix_rows_body<RW>(a, blockIdx.x); }
+__global__ void __launch_bounds__(256) k_fix_rows(const FixRowsArgs a) { fix_rows_body<RW, false>(a, blockIdx.x); }
 
 // two matrices in one launch (the centers and the classifier rows of mcq_prepare: one launch boundary less per trainer step)
 template <int RW>
 __global__ void __launch_bounds__(256) k_fix_rows2(const FixRowsArgs a, const FixRowsArgs b, unsigned blocks_a) {
-    if (blockIdx.x < blocks_a) fix_rows_body<RW>(a, blockIdx.x);
-    else fix_rows_body<RW>(b, blockIdx.x - blocks_a);
+    if (blockIdx.x < blocks_a) fix_rows_body<RW, false>(a, blockIdx.x);
+    else fix_rows_body<RW, true>(b, blockIdx.x - blocks_a);
 }
 
 // ------------------------------------------------------------------ the GEMM

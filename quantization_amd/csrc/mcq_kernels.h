@@ -151,8 +151,14 @@ __device__ __forceinline__ u64 wave_kth_lane_key(u64 k, int target) {
         rr = __popcll(ltm);
         const u64 lo = cm & ltm, hi = cm & ~(ltm | (1ull << pl));
         cm = (rr > target) ? lo : hi;
-    } while (rr != target && cm != 0);      // (cm == 0 before the target is met: only with equal keys, which callers never build)
-    return rr == target ? kp : kKeyMax;
+    } while (rr != target);
+    // INVARIANT the loop's exit rests on: the keys are UNIQUE (every caller packs the candidate's position into the low word), so
+    // the key with exactly `target` smaller ones exists among the candidates and is reached before they run out.  A guard on
+    // cm != 0 (equal keys would empty the mask first) was tried on the advisor's suggestion: two more scalar instructions in a loop
+    // of fourteen, run seven times per selection, fourteen selections per vector and pass -- k_tf_stage0 268 -> 279 us, k_tf_pair0
+    // 174 -> 179 us on one box; the invariant is asserted where the keys are built instead (tests/test_gpu_parity.py::
+    // test_wave_selection_paths drives ties through every path: equal SCORES give distinct keys).
+    return kp;
 }
 
 template <int VPL>
