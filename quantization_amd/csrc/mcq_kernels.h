@@ -115,6 +115,9 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 load_h4(const void *p) {
     return __builtin_convertvector(*reinterpret_cast<const f16x4 *>(p), f32x4);
 }
+#ifndef MCQ_SEL_WIN
+#define MCQ_SEL_WIN 4      // window of the selection's bound (wave_kth_lane_key); 0 = the exact key
+#endif
 constexpr int kSelectLdsU64 = 208;  // per-wave LDS scratch of wave_select_fast, in u64 (136 survivors + 64 results)
 
 __device__ __forceinline__ uint32_t ord32(float v) {
@@ -139,19 +142,21 @@ __device__ __forceinline__ void wave_lds_fence() {
 // one ballot, one popcount; written as a do-while with both successor masks formed unconditionally (the while-with-break
 // form compiled to 22 instructions and four branches per round, this one to about 14 and one).  kKeyMax when there are
 // fewer than target + 1 keys.
-__device__ __forceinline__ u64 wave_kth_lane_key(u64 k, int target) {
+// `win` > 0: ANY key with target .. target + win smaller ones will do (the caller only needs an upper bound of the target-th
+// key that not many more keys lie below): the loop stops at the first pivot that lands in the window -- about two rounds of seven
+// earlier for win = 4.
+__device__ __forceinline__ u64 wave_kth_lane_key(u64 k, int target, int win = 0) {
     u64 cm = __ballot(k != kKeyMax);
     if (__popcll(cm) <= target) return kKeyMax;
     u64 kp;
     int rr;
     do {                          // every round removes at least the pivot's lane from the candidates: <= 64 rounds
-        const int pl = __ffsll((long long)cm) - 1;
+        const int pl = __builtin_ctzll(cm);      // (cm != 0 here; __ffsll's zero case cost two scalar instructions per round)
         kp = readlane_u64(k, pl);
-        const u64 ltm = __ballot(k < kp);
-        rr = __popcll(ltm);
-        const u64 lo = cm & ltm, hi = cm & ~(ltm | (1ull << pl));
-        cm = (rr > target) ? lo : hi;
-    } while (rr != target);
+        const u64 ltm = __ballot(k < kp), gtm = __ballot(k > kp);      // (keys are unique: the lanes above the pivot, from a second
+        rr = __popcll(ltm);                                            // vector compare instead of two more scalar mask operations)
+        cm &= (rr > target) ? ltm : gtm;
+    } while ((unsigned)(rr - target) > (unsigned)win);
     // INVARIANT the loop's exit rests on: the keys are UNIQUE (every caller packs the candidate's position into the low word), so
     // the key with exactly `target` smaller ones exists among the candidates and is reached before they run out.  A guard on
     // cm != 0 (equal keys would empty the mask first) was tried on the advisor's suggestion: two more scalar instructions in a loop
@@ -190,15 +195,23 @@ __device__ __forceinline__ void wave_select_fast(const float (&v)[VPL], const in
         // round the loop is materialised as 0/1 VGPRs with v_cndmask / v_cmp pairs and nops on every round: the
         // selection is bound by exactly that scalar/VALU ping-pong).  Keys are unique, so the lanes above the
         // pivot are the complement of those below it minus the pivot's lane.
-        const u64 T0 = wave_kth_lane_key(lmin, target);
-        int base = 0;
+        // (a bound is all T0 has to be: any lane minimum with cnt - 1 .. cnt + 3 smaller ones.  Up to cnt + 4 lanes then hold
+        // survivors -- more than 64 of them only if those lanes hold nearly all their keys below T0, in which case the exact
+        // cnt-th minimum is taken after all: at most cnt * VPL <= 64 survive that)
+        u64 T0 = wave_kth_lane_key(lmin, target, MCQ_SEL_WIN);
+        int base;
+        for (int attempt = 0;; ++attempt) {
+            base = 0;
 #pragma unroll
-        for (int i = 0; i < VPL; ++i) {
-            const bool sel = key[i] <= T0;
-            const u64 m = __ballot(sel);
-            const int dst = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-            if (sel && dst < 64) ldsA[dst] = key[i];
-            base += __popcll(m);
+            for (int i = 0; i < VPL; ++i) {
+                const bool sel = key[i] <= T0;
+                const u64 m = __ballot(sel);
+                const int dst = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+                if (sel && dst < 64) ldsA[dst] = key[i];
+                base += __popcll(m);
+            }
+            if (base <= 64 || attempt > 0) break;
+            T0 = wave_kth_lane_key(lmin, target);
         }
         const int c0 = base < 64 ? base : 64;
         // ranking walks the survivors eight at a time; the tail is padded with sentinels (never smaller than a key)
