@@ -5,7 +5,7 @@ import collections, csv, glob, json, os, re, sys
 root = sys.argv[1]
 KERNELS = {"logits_product_argmax": "k_fgemm<1>", "xc_product": "k_fgemm<0>", "frames_to_limbs": "k_fix_rows<4>",
            "residual_energies": "k_tf_er<8>", "stage0_tables": "k_tf_stage0<256, 8>", "combine_level0": "k_tf_pair0<16>",
-           "combine_level1": "k_tf_pair1<16, 16>", "tables_level1": "k_tf_table1<16, 16>", "combine_level2": "k_tf_comb<16, 32>",
+           "combine_level1": "k_tf_pair1<16, 16>", "tables_level1": "k_tf_table1<16, 16>", "combine_level2": "k_tf_comb<16, 32, true>",
            # (outside mcq_profile_encode the level-1 combines and the level-2 cousin tables share one launch)
            "level1_combines_and_tables": "k_tf_level1<16, 16>"}
 vals = collections.defaultdict(lambda: collections.defaultdict(list))
