@@ -641,3 +641,27 @@ def test_config_e_phase_one_state_bit_exact_vs_oracle():
         got = q.encode(xg, it, as_bytes=False).cpu().numpy()
         assert np.array_equal(got, want), (it, int((got != want).any(axis=1).sum()))
     assert np.array_equal(q.encode(xg, 2).cpu().numpy(), o.encode(x, 2))
+
+
+def test_full_size_config_b_with_a_reference_trained_state_and_shifted_frames():
+    """BASELINE config B's shape with the state the REFERENCE trained at dim 512 / 8 bytes (trained_d512_b8_p2) on 65,536 frames --
+    half of them the training distribution, half with a common offset of 10, where the centered tables matter:
+    sampled rows bit-exact against the oracle; the fixture's 2,048 rows, riding inside the batch across the middle, against the
+    reference's own codes; chunk independence."""
+    fx = fixtures.load("trained_d512_b8_p2")
+    D, K, N, B = 512, 256, 8, 65536
+    q = load_quantizer(fx["state"], D, K, N)
+    o = oracle_of(fx["state"])
+    x = np.concatenate([gen.make_kind("make_x", 777, B // 2, D), gen.make_kind("mean10", 778, B // 2, D)])
+    x[B // 2 - 1024:B // 2 - 1024 + fx["B"]] = fx["x"]
+    xd = torch.from_numpy(x).cuda()
+    codes = q.encode(xd, 5)
+    c = codes.cpu().numpy()
+    rows = np.random.RandomState(3).choice(B, 640, replace=False)
+    assert np.array_equal(c[rows], o.encode(x[rows], 5))
+    fixtures.check_codes(fx, 5, c[B // 2 - 1024:B // 2 - 1024 + fx["B"]], "trained d512 state inside a full batch (HIP vs reference fixture)")
+    part = torch.cat([q.encode(xd[B // 2 - 500:B // 2], 5), q.encode(xd[B // 2:B // 2 + 700], 5)])
+    assert torch.equal(part, codes[B // 2 - 500:B // 2 + 700])
+    # the shifted half is far from what the quantizer was trained on: refinement must still not lose against the initial guess
+    y5, y0 = q.decode(codes), q.decode(q.encode(xd, 0))
+    assert float(((y5 - xd) ** 2).sum()) < float(((y0 - xd) ** 2).sum())
