@@ -164,7 +164,7 @@ k_tf_stage0(const float *__restrict__ G, const float *__restrict__ XC, const uin
     const float *q = Q + n * K + k0;
     float xcv[VPL], qv[VPL];
     if constexpr (VPL == 4) {
-        const f32x4 x4 = *reinterpret_cast<const f32x4 *>(xc), q4 = *reinterpret_cast<const f32x4 *>(q);
+        const f32x4 x4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(xc)), q4 = *reinterpret_cast<const f32x4 *>(q);
 #pragma unroll
         for (int i = 0; i < 4; ++i) { xcv[i] = x4[i]; qv[i] = q4[i]; }
     } else {
@@ -710,7 +710,7 @@ __device__ __forceinline__ void tf_table1_body(unsigned bid, float *leaf, const 
     tf_table1<KCH, KC>(G, idx, L, b, N, K, X, Y, leaf, tv);
     float *dst = tabs + ((size_t)(b * ntab + t) * (KC * KC) + VPL * lane);
     if constexpr (VPL == 4) {
-        *reinterpret_cast<f32x4 *>(dst) = (f32x4){tv[0], tv[1], tv[2], tv[3]};
+        __builtin_nontemporal_store((f32x4){tv[0], tv[1], tv[2], tv[3]}, reinterpret_cast<f32x4 *>(dst));
     } else {
 #pragma unroll
         for (int v = 0; v < VPL; ++v) dst[v] = tv[v];
