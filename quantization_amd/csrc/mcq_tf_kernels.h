@@ -758,7 +758,7 @@ __device__ __forceinline__ void tf_load_tables(const float *__restrict__ src, fl
             f32x4 r[BATCH];
 #pragma unroll
             for (int i = 0; i < BATCH; ++i)
-                if (i0 + i < IT) r[i] = reinterpret_cast<const f32x4 *>(src)[lane + 64 * (i0 + i)];
+                if (i0 + i < IT) r[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(src) + lane + 64 * (i0 + i));      // (read once: past the L2's Gram blocks)
 #pragma unroll
             for (int i = 0; i < BATCH; ++i)
                 if (i0 + i < IT) {
