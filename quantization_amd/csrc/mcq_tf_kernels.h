@@ -829,7 +829,7 @@ k_tf_up(TfLists L, long B, int N, int u, int ntab, int per, const float *__restr
     tf_up<KH, KC>(th, th + TS, th + 2 * TS, th + 3 * TS, L.pos[u] + ((b * Gu + X) * KC) * 2, L.pos[u] + ((b * Gu + Y) * KC) * 2, tv);
     float *dst = tabs_out + ((size_t)(b * ntab + t) * (KC * KC) + VPL * lane);
 #pragma unroll
-    for (int v = 0; v < VPL; ++v) dst[v] = tv[v];
+    for (int v = 0; v < VPL; ++v) __builtin_nontemporal_store(tv[v], dst + v);      // (a stream: past the L2, like the level-1 tables)
 }
 
 // ------------------------------------------------ combine of a level >= 2
