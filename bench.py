@@ -392,6 +392,17 @@ def main():
         else ("stage0_tables", "combine_level0", "combine_level1")
     executed_floor_ms = round((LIMB_PRODUCTS * exec_fpv * B / (PEAK_I8_MFMA_TOPS * 1e12) +
                                iters * sum(_w[n_][2] + (_w[n_][1] if n_ == "stage0_tables" else 0.0) for n_ in _pass_names) / (PEAK_L2_GBPS * 1e9)) * 1e3, 3)
+    # the same floor with the table passes priced by the 128-byte LINES their gathers move from L2 to L1 (what the L2 serves:
+    # one line per channel and clock whatever part of it is used), from the committed --pmc passes of this workload
+    line_floor_ms = None
+    if (D, N, K, B, iters) == (512, 8, 256, 65536, 5):
+        import glob as _glob2
+        _pf = sorted(_glob2.glob(os.path.join(ROOT, "profiles", "r??_pmc_traffic.json")))
+        if _pf:
+            _pmc = json.load(open(_pf[-1]))
+            _lines = sum(_pmc.get(n_, {}).get("l2_read_request_bytes", 0) for n_ in _pass_names)
+            if _lines > 0:
+                line_floor_ms = round((LIMB_PRODUCTS * exec_fpv * B / (PEAK_I8_MFMA_TOPS * 1e12) + iters * _lines / (PEAK_L2_GBPS * 1e9)) * 1e3, 3)
     value = world * B * args.steps / dt
     out = {
         "metric": "vectors encoded/sec at dim=512, 8 codebooks; uint8 codes bit-exact vs ref",
@@ -405,6 +416,11 @@ def main():
         "parity": parity,
         "whole_encode": {"kernels_sum_ms": kernels_sum_ms,
                          "executed_floor_ms": executed_floor_ms, "frac_of_floor": round(executed_floor_ms / (dt / args.steps * 1e3), 4),
+                         "line_floor_ms": line_floor_ms,
+                         "frac_of_line_floor": None if line_floor_ms is None else round(line_floor_ms / (dt / args.steps * 1e3), 4),
+                         "line_floor_note": "as executed_floor_ms, but the table passes move the 128-byte lines their 4-byte gathers "
+                                            "touch (TCP_TCC_READ_REQ x 128 B per launch, profiles/rNN_pmc_traffic.json) at the L2 peak: "
+                                            "the floor of THIS data layout (fp32 Gram matrix, 16 of a segment's 256 entries per row)",
                          "executed_floor_note": "products: 2 x 2*D*N*K multiply-adds x 10 limb products per vector at the dense i8 peak; "
                                                 "table passes: the useful Gram / x.C bytes of the five table kernels at the L2 peak "
                                                 "(34.5 TB/s); what an encode of this ALGORITHM costs at the chip's peaks",
