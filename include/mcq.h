@@ -19,9 +19,12 @@
  *    (mcq_last_encode_launches);
  *  - return value: 0 = ok; MCQ_E* < 0 = rejected argument; > 0 = hipError_t of a
  *    failed launch.  Nothing is thrown across the boundary.
- *  - supported domain: codebook_size K a power of two in [16, 256], num_codebooks N
- *    a power of two, N <= 64 (the reference's trainer produces at most 64 x 16 and 32 x 256:
- *    bytes_per_frame <= 32, quantization/quantization.py:614; `prepared` holds the N*K x N*K Gram matrix), any
+ *  - supported domain: codebook_size K a power of two in [16, 1024], num_codebooks N
+ *    a power of two, N <= 64, N*K <= 16384 (the reference's trainer produces at most 64 x 16 and 32 x 256:
+ *    bytes_per_frame <= 32, quantization/quantization.py:614; `prepared` holds the N*K x N*K Gram matrix).
+ *    K = 512 / 1024 (Quantizer(codebook_size=...) with as_bytes=False, :35): the index search, mcq_refine_indexes,
+ *    mcq_logits and mcq_decode (int64 codes); every uint8 output must be NULL there (MCQ_EINVAL otherwise), and the
+ *    trainer's entry points (mcq_logits_argmax, mcq_loss_*, mcq_recon_fwd, ...) answer MCQ_EUNSUPPORTED.  Any
  *    dim 1 <= D <= 16384 (rows are zero-padded to a multiple of 16 inside `prepared`; the i32 accumulators
  *    of the fixed-point products bound D).  The reference crashes for K < 16
  *    (quantization/quantization.py:506) and needs K <= 256 for byte output (:271).

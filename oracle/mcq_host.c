@@ -16,10 +16,11 @@ typedef struct mcq_oracle mcq_oracle;
 mcq_oracle *mcq_oracle_create(const float *centers, float cscale_exp, const float *W, const float *bias,
                               float lscale_exp, int N, int K, int D);
 void mcq_oracle_free(mcq_oracle *o);
-int mcq_oracle_compute_indexes(const mcq_oracle *o, const float *x, long B, int iters, uint8_t *idx, int nthreads);
-int mcq_oracle_refine(const mcq_oracle *o, const float *x, long B, int iters, uint8_t *idx, int nthreads);
+typedef uint16_t mcq_code;      /* as in mcq_oracle.c */
+int mcq_oracle_compute_indexes(const mcq_oracle *o, const float *x, long B, int iters, mcq_code *idx, int nthreads);
+int mcq_oracle_refine(const mcq_oracle *o, const float *x, long B, int iters, mcq_code *idx, int nthreads);
 int mcq_oracle_logits(const mcq_oracle *o, const float *x, long B, float *logits);
-void mcq_oracle_decode(const mcq_oracle *o, const uint8_t *idx, long B, float *out);
+void mcq_oracle_decode(const mcq_oracle *o, const mcq_code *idx, long B, float *out);
 
 typedef struct {
     uint32_t magic;
@@ -31,9 +32,9 @@ typedef struct {
 
 static int is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 static int domain_ok(int N, int K, int D) {
-    return is_pow2(K) && K >= 16 && K <= 256 && is_pow2(N) && N <= (K == 16 ? 64 : 32) && D >= 1 && D <= 16384;
+    return is_pow2(K) && K >= 16 && K <= 1024 && is_pow2(N) && N <= 64 && (long)N * K <= 16384 && D >= 1 && D <= 16384;
 }
-static int domain_err(int N, int K) { return (K < 16 || K > 256 || N > (K == 16 ? 64 : 32)) ? MCQ_EUNSUPPORTED : MCQ_EINVAL; }
+static int domain_err(int N, int K) { return (K < 16 || K > 1024 || N > 64 || (long)N * K > 16384) ? MCQ_EUNSUPPORTED : MCQ_EINVAL; }
 
 size_t mcq_prepared_bytes_host(int N, int K, int D) {
     size_t nk = (size_t)N * K;
@@ -73,13 +74,13 @@ size_t mcq_encode_workspace_bytes_host(long B, int N, int K, int D) {
 }
 
 /* encode tail (quantization/quantization.py:266-275): nibble packing when K == 16, cast */
-static void write_codes(const uint8_t *idx, long B, int N, int K, uint8_t *out_u8, int64_t *out_i64) {
+static void write_codes(const mcq_code *idx, long B, int N, int K, uint8_t *out_u8, int64_t *out_i64) {
     if (out_i64) {
         for (size_t i = 0; i < (size_t)B * N; i++) out_i64[i] = idx[i];
     } else if (K == 16 && N >= 2) {
         for (size_t i = 0; i < (size_t)B * N / 2; i++) out_u8[i] = (uint8_t)(idx[2 * i] | (idx[2 * i + 1] << 4));
     } else {
-        memcpy(out_u8, idx, (size_t)B * N);
+        for (size_t i = 0; i < (size_t)B * N; i++) out_u8[i] = (uint8_t)idx[i];
     }
 }
 
@@ -89,11 +90,12 @@ int mcq_encode_host(const float *x, long B, const void *prepared, float lscale_e
     (void)stream; (void)workspace_bytes;
     if (!domain_ok(N, K, D)) return domain_err(N, K);
     if (B < 0 || refine_iters < 0 || refine_iters > 60 || (out_u8 == NULL) == (out_i64 == NULL)) return MCQ_EINVAL;
+    if (K > 256 && out_u8 != NULL) return MCQ_EINVAL;      /* (:271: bytes hold entries of up to 256-entry codebooks) */
     if (B == 0) return 0;
     if (!x || !prepared || !workspace) return MCQ_EINVAL;
     mcq_oracle *o = open_state(prepared, lscale_exp, N, K, D, 1);
     if (!o) return MCQ_EINVAL;
-    uint8_t *idx = (uint8_t *)malloc((size_t)B * N);
+    mcq_code *idx = (mcq_code *)malloc(sizeof(mcq_code) * (size_t)B * N);
     int rc = mcq_oracle_compute_indexes(o, x, B, refine_iters, idx, 0);
     if (rc == 0) write_codes(idx, B, N, K, out_u8, out_i64);
     free(idx);
@@ -112,10 +114,10 @@ int mcq_refine_indexes_host(const float *x, long B, const void *prepared, int N,
     if (!x || !prepared || !workspace) return MCQ_EINVAL;
     mcq_oracle *o = open_state(prepared, 1.0f, N, K, D, 0);
     if (!o) return MCQ_EINVAL;
-    uint8_t *idx = (uint8_t *)malloc((size_t)B * N);
+    mcq_code *idx = (mcq_code *)malloc(sizeof(mcq_code) * (size_t)B * N);
     for (size_t i = 0; i < (size_t)B * N; i++) {
         if (idx_in[i] < 0 || idx_in[i] >= K) { free(idx); mcq_oracle_free(o); return MCQ_EINVAL; }
-        idx[i] = (uint8_t)idx_in[i];
+        idx[i] = (mcq_code)idx_in[i];
     }
     int rc = mcq_oracle_refine(o, x, B, refine_iters, idx, 0);
     if (rc == 0)
@@ -138,13 +140,13 @@ int mcq_decode_host(const void *codes, int code_bytes, int codes_per_row, long B
     mcq_oracle *o = open_state(prepared, 1.0f, N, K, D, 0);
     if (!o) return MCQ_EINVAL;
     /* _maybe_separate_indexes (:551-573): digit t of code j -> codebook j*rep + t */
-    uint8_t *idx = (uint8_t *)malloc((size_t)B * N);
+    mcq_code *idx = (mcq_code *)malloc(sizeof(mcq_code) * (size_t)B * N);
     for (long b = 0; b < B; b++)
         for (int j = 0; j < codes_per_row; j++) {
             size_t at = (size_t)b * codes_per_row + j;
             uint64_t c = code_bytes == 1 ? ((const uint8_t *)codes)[at] : (uint64_t)((const int64_t *)codes)[at];
             for (int t = 0; t < rep; t++) {
-                idx[(size_t)b * N + j * rep + t] = (uint8_t)(c % (uint64_t)K);
+                idx[(size_t)b * N + j * rep + t] = (mcq_code)(c % (uint64_t)K);
                 c /= (uint64_t)K;
             }
         }

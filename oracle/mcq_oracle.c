@@ -83,6 +83,9 @@
 #include <omp.h>
 #endif
 
+/* a codebook entry / index: two bytes (codebook_size up to 1,024; the product holds one byte up to 256 entries) */
+typedef uint16_t mcq_code;
+
 typedef struct {
     int N, K, D, Dp;
     float *C;      /* [N][K][Dp]   scaled centers, zero padded            */
@@ -316,7 +319,7 @@ static void frame_logits(const mcq_oracle *o, const int8_t *xl, int xe, float *o
 }
 
 /* A.1: initial indexes from the logits (:297-301) */
-static void init_indexes(const mcq_oracle *o, const int8_t *xl, int xe, uint8_t *idx, float *acc /*[N*K]*/) {
+static void init_indexes(const mcq_oracle *o, const int8_t *xl, int xe, mcq_code *idx, float *acc /*[N*K]*/) {
     int N = o->N, K = o->K;
     frame_logits(o, xl, xe, acc);
     for (int n = 0; n < N; n++) {
@@ -325,7 +328,7 @@ static void init_indexes(const mcq_oracle *o, const int8_t *xl, int xe, uint8_t 
             float v = acc[(size_t)n * K + k];
             if (v > bv) { bv = v; best = k; }
         }
-        idx[n] = (uint8_t)best;
+        idx[n] = (mcq_code)best;
     }
 }
 
@@ -373,20 +376,20 @@ static void compute_xc(const mcq_oracle *o, const int8_t *xl, int xe, float *xc)
 #define MCQ_MAX_LEVELS 7   /* candidates of 1, 2, 4, ..., 64 codebooks */
 typedef struct {
     int kc[MCQ_MAX_LEVELS];                 /* list length per level                             */
-    uint8_t *ent1;                          /* [N][kc[0]] codebook entries of the level-0 lists  */
+    mcq_code *ent1;                         /* [N][kc[0]] codebook entries of the level-0 lists  */
     uint8_t *pos[MCQ_MAX_LEVELS];           /* level v >= 1: [N >> v][kc[v]][2] positions in the halves' lists */
     float *S[MCQ_MAX_LEVELS];               /* [N >> v][kc[v]] scores                            */
 } tf_lists;
 
 /* T[X][Y] of level v (groups of 2^v codebooks, X < Y), kc[v] x kc[v] floats into `out` */
-static void tf_table(const mcq_oracle *o, const uint8_t *idx, const tf_lists *L, int v, int X, int Y, float *out) {
+static void tf_table(const mcq_oracle *o, const mcq_code *idx, const tf_lists *L, int v, int X, int Y, float *out) {
     const int K = o->K;
     const size_t nk = (size_t)o->N * K;
     const int kc = L->kc[v];
     if (v == 0) {
         const float *G = o->G;
         const size_t on = (size_t)X * K + idx[X], om = (size_t)Y * K + idx[Y];
-        const uint8_t *en = L->ent1 + (size_t)X * kc, *em = L->ent1 + (size_t)Y * kc;
+        const mcq_code *en = L->ent1 + (size_t)X * kc, *em = L->ent1 + (size_t)Y * kc;
         const float w = G[on * nk + om];
         for (int i = 0; i < kc; i++) {
             const size_t sn = (size_t)X * K + en[i];
@@ -417,7 +420,7 @@ static void tf_table(const mcq_oracle *o, const uint8_t *idx, const tf_lists *L,
 }
 
 /* one _refine_indexes pass for one vector (:308-547); xc = compute_xc(x); idx updated in place */
-static void refine_one_table(const mcq_oracle *o, const float *x, const float *xc, uint8_t *idx, scratch *s,
+static void refine_one_table(const mcq_oracle *o, const float *x, const float *xc, mcq_code *idx, scratch *s,
                              mcq_trace *tr) {
     const int N = o->N, K = o->K, D = o->D, Dp = o->Dp;
     const size_t nk = (size_t)N * K;
@@ -475,7 +478,7 @@ static void refine_one_table(const mcq_oracle *o, const float *x, const float *x
         float v1;
         select_smallest(s->S, K, 1, s->pos, &v1);
         if (tr && tr->sel_pos) { tr->sel_pos[0] = s->pos[0]; tr->sel_val[0] = v1; }
-        idx[0] = (uint8_t)s->pos[0];
+        idx[0] = (mcq_code)s->pos[0];
         return;
     }
     int nlev = 0;
@@ -483,7 +486,7 @@ static void refine_one_table(const mcq_oracle *o, const float *x, const float *x
     tf_lists L;
     memset(&L, 0, sizeof(L));
     for (int v = 0; v < nlev; v++) L.kc[v] = k_cutoff(K, 1 << v);
-    L.ent1 = (uint8_t *)malloc((size_t)N * L.kc[0]);
+    L.ent1 = (mcq_code *)malloc(sizeof(mcq_code) * (size_t)N * L.kc[0]);
     for (int v = 0; v < nlev; v++) {
         L.S[v] = (float *)malloc(sizeof(float) * (N >> v) * L.kc[v]);
         if (v > 0) L.pos[v] = (uint8_t *)malloc((size_t)(N >> v) * L.kc[v] * 2);
@@ -492,7 +495,7 @@ static void refine_one_table(const mcq_oracle *o, const float *x, const float *x
     for (int n = 0; n < N; n++) {                   /* first sort-and-truncate (:470-503) */
         select_smallest(s->S + (size_t)n * K, K, L.kc[0], s->pos, L.S[0] + (size_t)n * L.kc[0]);
         for (int j = 0; j < L.kc[0]; j++) {
-            L.ent1[(size_t)n * L.kc[0] + j] = (uint8_t)s->pos[j];
+            L.ent1[(size_t)n * L.kc[0] + j] = (mcq_code)s->pos[j];
             if (tr && tr->sel_pos) { tr->sel_pos[tr_sel] = s->pos[j]; tr->sel_val[tr_sel] = L.S[0][(size_t)n * L.kc[0] + j]; tr_sel++; }
         }
     }
@@ -528,7 +531,7 @@ static void refine_one_table(const mcq_oracle *o, const float *x, const float *x
         }
     }
     /* the winner's leaves, codebook by codebook (:468-469): walk down the position tree */
-    uint8_t res[64];
+    mcq_code res[64];
     for (int n = 0; n < N; n++) {
         int v = nlev - 1, g = 0;
         int p = ((n >> v) & 1) ? win % L.kc[v] : win / L.kc[v];   /* position in the level-v list of group n >> v */
@@ -541,21 +544,21 @@ static void refine_one_table(const mcq_oracle *o, const float *x, const float *x
         }
         res[n] = L.ent1[(size_t)n * L.kc[0] + p];
     }
-    memcpy(idx, res, N);
+    memcpy(idx, res, sizeof(mcq_code) * N);
     free(L.ent1);
     for (int v = 0; v < nlev; v++) { free(L.S[v]); free(L.pos[v]); }
 }
 
-static void refine_any(const mcq_oracle *o, const float *x, const float *xc, uint8_t *idx, scratch *s, mcq_trace *tr) {
+static void refine_any(const mcq_oracle *o, const float *x, const float *xc, mcq_code *idx, scratch *s, mcq_trace *tr) {
     refine_one_table(o, x, xc, idx, s, tr);
 }
 
-/* _compute_indexes for a batch (:281-305).  idx: uint8 [B][N]. */
-int mcq_oracle_compute_indexes(const mcq_oracle *o, const float *x, long B, int iters, uint8_t *idx,
+/* _compute_indexes for a batch (:281-305).  idx: uint16 [B][N] (codebooks of up to 1,024 entries). */
+int mcq_oracle_compute_indexes(const mcq_oracle *o, const float *x, long B, int iters, mcq_code *idx,
                                int nthreads) {
     if (!o->Wl) return -1;
     const int N = o->N, K = o->K, D = o->D, Dp = o->Dp;
-    if (K < 16 || K > 256) return -2;
+    if (K < 16 || K > 1024) return -2;
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
 #else
@@ -570,7 +573,7 @@ int mcq_oracle_compute_indexes(const mcq_oracle *o, const float *x, long B, int 
         float *xc = (float *)malloc(sizeof(float) * N * K);
 #pragma omp for schedule(dynamic, 8)
         for (long b = 0; b < B; b++) {
-            uint8_t *id = idx + (size_t)b * N;
+            mcq_code *id = idx + (size_t)b * N;
             const int xe = frame_limbs_centered(o, x + (size_t)b * D, xl, s.xpad);
             init_indexes(o, xl, xe, id, acc);
             if (iters > 0) compute_xc(o, xl, xe, xc);
@@ -582,9 +585,9 @@ int mcq_oracle_compute_indexes(const mcq_oracle *o, const float *x, long B, int 
 }
 
 /* `iters` passes of _refine_indexes (:308-547) from caller-supplied indexes, batch form */
-int mcq_oracle_refine(const mcq_oracle *o, const float *x, long B, int iters, uint8_t *idx, int nthreads) {
+int mcq_oracle_refine(const mcq_oracle *o, const float *x, long B, int iters, mcq_code *idx, int nthreads) {
     const int N = o->N, K = o->K, D = o->D, Dp = o->Dp;
-    if (K < 16 || K > 256) return -2;
+    if (K < 16 || K > 1024) return -2;
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
 #else
@@ -607,7 +610,7 @@ int mcq_oracle_refine(const mcq_oracle *o, const float *x, long B, int iters, ui
 }
 
 /* one refinement pass from given indexes, with the per-stage trace (one vector) */
-int mcq_oracle_refine_trace(const mcq_oracle *o, const float *x, uint8_t *idx, float *xerr, float *E,
+int mcq_oracle_refine_trace(const mcq_oracle *o, const float *x, mcq_code *idx, float *xerr, float *E,
                             float *R, float *S0, int *sel_pos, float *sel_val, float *comb) {
     scratch s; scratch_alloc(&s, o->N, o->K, o->Dp);
     mcq_trace tr = {xerr, E, R, S0, sel_pos, sel_val, comb};
@@ -640,11 +643,11 @@ int mcq_oracle_logits(const mcq_oracle *o, const float *x, long B, float *logits
 }
 
 /* decode (:131-148): out[b,:] = sum_n C[n, idx[b,n], :], n ascending */
-void mcq_oracle_decode(const mcq_oracle *o, const uint8_t *idx, long B, float *out) {
+void mcq_oracle_decode(const mcq_oracle *o, const mcq_code *idx, long B, float *out) {
     const int N = o->N, K = o->K, D = o->D, Dp = o->Dp;
 #pragma omp parallel for schedule(static)
     for (long b = 0; b < B; b++) {
-        const uint8_t *id = idx + (size_t)b * N;
+        const mcq_code *id = idx + (size_t)b * N;
         float *ob = out + (size_t)b * D;
         const float *c0 = o->C + ((size_t)0 * K + id[0]) * Dp;
         for (int d = 0; d < D; d++) ob[d] = c0[d];

@@ -29,7 +29,7 @@ def _load():
         return _lib
     lib = ctypes.CDLL(build())
     f32p = ctypes.POINTER(ctypes.c_float)
-    u8p = ctypes.POINTER(ctypes.c_uint8)
+    u16p = ctypes.POINTER(ctypes.c_uint16)      # indexes / entries: uint16 in the C oracle (codebook_size up to 1,024)
     i32p = ctypes.POINTER(ctypes.c_int)
     lib.mcq_oracle_create.restype = ctypes.c_void_p
     lib.mcq_oracle_create.argtypes = [f32p, ctypes.c_float, f32p, f32p, ctypes.c_float,
@@ -37,14 +37,14 @@ def _load():
     lib.mcq_oracle_free.argtypes = [ctypes.c_void_p]
     lib.mcq_oracle_get_centers.argtypes = [ctypes.c_void_p, f32p, f32p]
     lib.mcq_oracle_compute_indexes.restype = ctypes.c_int
-    lib.mcq_oracle_compute_indexes.argtypes = [ctypes.c_void_p, f32p, ctypes.c_long, ctypes.c_int, u8p,
+    lib.mcq_oracle_compute_indexes.argtypes = [ctypes.c_void_p, f32p, ctypes.c_long, ctypes.c_int, u16p,
                                                ctypes.c_int]
     lib.mcq_oracle_refine_trace.restype = ctypes.c_int
-    lib.mcq_oracle_refine_trace.argtypes = [ctypes.c_void_p, f32p, u8p, f32p, f32p, f32p, f32p, i32p, f32p,
+    lib.mcq_oracle_refine_trace.argtypes = [ctypes.c_void_p, f32p, u16p, f32p, f32p, f32p, f32p, i32p, f32p,
                                             f32p]
     lib.mcq_oracle_logits.restype = ctypes.c_int
     lib.mcq_oracle_logits.argtypes = [ctypes.c_void_p, f32p, ctypes.c_long, f32p]
-    lib.mcq_oracle_decode.argtypes = [ctypes.c_void_p, u8p, ctypes.c_long, f32p]
+    lib.mcq_oracle_decode.argtypes = [ctypes.c_void_p, u16p, ctypes.c_long, f32p]
     lib.mcq_oracle_ladder.restype = ctypes.c_int
     lib.mcq_oracle_ladder.argtypes = [ctypes.c_int, ctypes.c_int, i32p, i32p, i32p]
     lib.mcq_oracle_dp.restype = ctypes.c_int
@@ -120,12 +120,12 @@ class OracleQuantizer:
 
     def compute_indexes(self, x, refine_indexes_iters=3, nthreads=0):
         x = _f32(x).reshape(-1, self.D)
-        idx = np.empty((x.shape[0], self.N), np.uint8)
+        idx = np.empty((x.shape[0], self.N), np.uint16)
         rc = self._lib.mcq_oracle_compute_indexes(self._h, _ptr(x, ctypes.c_float), x.shape[0],
-                                                  int(refine_indexes_iters), _ptr(idx, ctypes.c_uint8),
+                                                  int(refine_indexes_iters), _ptr(idx, ctypes.c_uint16),
                                                   int(nthreads))
         assert rc == 0, f"oracle error {rc}"
-        return idx
+        return idx.astype(np.uint8) if self.K <= 256 else idx
 
     def encode(self, x, refine_indexes_iters=5, as_bytes=True, nthreads=0):
         """Quantizer.encode (quantization/quantization.py:244-275) incl. nibble packing."""
@@ -136,6 +136,7 @@ class OracleQuantizer:
             while K * K <= 256:
                 idx = idx[:, ::2] + K * idx[:, 1::2]
                 K = K * K
+            assert K <= 256                                            # quantization.py:271
             idx = idx.astype(np.uint8)
         return idx.reshape(*x.shape[:-1], -1)
 
@@ -160,9 +161,9 @@ class OracleQuantizer:
     def decode(self, codes):
         codes = np.asarray(codes)
         lead = codes.shape[:-1]
-        idx = np.ascontiguousarray(self.separate_indexes(codes).astype(np.uint8))
+        idx = np.ascontiguousarray(self.separate_indexes(codes).astype(np.uint16))
         out = np.empty((idx.shape[0], self.D), np.float32)
-        self._lib.mcq_oracle_decode(self._h, _ptr(idx, ctypes.c_uint8), idx.shape[0], _ptr(out, ctypes.c_float))
+        self._lib.mcq_oracle_decode(self._h, _ptr(idx, ctypes.c_uint16), idx.shape[0], _ptr(out, ctypes.c_float))
         return out.reshape(*lead, self.D)
 
     def refine_trace(self, x1, idx1):
@@ -177,12 +178,12 @@ class OracleQuantizer:
             n_sel += groups * kout
         Dp = self._lib.mcq_oracle_dp(self.D)
         x1 = _f32(x1).reshape(self.D)
-        idx = np.ascontiguousarray(idx1, dtype=np.uint8).reshape(self.N).copy()
+        idx = np.ascontiguousarray(idx1, dtype=np.uint16).reshape(self.N).copy()
         t = dict(xerr=np.zeros(Dp, np.float32), E=np.zeros(1, np.float32), R=np.zeros(self.N, np.float32),
                  S0=np.zeros((self.N, self.K), np.float32), sel_pos=np.zeros(n_sel, np.int32),
                  sel_val=np.zeros(n_sel, np.float32), comb=np.zeros(max(n_comb, 1), np.float32))
         f = ctypes.c_float
-        self._lib.mcq_oracle_refine_trace(self._h, _ptr(x1, f), _ptr(idx, ctypes.c_uint8), _ptr(t["xerr"], f),
+        self._lib.mcq_oracle_refine_trace(self._h, _ptr(x1, f), _ptr(idx, ctypes.c_uint16), _ptr(t["xerr"], f),
                                           _ptr(t["E"], f), _ptr(t["R"], f), _ptr(t["S0"], f),
                                           _ptr(t["sel_pos"], ctypes.c_int), _ptr(t["sel_val"], f),
                                           _ptr(t["comb"], f))

@@ -71,8 +71,10 @@ Prepared prepared_view(const void *p, int N, int K, int D) {
                     reinterpret_cast<const int *>(b + l.offCe), reinterpret_cast<const int *>(b + l.offWe)};
 }
 
-struct Workspace {
-    uint8_t *idx, *idxB, *idxC, *final_idx;   // B, C, final: fixed-point skipping only
+// CT: how a codebook entry is held (mcq_tf_kernels.h: one byte up to 256 entries per codebook, two above)
+template <typename CT>
+struct WorkspaceT {
+    CT *idx, *idxB, *idxC, *final_idx;        // B, C, final: fixed-point skipping only
     int *map[2], *cnt;
     float *E, *R, *xx, *XC;                   // per vector: |x_err|^2, |x_err - old_n|^2, |x|^2, x.C products
     float *gterms;                            // per vector: the N*N Gram entries G[o_m][o_m2] of the current indexes
@@ -99,10 +101,13 @@ size_t tf_tab_floats(int N, int K) {
     return best;
 }
 
+inline size_t code_bytes_of(int K) { return K > 256 ? 2 : 1; }
+
 size_t workspace_per_vector(int N, int K, int D) {
-    // idx x4, maps, E, xx, R, XC, lists (entries / positions / scores: <= 16 + 2*16 + 4*16 bytes per codebook and level), tabs x2,
+    // idx x4, maps, E, xx, R, XC, lists (entries / positions / scores: <= 16 cb + 2*16 + 4*16 bytes per codebook and level), tabs x2,
     // the frame as limb planes + its exponent, the N*N Gram terms of E / R
-    return 4 * (size_t)N + 8 + 8 + 4 * (size_t)N + 4 * (size_t)N * K + (size_t)tf_levels(N) * N * (16 + 2 * 16 + 4 * 16) + 64 +
+    const size_t cb = code_bytes_of(K);
+    return 4 * cb * (size_t)N + 8 + 8 + 4 * (size_t)N + 4 * (size_t)N * K + (size_t)tf_levels(N) * N * (16 * cb + 2 * 16 + 4 * 16) + 64 +
            2 * 4 * tf_tab_floats(N, K) + 4 * (size_t)fix_round_cols(D) + 4 + 4 * (size_t)N * N;
 }
 // alignment of the carved arrays + the rows the limb planes are padded by (to a multiple of 128)
@@ -117,15 +122,16 @@ long default_chunk(int N, int K, int D) {
     return c & ~127L;
 }
 
-Workspace carve(void *ws, long Bc, int N, int K, int D) {
+template <typename CT>
+WorkspaceT<CT> carve(void *ws, long Bc, int N, int K, int D) {
     char *p = static_cast<char *>(ws);
     size_t off = 0;
     auto take = [&](size_t bytes) { char *q = p + off; off = align256(off + bytes); return q; };
-    Workspace w;
-    w.idx = reinterpret_cast<uint8_t *>(take((size_t)Bc * N));
-    w.idxB = reinterpret_cast<uint8_t *>(take((size_t)Bc * N));
-    w.idxC = reinterpret_cast<uint8_t *>(take((size_t)Bc * N));
-    w.final_idx = reinterpret_cast<uint8_t *>(take((size_t)Bc * N));
+    WorkspaceT<CT> w;
+    w.idx = reinterpret_cast<CT *>(take((size_t)Bc * N * sizeof(CT)));
+    w.idxB = reinterpret_cast<CT *>(take((size_t)Bc * N * sizeof(CT)));
+    w.idxC = reinterpret_cast<CT *>(take((size_t)Bc * N * sizeof(CT)));
+    w.final_idx = reinterpret_cast<CT *>(take((size_t)Bc * N * sizeof(CT)));
     for (int i = 0; i < 2; ++i) w.map[i] = reinterpret_cast<int *>(take((size_t)Bc * 4));
     w.cnt = reinterpret_cast<int *>(take(64 * 4));
     w.E = reinterpret_cast<float *>(take((size_t)Bc * 4));
@@ -148,7 +154,7 @@ Workspace carve(void *ws, long Bc, int N, int K, int D) {
         w.tf.S[v] = nullptr;
         if (v >= nlev) continue;                       // no list of that level
         const int kc = w.tf.kc[v];
-        if (v == 0) w.tf.ent = reinterpret_cast<uint8_t *>(take((size_t)Bc * N * kc));
+        if (v == 0) w.tf.ent = reinterpret_cast<uint8_t *>(take((size_t)Bc * N * kc * sizeof(CT)));
         else w.tf.pos[v] = reinterpret_cast<uint8_t *>(take((size_t)Bc * (N >> v) * kc * 2));
         w.tf.S[v] = reinterpret_cast<float *>(take((size_t)Bc * (N >> v) * kc * 4));
     }
@@ -157,11 +163,14 @@ Workspace carve(void *ws, long Bc, int N, int K, int D) {
     return w;
 }
 
-// up to 64 codebooks (QuantizerTrainer produces at most 64 x 16 and 32 x 256: bytes_per_frame <= 32)
+// up to 64 codebooks (QuantizerTrainer produces at most 64 x 16 and 32 x 256: bytes_per_frame <= 32); codebooks of 512 and 1,024
+// entries (Quantizer(codebook_size = ...) used with as_bytes = False) as long as the Gram matrix stays within 16,384 rows (1 GB)
 bool domain_ok(int N, int K, int D) {
-    return is_pow2(K) && K >= 16 && K <= 256 && is_pow2(N) && N <= 64 && D >= 1 && D <= 16384;
+    return is_pow2(K) && K >= 16 && K <= 1024 && is_pow2(N) && N <= 64 && (long)N * K <= 16384 && D >= 1 && D <= 16384;
 }
-int domain_err(int N, int K, int D = 1) { return (K < 16 || K > 256 || N > 64 || D > 16384) ? MCQ_EUNSUPPORTED : MCQ_EINVAL; }
+int domain_err(int N, int K, int D = 1) {
+    return (K < 16 || K > 1024 || N > 64 || (long)N * K > 16384 || D > 16384) ? MCQ_EUNSUPPORTED : MCQ_EINVAL;
+}
 
 // optional per-launch timing (mcq_profile_encode)
 struct Prof {
@@ -270,7 +279,7 @@ int launch_xc(const int8_t *xf, const int *xe, long B, const int8_t *Cf, const i
 
 // logits[b][r] = fixdot(x_b, W_r) * lscale + bias[r] (stored when logits != nullptr) and the arg max per codebook
 int launch_logits(const int8_t *xf, const int *xe, long B, const Prepared &P, int N, int K, int D, float lscale,
-                  const float *lscale_ptr, float *logits, uint8_t *idx, hipStream_t st) {
+                  const float *lscale_ptr, float *logits, void *idx, hipStream_t st) {
     const long nk = (long)N * K;
     FixGemm g{};
     g.A = P.Wf; g.ea = P.We; g.RA = fix_round_rows(nk); g.M = nk;
@@ -278,14 +287,14 @@ int launch_logits(const int8_t *xf, const int *xe, long B, const Prepared &P, in
     g.Dq = fix_round_cols(D);
     g.walk_rows = 1;
     g.bias = P.bias; g.wmu = P.wmu; g.lscale = lscale; g.lscale_ptr = lscale_ptr;
-    g.logits = logits; g.ldo = nk; g.idx = idx; g.K = K; g.ncb = N;
+    g.logits = logits; g.ldo = nk; g.idx = idx; g.idx_wide = K > 256 ? 1 : 0; g.K = K; g.ncb = N;
     return launch_fgemm<FG_LOGITS>(g, st);
 }
 
 // ---------------------------------------------------------------- the refinement pass
 template <int K>
-int launch_tf_stage0_k(int N, const float *G, const float *XC, const uint8_t *idx, const float *R, const float *Q, long B,
-                       int keep, uint8_t *ent, float *S, uint8_t *fin, const int *nact, const int *map, hipStream_t st) {
+int launch_tf_stage0_k(int N, const float *G, const float *XC, const tf_code_of<K> *idx, const float *R, const float *Q, long B,
+                       int keep, tf_code_of<K> *ent, float *S, tf_code_of<K> *fin, const int *nact, const int *map, hipStream_t st) {
     const dim3 grid((unsigned)(((B + 3) / 4) * N)), block(256);
 #define MCQ_S0_CASE(NN) \
     case NN: hipLaunchKernelGGL((k_tf_stage0<K, NN>), grid, block, 0, st, G, XC, idx, R, Q, B, keep, ent, S, fin, nact, map); break;
@@ -296,6 +305,15 @@ int launch_tf_stage0_k(int N, const float *G, const float *XC, const uint8_t *id
 #undef MCQ_S0_CASE
     MCQ_LAUNCH_CHECK();
     return 0;
+}
+
+int launch_tf_stage0(int K, int N, const float *G, const float *XC, const uint16_t *idx, const float *R, const float *Q,
+                     long B, int keep, uint16_t *ent, float *S, uint16_t *fin, const int *nact, const int *map, hipStream_t st) {
+    switch (K) {
+        case 512: return launch_tf_stage0_k<512>(N, G, XC, idx, R, Q, B, keep, ent, S, fin, nact, map, st);
+        case 1024: return launch_tf_stage0_k<1024>(N, G, XC, idx, R, Q, B, keep, ent, S, fin, nact, map, st);
+        default: return MCQ_EUNSUPPORTED;
+    }
 }
 
 int launch_tf_stage0(int K, int N, const float *G, const float *XC, const uint8_t *idx, const float *R, const float *Q,
@@ -322,18 +340,19 @@ int launch_tf_stage0(int K, int N, const float *G, const float *XC, const uint8_
     }
 }
 
-int launch_tf_er(int N, const float *G, const float *XC, const uint8_t *idx, const float *xx, long B, int K, float *E, float *R,
+template <typename CT>
+int launch_tf_er(int N, const float *G, const float *XC, const CT *idx, const float *xx, long B, int K, float *E, float *R,
                  float *gterms, const int *nact, const int *map, hipStream_t st) {
     const dim3 grid((unsigned)((B + 3) / 4)), block(256);
     const bool direct = B <= 8192;          // one launch instead of two (E / R of a trainer batch: 4.9 + 4.7 -> about 5 us)
 #define MCQ_ER_CASE(NN)                                                                                                  \
     case NN:                                                                                                             \
         if (!direct) {                                                                                                   \
-            hipLaunchKernelGGL((k_tf_gram_terms<NN>), dim3((unsigned)(((B + 4 * (64 / NN) - 1) / (4 * (64 / NN))) * NN)), block, 0, st, G, idx, \
+            hipLaunchKernelGGL((k_tf_gram_terms<NN, CT>), dim3((unsigned)(((B + 4 * (64 / NN) - 1) / (4 * (64 / NN))) * NN)), block, 0, st, G, idx, \
                                B, K, gterms, nact);                                                                      \
             MCQ_LAUNCH_CHECK();                                                                                          \
         }                                                                                                                \
-        hipLaunchKernelGGL((k_tf_er<NN>), grid, block, 0, st, gterms, XC, idx, xx, B, K, E, R, nact, map,                  \
+        hipLaunchKernelGGL((k_tf_er<NN, CT>), grid, block, 0, st, gterms, XC, idx, xx, B, K, E, R, nact, map,              \
                            direct ? G : static_cast<const float *>(nullptr));                                           \
         break;
     switch (N) {
@@ -357,17 +376,19 @@ int launch_tf_up(int kh, int kc, const TfLists &L, long B, int N, int u, int nta
 }
 
 // combine of the siblings of level v >= 2 (list lengths kh at level v - 1, kc at level v)
+template <typename CT>
 int launch_tf_comb(int kh, int kc, const float *E, const TfLists &L, long B, int N, int v, int keep, const float *tabs,
-                   uint8_t *fin, const int *nact, hipStream_t st) {
+                   CT *fin, const int *nact, hipStream_t st) {
     const dim3 grid((unsigned)(B * (N >> (v + 1)))), block(64);
 #define MCQ_COMB_CASE(A, C)                                                                                                        \
     if (kh == A && kc == C) {                                                                                                     \
-        if (fin) hipLaunchKernelGGL((k_tf_comb<A, C, true>), grid, block, 0, st, E, L, B, N, v, keep, tabs, fin, nact);           \
-        else hipLaunchKernelGGL((k_tf_comb<A, C, false>), grid, block, 0, st, E, L, B, N, v, keep, tabs, fin, nact);              \
+        if (fin) hipLaunchKernelGGL((k_tf_comb<A, C, true, CT>), grid, block, 0, st, E, L, B, N, v, keep, tabs, fin, nact);       \
+        else hipLaunchKernelGGL((k_tf_comb<A, C, false, CT>), grid, block, 0, st, E, L, B, N, v, keep, tabs, fin, nact);          \
         MCQ_LAUNCH_CHECK();                                                                                                       \
         return 0;                                                                                                                 \
     }
-    MCQ_COMB_CASE(16, 32) MCQ_COMB_CASE(32, 32) MCQ_COMB_CASE(32, 64) MCQ_COMB_CASE(64, 64) MCQ_COMB_CASE(8, 16) MCQ_COMB_CASE(16, 16)
+    MCQ_COMB_CASE(16, 32) MCQ_COMB_CASE(32, 32) MCQ_COMB_CASE(32, 64) MCQ_COMB_CASE(64, 64)
+    if constexpr (sizeof(CT) == 1) { MCQ_COMB_CASE(8, 16) MCQ_COMB_CASE(16, 16) }      // (lists of 8: 16-entry codebooks)
 #undef MCQ_COMB_CASE
     return MCQ_EUNSUPPORTED;
 }
@@ -393,17 +414,27 @@ const char *const kCatNames[CAT_COUNT] = {
 };
 
 // the combines of one refinement pass; lists of K >= 32 hold 16, 16, 32, 32, 64 candidates, of K == 16: 8, 8, 16, 16, 32, 32
-int run_tf_combines(const float *G, const uint8_t *idx_cur, uint8_t *idx_new, const Workspace &w, const TfLists &L, long B, int N,
+// (the kernels over lists of 8 -- 16-entry codebooks -- exist for one-byte entries only)
+#define MCQ_TF_LAUNCH2(SMALLK, BIGK, grid, block, ...)                                                       \
+    do {                                                                                                     \
+        bool s_ = false;                                                                                     \
+        if constexpr (sizeof(CT) == 1) {                                                                     \
+            if (small) { hipLaunchKernelGGL(SMALLK, grid, block, 0, st, __VA_ARGS__); s_ = true; }           \
+        }                                                                                                    \
+        if (!s_) hipLaunchKernelGGL(BIGK, grid, block, 0, st, __VA_ARGS__);                                  \
+    } while (0)
+
+template <typename CT>
+int run_tf_combines(const float *G, const CT *idx_cur, CT *idx_new, const WorkspaceT<CT> &w, const TfLists &L, long B, int N,
                     int K, const int *nact, hipStream_t st, Prof *prof) {
     const bool small = (K == 16);
     const int nlev = tf_levels(N);
     {   // level 0: single codebooks
         const int keep = (N == 2) ? 1 : L.kc[1];
-        uint8_t *fin = (N == 2) ? idx_new : nullptr;
+        CT *fin = (N == 2) ? idx_new : nullptr;
         const dim3 grid((unsigned)(B * (N / 2)));
         if (prof) prof->begin(CAT_LEVEL0);
-        if (small) hipLaunchKernelGGL((k_tf_pair0<8>), grid, dim3(64), 0, st, G, idx_cur, w.E, L, B, N, K, keep, fin, nact);
-        else hipLaunchKernelGGL((k_tf_pair0<16>), grid, dim3(64), 0, st, G, idx_cur, w.E, L, B, N, K, keep, fin, nact);
+        MCQ_TF_LAUNCH2((k_tf_pair0<8, CT>), (k_tf_pair0<16, CT>), grid, dim3(64), G, idx_cur, w.E, L, B, N, K, keep, fin, nact);
         MCQ_LAUNCH_CHECK();
         if (prof) prof->end(CAT_LEVEL0);
     }
@@ -421,17 +452,16 @@ int run_tf_combines(const float *G, const uint8_t *idx_cur, uint8_t *idx_new, co
         const int ntab3 = fuse_l3 ? 16 : 1, per3 = fuse_l3 ? 4 : 1;
         const dim3 grid(pair_blocks + tab_blocks + (fuse_l3 ? (unsigned)(B * ntab3) : 0u));
         if (prof) prof->begin(CAT_LEVEL1_FUSED);
-        if (small) hipLaunchKernelGGL((k_tf_level1<8, 8>), grid, dim3(64), 0, st, G, idx_cur, w.E, L, B, N, K, keep, ntab1, per1, w.tabs[0], nact, pair_blocks, tab_blocks, ntab3, per3, w.tabs[1]);
-        else hipLaunchKernelGGL((k_tf_level1<16, 16>), grid, dim3(64), 0, st, G, idx_cur, w.E, L, B, N, K, keep, ntab1, per1, w.tabs[0], nact, pair_blocks, tab_blocks, ntab3, per3, w.tabs[1]);
+        MCQ_TF_LAUNCH2((k_tf_level1<8, 8, CT>), (k_tf_level1<16, 16, CT>), grid, dim3(64), G, idx_cur, w.E, L, B, N, K, keep, ntab1, per1, w.tabs[0],
+                       nact, pair_blocks, tab_blocks, ntab3, per3, w.tabs[1]);
         MCQ_LAUNCH_CHECK();
         if (prof) prof->end(CAT_LEVEL1_FUSED);
     } else if (N >= 4) {   // level 1: pairs of codebooks
         const int keep = (N == 4) ? 1 : L.kc[2];
-        uint8_t *fin = (N == 4) ? idx_new : nullptr;
+        CT *fin = (N == 4) ? idx_new : nullptr;
         const dim3 grid((unsigned)(B * (N / 4)));
         if (prof) prof->begin(CAT_LEVEL1);
-        if (small) hipLaunchKernelGGL((k_tf_pair1<8, 8>), grid, dim3(64), 0, st, G, idx_cur, w.E, L, B, N, K, keep, fin, nact);
-        else hipLaunchKernelGGL((k_tf_pair1<16, 16>), grid, dim3(64), 0, st, G, idx_cur, w.E, L, B, N, K, keep, fin, nact);
+        MCQ_TF_LAUNCH2((k_tf_pair1<8, 8, CT>), (k_tf_pair1<16, 16, CT>), grid, dim3(64), G, idx_cur, w.E, L, B, N, K, keep, fin, nact);
         MCQ_LAUNCH_CHECK();
         if (prof) prof->end(CAT_LEVEL1);
     }
@@ -439,21 +469,20 @@ int run_tf_combines(const float *G, const uint8_t *idx_cur, uint8_t *idx_new, co
         const int groups = N >> (v + 1);
         const bool last = (v == nlev - 1);
         const int keep = last ? 1 : L.kc[v + 1];
-        uint8_t *fin = last ? idx_new : nullptr;
+        CT *fin = last ? idx_new : nullptr;
         const int per1 = 1 << (v - 1), ntab1 = groups * per1 * per1;
         const int cat_tab = (v == 2) ? CAT_TABLES : CAT_TABLES_UP, cat_comb = (v == 2) ? CAT_COMBINE : CAT_COMBINE_UP;
         if (!(fuse_l1 && v == 2) && !(fuse_l3 && v == 3)) {     // (these tables came with the level-1 combines)
             if (prof) prof->begin(cat_tab);
-            if (small) hipLaunchKernelGGL((k_tf_table1<8, 8>), dim3((unsigned)(B * ntab1)), dim3(64), 0, st, G, idx_cur, L, B, N, K, ntab1, per1, w.tabs[0], nact);
-            else hipLaunchKernelGGL((k_tf_table1<16, 16>), dim3((unsigned)(B * ntab1)), dim3(64), 0, st, G, idx_cur, L, B, N, K, ntab1, per1, w.tabs[0], nact);
+            MCQ_TF_LAUNCH2((k_tf_table1<8, 8, CT>), (k_tf_table1<16, 16, CT>), dim3((unsigned)(B * ntab1)), dim3(64), G, idx_cur, L, B, N, K, ntab1, per1,
+                           w.tabs[0], nact);
             MCQ_LAUNCH_CHECK();
             if (prof) prof->end(cat_tab);
         }
         if (N == 16 && v == 3) {       // two groups of eight: levels 2 and 3 in one kernel, tables in LDS
             if (prof) prof->begin(cat_comb);
             const float *t3 = fuse_l3 ? w.tabs[1] : w.tabs[0];
-            if (small) hipLaunchKernelGGL((k_tf_comb3<8, 16, 16>), dim3((unsigned)B), dim3(256), 0, st, idx_cur, w.E, L, B, N, t3, idx_new, nact);
-            else hipLaunchKernelGGL((k_tf_comb3<16, 32, 32>), dim3((unsigned)B), dim3(256), 0, st, idx_cur, w.E, L, B, N, t3, idx_new, nact);
+            MCQ_TF_LAUNCH2((k_tf_comb3<8, 16, 16, CT>), (k_tf_comb3<16, 32, 32, CT>), dim3((unsigned)B), dim3(256), idx_cur, w.E, L, B, N, t3, idx_new, nact);
             MCQ_LAUNCH_CHECK();
             if (prof) prof->end(cat_comb);
             continue;
@@ -468,20 +497,24 @@ int run_tf_combines(const float *G, const uint8_t *idx_cur, uint8_t *idx_new, co
             cur ^= 1;
         }
         if (prof) prof->begin(cat_comb);
-        const int rc = launch_tf_comb(L.kc[v - 1], L.kc[v], w.E, L, B, N, v, keep, w.tabs[cur], fin, nact, st);
+        const int rc = launch_tf_comb<CT>(L.kc[v - 1], L.kc[v], w.E, L, B, N, v, keep, w.tabs[cur], fin, nact, st);
         if (rc) return rc;
         if (prof) prof->end(cat_comb);
     }
     return 0;
 }
+#undef MCQ_TF_LAUNCH2
 
-int run_encode(const float *x, long B, const void *prepared, float lscale, int N, int K, int D, int iters,
-               uint8_t *out_u8, int64_t *out_i64, void *workspace, size_t workspace_bytes, hipStream_t st,
-               Prof *prof, const int64_t *init_idx = nullptr, unsigned flags = 0, float *logits_out = nullptr,
-               uint8_t *codes_also = nullptr /* with out_i64: the same indexes as unpacked bytes [B][N] */) {
+template <typename CT>
+int run_encode_t(const float *x, long B, const void *prepared, float lscale, int N, int K, int D, int iters,
+                 uint8_t *out_u8, int64_t *out_i64, void *workspace, size_t workspace_bytes, hipStream_t st,
+                 Prof *prof, const int64_t *init_idx, unsigned flags, float *logits_out,
+                 uint8_t *codes_also /* with out_i64: the same indexes as unpacked bytes [B][N] */) {
     g_last_launches = 0;
     if (!domain_ok(N, K, D)) return domain_err(N, K, D);
     if (B < 0 || iters < 0 || iters > 60 || (out_u8 == nullptr) == (out_i64 == nullptr)) return MCQ_EINVAL;
+    // entries of more than 256-entry codebooks do not fit the byte outputs (encode(as_bytes=True) asserts the same, :271)
+    if (sizeof(CT) > 1 && (out_u8 != nullptr || codes_also != nullptr)) return MCQ_EINVAL;
     if (B == 0) return 0;
     if (!x || !prepared || !workspace) return MCQ_EINVAL;
     const size_t per = workspace_per_vector(N, K, D), slack = workspace_slack(D);
@@ -498,7 +531,7 @@ int run_encode(const float *x, long B, const void *prepared, float lscale, int N
 
     for (long lo = 0; lo < B; lo += chunk) {
         const long Bc = (B - lo < chunk) ? (B - lo) : chunk;
-        const Workspace w = carve(workspace, Bc, N, K, D);
+        const WorkspaceT<CT> w = carve<CT>(workspace, Bc, N, K, D);
         const int xh = (flags & MCQ_ENCODE_X_FP16) ? 1 : 0;   // rows of 2-byte elements
         const float *xc = xh ? reinterpret_cast<const float *>(reinterpret_cast<const uint16_t *>(x) + lo * D) : x + lo * D;
         int rc;
@@ -511,7 +544,7 @@ int run_encode(const float *x, long B, const void *prepared, float lscale, int N
             if (prof) prof->end(CAT_XX);
         }
         if (init_idx != nullptr) {
-            hipLaunchKernelGGL(k_import_indexes, dim3((unsigned)((Bc * N + 255) / 256)), dim3(256), 0, st,
+            hipLaunchKernelGGL(k_import_indexes<CT>, dim3((unsigned)((Bc * N + 255) / 256)), dim3(256), 0, st,
                                init_idx + lo * N, Bc * N, K, w.idx);
             MCQ_LAUNCH_CHECK();
         } else {
@@ -529,7 +562,7 @@ int run_encode(const float *x, long B, const void *prepared, float lscale, int N
             if (prof) prof->end(CAT_XC);
         }
         // without skipping: indexes are refined in place in w.idx, nothing is packed
-        uint8_t *idx_cur = w.idx, *idx_new = skip ? w.idxB : w.idx, *idx_pk = w.idxC;
+        CT *idx_cur = w.idx, *idx_new = skip ? w.idxB : w.idx, *idx_pk = w.idxC;
         const int *map_cur = nullptr, *nact = nullptr;
         int *map_nxt = w.map[0], *map_spare = w.map[1];
         if (skip) {
@@ -544,14 +577,14 @@ int run_encode(const float *x, long B, const void *prepared, float lscale, int N
         for (int it = 0; it < iters; ++it) {
             if (!er_ready) {
                 if (prof) prof->begin(CAT_ER);
-                rc = launch_tf_er(N, P.G, w.XC, idx_cur, w.xx, Bc, K, w.E, w.R, w.gterms, nact, map_cur, st);
+                rc = launch_tf_er<CT>(N, P.G, w.XC, idx_cur, w.xx, Bc, K, w.E, w.R, w.gterms, nact, map_cur, st);
                 if (rc) return rc;
                 if (prof) prof->end(CAT_ER);
             }
             er_ready = false;
             if (prof) prof->begin(CAT_STAGE0);
-            rc = launch_tf_stage0(K, N, P.G, w.XC, idx_cur, w.R, P.Q, Bc, (N == 1) ? 1 : w.tf.kc[0], w.tf.ent, w.tf.S[0],
-                                  (N == 1) ? idx_new : nullptr, nact, map_cur, st);
+            rc = launch_tf_stage0(K, N, P.G, w.XC, idx_cur, w.R, P.Q, Bc, (N == 1) ? 1 : w.tf.kc[0], reinterpret_cast<CT *>(w.tf.ent),
+                                  w.tf.S[0], (N == 1) ? idx_new : static_cast<CT *>(nullptr), nact, map_cur, st);
             if (rc) return rc;
             if (prof) prof->end(CAT_STAGE0);
             if (N >= 2) {
@@ -567,18 +600,18 @@ int run_encode(const float *x, long B, const void *prepared, float lscale, int N
                     L.out_u8 = out_u8 ? out_u8 + lo * N : (codes_also ? codes_also + lo * N : nullptr);
                     wrote_direct = true;
                 }
-                rc = run_tf_combines(P.G, idx_cur, idx_new, w, L, Bc, N, K, nact, st, prof);
+                rc = run_tf_combines<CT>(P.G, idx_cur, idx_new, w, L, Bc, N, K, nact, st, prof);
                 if (rc) return rc;
             }
             if (skip) {
                 const int last = (it + 1 == iters) ? 1 : 0;
                 if (prof) prof->begin(CAT_TAIL);
-                hipLaunchKernelGGL(k_compact, dim3((unsigned)((Bc + 255) / 256)), dim3(256), 0, st, idx_cur, idx_new,
+                hipLaunchKernelGGL(k_compact<CT>, dim3((unsigned)((Bc + 255) / 256)), dim3(256), 0, st, idx_cur, idx_new,
                                    map_cur, nact, Bc, N, last, w.final_idx, idx_pk, map_nxt, w.cnt + it);
                 MCQ_LAUNCH_CHECK();
                 if (prof) prof->end(CAT_TAIL);
                 // rotate: the packed list becomes the current one
-                uint8_t *t = idx_cur; idx_cur = idx_pk; idx_pk = t;
+                CT *t = idx_cur; idx_cur = idx_pk; idx_pk = t;
                 int *old_map = const_cast<int *>(map_cur);
                 map_cur = map_nxt;
                 map_nxt = old_map ? old_map : map_spare;
@@ -586,16 +619,27 @@ int run_encode(const float *x, long B, const void *prepared, float lscale, int N
             }
         }
         if (wrote_direct) continue;
-        const uint8_t *result = (skip && iters > 0) ? w.final_idx : w.idx;
+        const CT *result = (skip && iters > 0) ? w.final_idx : w.idx;
         const long outn = (out_i64 != nullptr) ? Bc * N : Bc * (N / pack);
         if (prof) prof->begin(CAT_TAIL);
-        hipLaunchKernelGGL(k_finalize, dim3((unsigned)((outn + 255) / 256)), dim3(256), 0, st, result, Bc, N, pack,
+        hipLaunchKernelGGL(k_finalize<CT>, dim3((unsigned)((outn + 255) / 256)), dim3(256), 0, st, result, Bc, N, pack,
                            out_u8 ? out_u8 + lo * (N / pack) : nullptr, out_i64 ? out_i64 + lo * N : nullptr,
                            codes_also ? codes_also + lo * N : nullptr);
         MCQ_LAUNCH_CHECK();
         if (prof) prof->end(CAT_TAIL);
     }
     return 0;
+}
+
+int run_encode(const float *x, long B, const void *prepared, float lscale, int N, int K, int D, int iters,
+               uint8_t *out_u8, int64_t *out_i64, void *workspace, size_t workspace_bytes, hipStream_t st,
+               Prof *prof, const int64_t *init_idx = nullptr, unsigned flags = 0, float *logits_out = nullptr,
+               uint8_t *codes_also = nullptr) {
+    if (K > 256)
+        return run_encode_t<uint16_t>(x, B, prepared, lscale, N, K, D, iters, out_u8, out_i64, workspace, workspace_bytes, st, prof,
+                                      init_idx, flags, logits_out, codes_also);
+    return run_encode_t<uint8_t>(x, B, prepared, lscale, N, K, D, iters, out_u8, out_i64, workspace, workspace_bytes, st, prof,
+                                 init_idx, flags, logits_out, codes_also);
 }
 
 // floats per lane of k_decode_backward when every row involved is 16-byte aligned.  Codebooks of 64 entries and more: 4 (a
@@ -962,7 +1006,7 @@ int mcq_logits(const float *x, long B, const void *prepared, float lscale_exp, i
 int mcq_logits_argmax(const float *x, long B, const void *prepared, float lscale_exp, int N, int K, int D,
                       float *logits_out, int64_t *argmax_out, void *workspace, size_t workspace_bytes, void *stream,
                       unsigned flags) {
-    if (!domain_ok(N, K, D)) return MCQ_EUNSUPPORTED;
+    if (!domain_ok(N, K, D) || K > 256) return MCQ_EUNSUPPORTED;      // (the trainer's entry point: one-byte entries)
     if (B < 0) return MCQ_EINVAL;
     if (B == 0) return 0;
     if (!x || !prepared || !logits_out || !argmax_out || !workspace) return MCQ_EINVAL;
@@ -1070,7 +1114,7 @@ int mcq_loss_tail(const float *sums, const float *prob_sum, const float *count, 
 
 int mcq_recon_fwd(const float *x, const int64_t *idx, long B, const void *prepared, const float *mean, int N, int K,
                   int D, float *err, float *num_part, float *den_part, void *stream) {
-    if (!domain_ok(N, K, D)) return MCQ_EUNSUPPORTED;
+    if (!domain_ok(N, K, D) || K > 256) return MCQ_EUNSUPPORTED;
     if (B <= 0) return MCQ_EINVAL;
     if (!x || !idx || !prepared || !mean || !err || !num_part || !den_part) return MCQ_EINVAL;
     const Prepared P = prepared_view(prepared, N, K, D);

@@ -285,9 +285,15 @@ struct FixGemm {
     const float *lscale_ptr;       // device scalar, or nullptr: lscale
     float lscale;
     float *logits;
-    uint8_t *idx;
+    void *idx;                     // uint8 [N cols][ncb], or uint16 when idx_wide (codebooks of more than 256 entries)
+    int idx_wide;
     int K, ncb;
 };
+
+__device__ __forceinline__ void fg_store_idx(const FixGemm &g, long pos, long entry) {
+    if (g.idx_wide) static_cast<uint16_t *>(g.idx)[pos] = (uint16_t)entry;
+    else static_cast<uint8_t *>(g.idx)[pos] = (uint8_t)entry;
+}
 
 // Persistent workgroups (one per CU: 132 KB of LDS): workgroup w takes the tiles w, w + grid, ... of an XCD-aware order and
 // runs their k steps as ONE stream through the LDS ring -- the first steps of the next tile are in flight while this one
@@ -528,7 +534,7 @@ k_fgemm(const FixGemm g) {
 #pragma unroll
                         for (int gi = 0; gi < 4; ++gi) {
                             const long row = m0 + bk[gi];
-                            if ((gi % span) == 0 && col < g.N && row < g.M) g.idx[col * g.ncb + row / K] = (uint8_t)(row % K);
+                            if ((gi % span) == 0 && col < g.N && row < g.M) fg_store_idx(g, col * g.ncb + row / K, row % K);
                         }
                     }
                 } else {
@@ -546,7 +552,7 @@ k_fgemm(const FixGemm g) {
                         if (hf > 0 && !(v > runv)) { v = runv; k = runk; }      // earlier rows win ties
                         runv = v;
                         runk = (int)k;
-                        if (hf == H - 1 && col < g.N && k < g.M) g.idx[col * g.ncb + k / K] = (uint8_t)(k % K);
+                        if (hf == H - 1 && col < g.N && k < g.M) fg_store_idx(g, col * g.ncb + k / K, k % K);
                     }
                 }
             }

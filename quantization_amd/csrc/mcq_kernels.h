@@ -437,9 +437,10 @@ __global__ void k_prepare_rows(const float *__restrict__ src, float scale, int a
 // One thread per active slot: converged (or last pass) -> the indexes go to their original row of
 // `final_idx`; otherwise the slot is re-packed (order irrelevant: vectors are independent) for the
 // next pass.  `cnt_next` was zeroed by the host (memset node ahead of the launch).
-__global__ void k_compact(const uint8_t *__restrict__ idx_old, const uint8_t *__restrict__ idx_new,
+template <typename CT>
+__global__ void k_compact(const CT *__restrict__ idx_old, const CT *__restrict__ idx_new,
                           const int *__restrict__ map_cur, const int *__restrict__ nact, long B, int N, int last,
-                          uint8_t *__restrict__ final_idx, uint8_t *__restrict__ idx_packed, int *__restrict__ map_next,
+                          CT *__restrict__ final_idx, CT *__restrict__ idx_packed, int *__restrict__ map_next,
                           int *__restrict__ cnt_next) {
     const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (nact) B = *nact;
@@ -460,30 +461,32 @@ __global__ void k_compact(const uint8_t *__restrict__ idx_old, const uint8_t *__
 // -------------------------------------------------------------------- output
 // encode tail (quantization.py:266-275): uint8 with nibble packing when K == 16
 // (low nibble = even codebook, :269), or int64 indexes.
-__global__ void k_finalize(const uint8_t *__restrict__ idx, long B, int N, int pack, uint8_t *__restrict__ out_u8,
+template <typename CT>
+__global__ void k_finalize(const CT *__restrict__ idx, long B, int N, int pack, uint8_t *__restrict__ out_u8,
                            int64_t *__restrict__ out_i64, uint8_t *__restrict__ codes_also) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (out_i64 != nullptr) {
         if (i < B * N) {
             out_i64[i] = idx[i];
-            if (codes_also) codes_also[i] = idx[i];
+            if (codes_also) codes_also[i] = (uint8_t)idx[i];
         }
     } else {
         const int per = N / pack;
         if (i < B * per) {
-            if (pack == 1) out_u8[i] = idx[i];
+            if (pack == 1) out_u8[i] = (uint8_t)idx[i];
             else out_u8[i] = (uint8_t)(idx[2 * i] + 16 * idx[2 * i + 1]);
         }
     }
 }
 
-// int64 indexes supplied by the caller -> the uint8 working copy of the search (values clamped to K-1)
-__global__ void k_import_indexes(const int64_t *__restrict__ in, long n, int K, uint8_t *__restrict__ out) {
+// int64 indexes supplied by the caller -> the working copy of the search (one or two bytes each; values clamped to K-1)
+template <typename CT>
+__global__ void k_import_indexes(const int64_t *__restrict__ in, long n, int K, CT *__restrict__ out) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
         long v = in[i];
         v = v < 0 ? 0 : (v > K - 1 ? K - 1 : v);
-        out[i] = (uint8_t)v;
+        out[i] = (CT)v;
     }
 }
 

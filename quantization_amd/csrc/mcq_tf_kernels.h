@@ -17,12 +17,20 @@
 #pragma once
 #include "mcq_kernels.h"
 
+#include <type_traits>
+
 namespace mcq {
 
 constexpr int kTfLevels = 6;   // lists of candidates over 1, 2, 4, 8, 16, 32 codebooks (N <= 64)
 
+// A codebook entry is held in one byte up to 256 entries per codebook (what QuantizerTrainer produces and what encode() packs,
+// quantization.py:266-271) and in two bytes above (Quantizer(codebook_size = 512 / 1024), as_bytes = False); the kernels that
+// touch entries take the type as `CT`.  The one-byte instantiations are the tuned ones; the two-byte ones take the plain paths.
+template <int K>
+using tf_code_of = std::conditional_t<(K > 256), uint16_t, uint8_t>;
+
 struct TfLists {
-    uint8_t *ent;               // [B][N][kc[0]]            level-0 lists: codebook entries
+    uint8_t *ent;               // [B][N][kc[0]]            level-0 lists: codebook entries (CT: one or two bytes each)
     uint8_t *pos[kTfLevels];    // [B][N >> v][kc[v]][2]    level v >= 1: positions in the halves' lists
     float *S[kTfLevels];        // [B][N >> v][kc[v]]       scores
     int kc[kTfLevels];
@@ -49,9 +57,9 @@ __device__ __forceinline__ float shfl_f(float v, int src) {
 // k_tf_gram_terms gathers them XCD by XCD instead: workgroup id mod N = m, a wave takes 64 / N vectors x the N entries of
 // row block m, so an XCD only ever touches the rows of its own codebooks (2 MB); the terms go to gterms[b][m][m2] and
 // k_tf_er reads its 64 terms as one coalesced line.
-template <int N>
+template <int N, typename CT = uint8_t>
 __global__ void __launch_bounds__(256)
-k_tf_gram_terms(const float *__restrict__ G, const uint8_t *__restrict__ idx, long B, int K, float *__restrict__ gterms,
+k_tf_gram_terms(const float *__restrict__ G, const CT *__restrict__ idx, long B, int K, float *__restrict__ gterms,
                 const int *__restrict__ nact) {
     constexpr int VW = 64 / N;                     // vectors per wave
     if (nact) B = *nact;
@@ -59,7 +67,7 @@ k_tf_gram_terms(const float *__restrict__ G, const uint8_t *__restrict__ idx, lo
     const long b = ((long)(blockIdx.x / N) * 4 + (threadIdx.x >> 6)) * VW + lane_id() / N;
     const int m2 = lane_id() % N;
     if (b >= B) return;
-    const uint8_t *id = idx + b * N;
+    const CT *id = idx + b * N;
     const int NK = N * K;
     gterms[(b * N + m) * N + m2] = G[((size_t)(m * K + id[m]) << __builtin_ctz((unsigned)NK)) + m2 * K + id[m2]];
 }
@@ -67,8 +75,8 @@ k_tf_gram_terms(const float *__restrict__ G, const uint8_t *__restrict__ idx, lo
 // One wave per vector: E = |x_err|^2 and R[n] = |x_err - old_n|^2 (:401-409) from the N*N Gram terms, N entries of XC
 // and |x|^2 (oracle "TABLE FORM", E, R).
 // The indexes come from memory (`id`) or, when the wave has just chosen them, from lane m of `e_reg` (FROM_REG).
-template <int N, bool FROM_REG>
-__device__ __forceinline__ void tf_er_wave(long b, long bx, const uint8_t *__restrict__ id, int e_reg,
+template <int N, bool FROM_REG, typename CT = uint8_t>
+__device__ __forceinline__ void tf_er_wave(long b, long bx, const CT *__restrict__ id, int e_reg,
                                            const float *__restrict__ gterms, const float *__restrict__ Gdirect,
                                            const float *__restrict__ XC, const float *__restrict__ xx, int K,
                                            float *__restrict__ E_out, float *__restrict__ R_out) {
@@ -113,16 +121,16 @@ __device__ __forceinline__ void tf_er_wave(long b, long bx, const uint8_t *__res
     if (lane == 0) E_out[b] = E;
 }
 
-template <int N>
+template <int N, typename CT = uint8_t>
 __global__ void __launch_bounds__(256)
-k_tf_er(const float *__restrict__ gterms, const float *__restrict__ XC, const uint8_t *__restrict__ idx,
+k_tf_er(const float *__restrict__ gterms, const float *__restrict__ XC, const CT *__restrict__ idx,
         const float *__restrict__ xx, long B, int K, float *__restrict__ E_out, float *__restrict__ R_out,
         const int *__restrict__ nact, const int *__restrict__ map, const float *__restrict__ Gdirect) {
     if (nact) B = *nact;
     const long b = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= B) return;
     const long bx = map ? (long)map[b] : b;          // row of the per-call arrays (XC, xx)
-    tf_er_wave<N, false>(b, bx, idx + b * N, 0, gterms, Gdirect, XC, xx, K, E_out, R_out);
+    tf_er_wave<N, false, CT>(b, bx, idx + b * N, 0, gterms, Gdirect, XC, xx, K, E_out, R_out);
 }
 
 // ------------------------------------------------------------------ stage 0
@@ -130,10 +138,12 @@ k_tf_er(const float *__restrict__ gterms, const float *__restrict__ XC, const ui
 // Q, then the first sort-and-truncate (:470-503).  Workgroup id mod N = n: an XCD's L2 holds G[:, segment n] only.
 template <int K, int N>
 __global__ void __launch_bounds__(256)
-k_tf_stage0(const float *__restrict__ G, const float *__restrict__ XC, const uint8_t *__restrict__ idx,
+k_tf_stage0(const float *__restrict__ G, const float *__restrict__ XC, const tf_code_of<K> *__restrict__ idx,
             const float *__restrict__ R, const float *__restrict__ Q, long B, int keep,
-            uint8_t *__restrict__ ent_out, float *__restrict__ S_out, uint8_t *__restrict__ idx_final /* N == 1 */,
+            tf_code_of<K> *__restrict__ ent_out, float *__restrict__ S_out, tf_code_of<K> *__restrict__ idx_final /* N == 1 */,
             const int *__restrict__ nact, const int *__restrict__ map) {
+    using CT = tf_code_of<K>;
+    constexpr int CB = (int)sizeof(CT);
     constexpr int VPL = (K >= 64) ? K / 64 : 1;
     constexpr int NK = N * K;
     constexpr int CH = (N - 1 < 8) ? (N > 1 ? N - 1 : 1) : 8;    // row segments in flight
@@ -157,7 +167,7 @@ k_tf_stage0(const float *__restrict__ G, const float *__restrict__ XC, const uin
     const int lane = lane_id();
     const bool act = VPL * lane < K;
     const int k0 = act ? VPL * lane : 0;
-    const uint8_t *id = idx + b * N;
+    const CT *id = idx + b * N;
     // the vector's own inputs (its x.C segment comes from HBM: the longest latency of the kernel) are requested first,
     // beside the index bytes, not after the Gram rows that depend on those bytes
     const float *xc = XC + ((size_t)(map ? (long)map[b] : b) * NK + n * K + k0);
@@ -167,6 +177,13 @@ k_tf_stage0(const float *__restrict__ G, const float *__restrict__ XC, const uin
         const f32x4 x4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(xc)), q4 = *reinterpret_cast<const f32x4 *>(q);
 #pragma unroll
         for (int i = 0; i < 4; ++i) { xcv[i] = x4[i]; qv[i] = q4[i]; }
+    } else if constexpr (VPL % 4 == 0) {      // codebooks of 512 / 1,024 entries
+#pragma unroll
+        for (int i4 = 0; i4 < VPL / 4; ++i4) {
+            const f32x4 x4 = reinterpret_cast<const f32x4 *>(xc)[i4], q4 = reinterpret_cast<const f32x4 *>(q)[i4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { xcv[4 * i4 + i] = x4[i]; qv[4 * i4 + i] = q4[i]; }
+        }
     } else {
 #pragma unroll
         for (int i = 0; i < VPL; ++i) { xcv[i] = xc[i]; qv[i] = q[i]; }
@@ -175,15 +192,15 @@ k_tf_stage0(const float *__restrict__ G, const float *__restrict__ XC, const uin
     __builtin_amdgcn_sched_barrier(0);                      // (the scheduler otherwise sinks the x.C read below the Gram reads)
     // the vector's N index bytes: one scalar load per 8 of them (the vector is the same for the whole wave) instead of N - 1
     // byte loads per lane; the Gram row addresses are then scalar too
-    unsigned long long iw[N >= 8 ? N / 8 : 1];
-    if constexpr (N >= 8) {
+    unsigned long long iw[N * CB >= 8 ? N * CB / 8 : 1];
+    if constexpr (N * CB >= 8) {
         const unsigned long long *ip =
-            reinterpret_cast<const unsigned long long *>(idx) + (size_t)__builtin_amdgcn_readfirstlane((int)b) * (N / 8);
+            reinterpret_cast<const unsigned long long *>(idx) + (size_t)__builtin_amdgcn_readfirstlane((int)b) * (N * CB / 8);
 #pragma unroll
-        for (int q8 = 0; q8 < N / 8; ++q8) iw[q8] = ip[q8];
+        for (int q8 = 0; q8 < N * CB / 8; ++q8) iw[q8] = ip[q8];
     }
     auto code = [&](int m) -> int {
-        if constexpr (N >= 8) return (int)((iw[m >> 3] >> (8 * (m & 7))) & 0xffull);
+        if constexpr (N * CB >= 8) return (int)((iw[(m * CB) >> 3] >> (8 * ((m * CB) & 7))) & (CB == 1 ? 0xffull : 0xffffull));
         else return (int)id[m];
     };
     float t[VPL];
@@ -197,10 +214,13 @@ k_tf_stage0(const float *__restrict__ G, const float *__restrict__ XC, const uin
             const int j = j0 + u < N - 1 ? j0 + u : N - 2;
             const int m = j < n ? j : j + 1;                    // m ascending over the codebooks other than n
             const float *p = G + ((size_t)(m * K + code(m)) * NK + n * K + k0);
-            if constexpr (VPL == 4) {
-                const f32x4 t4 = *reinterpret_cast<const f32x4 *>(p);
+            if constexpr (VPL % 4 == 0) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) gv[u][i] = t4[i];
+                for (int i4 = 0; i4 < VPL / 4; ++i4) {
+                    const f32x4 t4 = reinterpret_cast<const f32x4 *>(p)[i4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) gv[u][4 * i4 + i] = t4[i];
+                }
             } else {
 #pragma unroll
                 for (int i = 0; i < VPL; ++i) gv[u][i] = p[i];
@@ -225,11 +245,11 @@ k_tf_stage0(const float *__restrict__ G, const float *__restrict__ XC, const uin
     int op;
     wave_select_fast<VPL>(sv, sp, keep, K, sel[threadIdx.x >> 6], ov, op);
     if (N == 1) {                                             // the best entry is the result (:468-469)
-        if (lane == 0) idx_final[b] = (uint8_t)op;
+        if (lane == 0) idx_final[b] = (CT)op;
         return;
     }
     if (lane < keep) {
-        ent_out[(b * N + n) * keep + lane] = (uint8_t)op;
+        ent_out[(b * N + n) * keep + lane] = (CT)op;
         S_out[(b * N + n) * keep + lane] = ov;
     }
 }
@@ -308,9 +328,9 @@ k_tf_stage0_k16(const float *__restrict__ G, const float *__restrict__ XC, const
 // D[n][m] (codebooks n < m) over the two level-0 lists of KC entries: lane holds positions p = VPL*lane + v
 // (row i = p / KC, column j = p % KC).  KC*KC core reads plus one read per lane for the 2*KC + 1 border values
 // G[s_n,i][o_m] (lanes 0..KC-1), G[o_n][s_m,j] (KC..2KC-1), G[o_n][o_m] (lane 2KC), handed round by ds_bpermute.
-template <int KC>
+template <int KC, typename CT = uint8_t>
 __device__ __forceinline__ void tf_leaf(const float *__restrict__ G, int NK, int K, int n, int m,
-                                        const uint8_t *__restrict__ en, const uint8_t *__restrict__ em, int old_n,
+                                        const CT *__restrict__ en, const CT *__restrict__ em, int old_n,
                                         int old_m, float (&d)[KC * KC / 64]) {
     constexpr int VPL = KC * KC / 64;
     const int lane = lane_id();
@@ -321,11 +341,12 @@ __device__ __forceinline__ void tf_leaf(const float *__restrict__ G, int NK, int
     // use: left to the compiler the border bytes were loaded one after the other BEHIND the first wait, and the Gram reads
     // started four memory round trips into the kernel instead of two
     const int bl = lane < 2 * KC ? lane : 2 * KC;
-    const uint8_t *bp = bl < KC ? en + bl : em + (bl < 2 * KC ? bl - KC : 0);
+    const CT *bp = bl < KC ? en + bl : em + (bl < 2 * KC ? bl - KC : 0);
     int e_i = en[i], e_b = *bp;
     uint32_t w4 = 0;
     int ej[VPL];
-    if constexpr (VPL == 4) {
+    constexpr bool kPacked = (VPL == 4 && sizeof(CT) == 1);      // the lane's four column entries as one 32-bit word
+    if constexpr (kPacked) {
         w4 = *reinterpret_cast<const uint32_t *>(em + j0);
         asm volatile("" : "+v"(e_i), "+v"(e_b), "+v"(w4));
     } else {
@@ -337,7 +358,7 @@ __device__ __forceinline__ void tf_leaf(const float *__restrict__ G, int NK, int
     const uint32_t br = bl < KC ? rown + (uint32_t)e_b : rown + (uint32_t)old_n;
     const uint32_t bc = (bl >= KC && bl < 2 * KC) ? colm + (uint32_t)e_b : colm + (uint32_t)old_m;
     float g[VPL];
-    if constexpr (VPL == 4) {
+    if constexpr (kPacked) {
 #pragma unroll
         for (int v = 0; v < 4; ++v) g[v] = G[(si << nksh) + colm + ((w4 >> (8 * v)) & 0xffu)];
     } else {
@@ -358,14 +379,15 @@ __device__ __forceinline__ void tf_leaf(const float *__restrict__ G, int NK, int
 // a crash).
 __device__ __attribute__((noinline)) void tf_er_next(const float *G, const float *XC, const float *xx, int K, float *E, float *R,
                                                      long b, int N, int e) {
-    if (N == 8) tf_er_wave<8, true>(b, b, nullptr, e, nullptr, G, XC, xx, K, E, R);
-    else if (N == 4) tf_er_wave<4, true>(b, b, nullptr, e, nullptr, G, XC, xx, K, E, R);
-    else if (N == 16) tf_er_wave<16, true>(b, b, nullptr, e, nullptr, G, XC, xx, K, E, R);
+    if (N == 8) tf_er_wave<8, true, uint8_t>(b, b, nullptr, e, nullptr, G, XC, xx, K, E, R);
+    else if (N == 4) tf_er_wave<4, true, uint8_t>(b, b, nullptr, e, nullptr, G, XC, xx, K, E, R);
+    else if (N == 16) tf_er_wave<16, true, uint8_t>(b, b, nullptr, e, nullptr, G, XC, xx, K, E, R);
 }
 
 // The winner's leaves, codebook by codebook (:468-469): lane n walks down the position tree.
 // `win` = position a*kc + b of the winner among the pairs of the two top-level lists.
-__device__ __forceinline__ void tf_emit(const TfLists &L, long b, int N, int nlev, int win, uint8_t *__restrict__ idx_out) {
+template <typename CT>
+__device__ __forceinline__ void tf_emit(const TfLists &L, long b, int N, int nlev, int win, CT *__restrict__ idx_out) {
     const int n = lane_id();
     int e = 0;
     if (n < N) {
@@ -378,19 +400,19 @@ __device__ __forceinline__ void tf_emit(const TfLists &L, long b, int N, int nle
             --v;
             g = n >> v;
         }
-        e = L.ent[(b * N + n) * L.kc[0] + p];
-        idx_out[b * N + n] = (uint8_t)e;
+        e = reinterpret_cast<const CT *>(L.ent)[(b * N + n) * L.kc[0] + p];
+        idx_out[b * N + n] = (CT)e;
         if (L.out_i64) L.out_i64[b * N + n] = e;
-        if (L.out_u8) L.out_u8[b * N + n] = (uint8_t)e;
+        if (L.out_u8) L.out_u8[b * N + n] = (uint8_t)e;      // (one-byte entries only: the host leaves it null otherwise)
     }
     if (L.erE) tf_er_next(L.erG, L.erXC, L.erxx, L.erK, L.erE, L.erR, b, N, e);      // E, R[n] of the next pass, from the indexes in lanes 0 .. N - 1
 }
 
 // select `keep` of the wave's scores and write the next level's list (or, for the last combine, the result)
-template <int VPL>
+template <int VPL, typename CT = uint8_t>
 __device__ __forceinline__ void tf_finish(const float (&sv)[VPL], const int (&sp)[VPL], int keep, int KCin, u64 *scratch,
                                           const TfLists &L, int vout /* level of the list written */, long b, int N,
-                                          int gout, uint8_t *__restrict__ idx_final) {
+                                          int gout, CT *__restrict__ idx_final) {
     if (idx_final != nullptr) {     // one group left, keep == 1: the smallest (score, position) is the result
         // (wave_select's rule for one winner -- smallest (score, position), NaN never taken -- without its general
         // bookkeeping of the previous winner: ten instructions per candidate there)
@@ -417,10 +439,10 @@ __device__ __forceinline__ void tf_finish(const float (&sv)[VPL], const int (&sp
 
 // ------------------------------------------------------- combine of level 0
 // Siblings n = 2g, m = 2g + 1 (single codebooks): scores straight from the leaf table.  One wave per (b, g).
-template <int KC>
+template <int KC, typename CT = uint8_t>
 __global__ void __launch_bounds__(64)
-k_tf_pair0(const float *__restrict__ G, const uint8_t *__restrict__ idx, const float *__restrict__ E, TfLists L, long B,
-           int N, int K, int keep, uint8_t *__restrict__ idx_final, const int *__restrict__ nact) {
+k_tf_pair0(const float *__restrict__ G, const CT *__restrict__ idx, const float *__restrict__ E, TfLists L, long B,
+           int N, int K, int keep, CT *__restrict__ idx_final, const int *__restrict__ nact) {
     constexpr int VPL = KC * KC / 64;
     __shared__ u64 scratch[kSelectLdsU64];
     if (nact) B = *nact;
@@ -430,7 +452,7 @@ k_tf_pair0(const float *__restrict__ G, const uint8_t *__restrict__ idx, const f
     if (b >= B) return;
     const int lane = lane_id();
     const int n = 2 * g, m = n + 1;
-    const uint8_t *en = L.ent + (b * N + n) * KC, *em = L.ent + (b * N + m) * KC;
+    const CT *en = reinterpret_cast<const CT *>(L.ent) + (b * N + n) * KC, *em = reinterpret_cast<const CT *>(L.ent) + (b * N + m) * KC;
     const int i = (VPL * lane) / KC, j0 = (VPL * lane) % KC;
     const float Eb = E[b];
     const float se = L.S[0][(b * N + n) * KC + i];
@@ -438,7 +460,7 @@ k_tf_pair0(const float *__restrict__ G, const uint8_t *__restrict__ idx, const f
 #pragma unroll
     for (int v = 0; v < VPL; ++v) so[v] = L.S[0][(b * N + m) * KC + j0 + v];
     float d[VPL];
-    tf_leaf<KC>(G, N * K, K, n, m, en, em, idx[b * N + n], idx[b * N + m], d);
+    tf_leaf<KC, CT>(G, N * K, K, n, m, en, em, idx[b * N + n], idx[b * N + m], d);
     float sv[VPL];
     int sp[VPL];
 #pragma unroll
@@ -446,7 +468,7 @@ k_tf_pair0(const float *__restrict__ G, const uint8_t *__restrict__ idx, const f
         sv[v] = ((se + so[v]) - Eb) + 2.0f * d[v];
         sp[v] = VPL * lane + v;
     }
-    tf_finish<VPL>(sv, sp, keep, KC, scratch, L, 1, b, N, g, idx_final);
+    tf_finish<VPL, CT>(sv, sp, keep, KC, scratch, L, 1, b, N, g, idx_final);
 }
 
 // ------------------------------------------------------------ level-1 tables
@@ -459,13 +481,14 @@ k_tf_pair0(const float *__restrict__ G, const uint8_t *__restrict__ idx, const f
 // plus the border).  The sets come from a 16-lane OR-reduction of position bits, the compact rank of a position is
 // a popcount, and the four compact leaf tables live in LDS.  Every entry is computed by the same formula as in the
 // full table, so the results are identical.
-template <int KCH, int KC>
-__device__ __forceinline__ void tf_table1(const float *__restrict__ G, const uint8_t *__restrict__ idx, const TfLists &L,
+template <int KCH, int KC, typename CT = uint8_t>
+__device__ __forceinline__ void tf_table1(const float *__restrict__ G, const CT *__restrict__ idx, const TfLists &L,
                                           long b, int N, int K, int X, int Y, float *leaf /* LDS [4][KCH*KCH + 64] */,
                                           float (&t)[KC * KC / 64]) {
     constexpr int VPLH = KCH * KCH / 64, VPL = KC * KC / 64, MH = KCH * KCH;
     const int lane = lane_id();
-    const uint8_t *id = idx + b * N;
+    const CT *id = idx + b * N;
+    const CT *ent = reinterpret_cast<const CT *>(L.ent);
     const int G1 = N >> 1;
     const uint8_t *px = L.pos[1] + ((b * G1 + X) * KC) * 2, *py = L.pos[1] + ((b * G1 + Y) * KC) * 2;
     if constexpr (KCH == 16 && KC == 16) {
@@ -474,8 +497,8 @@ __device__ __forceinline__ void tf_table1(const float *__restrict__ G, const uin
         // + 33 border values
         constexpr int RS = KCH + 1, BO = KCH * RS;
         constexpr int LS = BO + 36;                           // (33 border values; 5,056 bytes per wave in all: 32 waves per CU)
-        uint8_t *cent = reinterpret_cast<uint8_t *>(leaf + 4 * LS);   // [4][16] compact list -> codebook entry
-        uint8_t *crank = cent + 64;                                   // [4][16] candidate -> compact rank of its leaf
+        CT *cent = reinterpret_cast<CT *>(leaf + 4 * LS);             // [4][16] compact list -> codebook entry
+        uint8_t *crank = reinterpret_cast<uint8_t *>(cent + 64);      // [4][16] candidate -> compact rank of its leaf
         const int NK = N * K;
         const int nksh = __builtin_ctz((unsigned)NK);
         // quarter w of the wave = one of the four halves' lists: 0, 1 = the halves of X, 2, 3 = those of Y
@@ -485,7 +508,7 @@ __device__ __forceinline__ void tf_table1(const float *__restrict__ G, const uin
         // compiler they were loaded one at a time, each behind a full wait, and the four border reads below (which only
         // need the current entries of their codebooks) were serialised behind them -- eleven round trips instead of three
         int mypos = (w < 2 ? px : py)[2 * c + (w & 1)];
-        int myent = L.ent[(b * N + cb) * KCH + c];                  // entry at level-0 position c of that codebook
+        int myent = ent[(b * N + cb) * KCH + c];                    // entry at level-0 position c of that codebook
         int oldv = id[cb];                                          // current entry of this quarter's codebook
         asm volatile("" : "+v"(mypos), "+v"(myent), "+v"(oldv));
         int oldq[4];                                                // current entries of codebooks 2X, 2X+1, 2Y, 2Y+1
@@ -497,7 +520,7 @@ __device__ __forceinline__ void tf_table1(const float *__restrict__ G, const uin
         m |= (uint32_t)dpp_i<0x124>((int)m);
         m |= (uint32_t)dpp_i<0x128>((int)m);
         crank[lane] = (uint8_t)__popc(m & ((1u << mypos) - 1u));
-        if ((m >> c) & 1u) cent[w * 16 + __popc(m & ((1u << c) - 1u))] = (uint8_t)myent;
+        if ((m >> c) & 1u) cent[w * 16 + __popc(m & ((1u << c) - 1u))] = (CT)myent;
         uint32_t mq[4];
         mq[0] = (uint32_t)__builtin_amdgcn_readlane((int)m, 0);
         mq[1] = (uint32_t)__builtin_amdgcn_readlane((int)m, 16);
@@ -582,15 +605,15 @@ __device__ __forceinline__ void tf_table1(const float *__restrict__ G, const uin
         int e_row[2], e_col[2], e_brd[4], oldq[4];
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
-            e_row[a] = L.ent[(b * N + cbk[a]) * KCH + i];
-            e_col[a] = L.ent[(b * N + cbk[2 + a]) * KCH + j];
+            e_row[a] = ent[(b * N + cbk[a]) * KCH + i];
+            e_col[a] = ent[(b * N + cbk[2 + a]) * KCH + j];
         }
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {
             oldq[q4] = id[cbk[q4]];
             // border entry of this lane in a table whose row codebook is cbk[a] / column codebook cbk[2 + c]: lanes [0, KCH)
             // need ent of the ROW codebook at position lane, lanes [KCH, 2 KCH) ent of the COLUMN codebook at lane - KCH
-            e_brd[q4] = L.ent[(b * N + cbk[q4]) * KCH + (q4 < 2 ? (bl < KCH ? bl : 0) : (bl >= KCH && bl < 2 * KCH ? bl - KCH : 0))];
+            e_brd[q4] = ent[(b * N + cbk[q4]) * KCH + (q4 < 2 ? (bl < KCH ? bl : 0) : (bl >= KCH && bl < 2 * KCH ? bl - KCH : 0))];
         }
         asm volatile("" : "+v"(e_row[0]), "+v"(e_row[1]), "+v"(e_col[0]), "+v"(e_col[1]));
         asm volatile("" : "+v"(e_brd[0]), "+v"(e_brd[1]), "+v"(e_brd[2]), "+v"(e_brd[3]));
@@ -627,7 +650,7 @@ __device__ __forceinline__ void tf_table1(const float *__restrict__ G, const uin
             for (int c = 0; c < 2; ++c) {
                 const int n = 2 * X + a, m = 2 * Y + c;
                 float d[VPLH];
-                tf_leaf<KCH>(G, N * K, K, n, m, L.ent + (b * N + n) * KCH, L.ent + (b * N + m) * KCH, id[n], id[m], d);
+                tf_leaf<KCH, CT>(G, N * K, K, n, m, ent + (b * N + n) * KCH, ent + (b * N + m) * KCH, id[n], id[m], d);
                 float *dst = leaf + (a * 2 + c) * MH + VPLH * lane;
 #pragma unroll
                 for (int v = 0; v < VPLH; ++v) dst[v] = d[v];
@@ -644,17 +667,17 @@ __device__ __forceinline__ void tf_table1(const float *__restrict__ G, const uin
     }
 }
 
-constexpr int tf_leaf_lds_floats(int KCH) { return 4 * (KCH * (KCH + 1) + 36) + 32; }
+constexpr int tf_leaf_lds_floats(int KCH, int code_bytes = 1) { return 4 * (KCH * (KCH + 1) + 36) + 16 + 16 * code_bytes; }
 
 // combine of level 1: siblings X = 2g, Y = 2g + 1 (pairs of codebooks).  One wave per (b, g).
-template <int KCH, int KC>
-__device__ __forceinline__ void tf_pair1_body(unsigned bid, float *leaf, const float *__restrict__ G, const uint8_t *__restrict__ idx,
+template <int KCH, int KC, typename CT = uint8_t>
+__device__ __forceinline__ void tf_pair1_body(unsigned bid, float *leaf, const float *__restrict__ G, const CT *__restrict__ idx,
                                               const float *__restrict__ E, const TfLists &L, long B, int N, int K, int keep,
-                                              uint8_t *__restrict__ idx_final, const int *__restrict__ nact) {
+                                              CT *__restrict__ idx_final, const int *__restrict__ nact) {
     constexpr int VPL = KC * KC / 64;
     // the selection's scratch reuses the leaf tables' LDS (dead once the level-1 table sits in registers): 5.6 instead of
     // 7.3 KB per single-wave workgroup, i.e. 29 instead of 22 waves per CU
-    static_assert(tf_leaf_lds_floats(KCH) * 4 >= kSelectLdsU64 * 8, "");
+    static_assert(tf_leaf_lds_floats(KCH, sizeof(CT)) * 4 >= kSelectLdsU64 * 8, "");
     u64 *scratch = reinterpret_cast<u64 *>(leaf);
     if (nact) B = *nact;
     const int Gout = N >> 2;
@@ -670,7 +693,7 @@ __device__ __forceinline__ void tf_pair1_body(unsigned bid, float *leaf, const f
 #pragma unroll
     for (int v = 0; v < VPL; ++v) so[v] = L.S[1][(b * G1 + Y) * KC + j0 + v];
     float t[VPL];
-    tf_table1<KCH, KC>(G, idx, L, b, N, K, X, Y, leaf, t);
+    tf_table1<KCH, KC, CT>(G, idx, L, b, N, K, X, Y, leaf, t);
     float sv[VPL];
     int sp[VPL];
 #pragma unroll
@@ -679,22 +702,22 @@ __device__ __forceinline__ void tf_pair1_body(unsigned bid, float *leaf, const f
         sp[v] = VPL * lane + v;
     }
     wave_lds_fence();                                   // the table reads are done before the selection writes there
-    tf_finish<VPL>(sv, sp, keep, KC, scratch, L, 2, b, N, g, idx_final);
+    tf_finish<VPL, CT>(sv, sp, keep, KC, scratch, L, 2, b, N, g, idx_final);
 }
 
-template <int KCH, int KC>
+template <int KCH, int KC, typename CT = uint8_t>
 __global__ void __launch_bounds__(64)
-k_tf_pair1(const float *__restrict__ G, const uint8_t *__restrict__ idx, const float *__restrict__ E, TfLists L, long B,
-           int N, int K, int keep, uint8_t *__restrict__ idx_final, const int *__restrict__ nact) {
-    __shared__ __attribute__((aligned(16))) float leaf[tf_leaf_lds_floats(KCH)];
-    tf_pair1_body<KCH, KC>(blockIdx.x, leaf, G, idx, E, L, B, N, K, keep, idx_final, nact);
+k_tf_pair1(const float *__restrict__ G, const CT *__restrict__ idx, const float *__restrict__ E, TfLists L, long B,
+           int N, int K, int keep, CT *__restrict__ idx_final, const int *__restrict__ nact) {
+    __shared__ __attribute__((aligned(16))) float leaf[tf_leaf_lds_floats(KCH, sizeof(CT))];
+    tf_pair1_body<KCH, KC, CT>(blockIdx.x, leaf, G, idx, E, L, B, N, K, keep, idx_final, nact);
 }
 
 // T_1 of COUSIN pairs under the siblings of a higher level -> tabs[b][t][KC*KC].  One wave per (b, t); workgroup id
 // mod ntab = t, so an XCD reads the leaf blocks of its own tables only.  Under sibling pair g each side has `per`
 // level-1 groups: t = (g * per + a) * per + c  ->  X = 2 g per + a,  Y = (2 g + 1) per + c.
-template <int KCH, int KC>
-__device__ __forceinline__ void tf_table1_body(unsigned bid, float *leaf, const float *__restrict__ G, const uint8_t *__restrict__ idx,
+template <int KCH, int KC, typename CT = uint8_t>
+__device__ __forceinline__ void tf_table1_body(unsigned bid, float *leaf, const float *__restrict__ G, const CT *__restrict__ idx,
                                                const TfLists &L, long B, int N, int K, int ntab, int per, float *__restrict__ tabs,
                                                const int *__restrict__ nact) {
     constexpr int VPL = KC * KC / 64;
@@ -707,7 +730,7 @@ __device__ __forceinline__ void tf_table1_body(unsigned bid, float *leaf, const 
     const int c = t & (per - 1), a = (t >> psh) & (per - 1), g = t >> (2 * psh);
     const int X = 2 * g * per + a, Y = (2 * g + 1) * per + c;
     float tv[VPL];
-    tf_table1<KCH, KC>(G, idx, L, b, N, K, X, Y, leaf, tv);
+    tf_table1<KCH, KC, CT>(G, idx, L, b, N, K, X, Y, leaf, tv);
     float *dst = tabs + ((size_t)(b * ntab + t) * (KC * KC) + VPL * lane);
     if constexpr (VPL == 4) {
         __builtin_nontemporal_store((f32x4){tv[0], tv[1], tv[2], tv[3]}, reinterpret_cast<f32x4 *>(dst));
@@ -717,26 +740,26 @@ __device__ __forceinline__ void tf_table1_body(unsigned bid, float *leaf, const 
     }
 }
 
-template <int KCH, int KC>
+template <int KCH, int KC, typename CT = uint8_t>
 __global__ void __launch_bounds__(64)
-k_tf_table1(const float *__restrict__ G, const uint8_t *__restrict__ idx, TfLists L, long B, int N, int K, int ntab,
+k_tf_table1(const float *__restrict__ G, const CT *__restrict__ idx, TfLists L, long B, int N, int K, int ntab,
             int per, float *__restrict__ tabs, const int *__restrict__ nact) {
-    __shared__ __attribute__((aligned(16))) float leaf[tf_leaf_lds_floats(KCH)];
-    tf_table1_body<KCH, KC>(blockIdx.x, leaf, G, idx, L, B, N, K, ntab, per, tabs, nact);
+    __shared__ __attribute__((aligned(16))) float leaf[tf_leaf_lds_floats(KCH, sizeof(CT))];
+    tf_table1_body<KCH, KC, CT>(blockIdx.x, leaf, G, idx, L, B, N, K, ntab, per, tabs, nact);
 }
 
 // The sibling combines of level 1 and the cousin tables the level-2 combine needs, in ONE launch: both read the level-1 lists
 // and nothing of each other; the workgroup-to-XCD mapping of both kinds is what it is in their own launches (the pair
 // blocks are a multiple of 8).
-template <int KCH, int KC>
+template <int KCH, int KC, typename CT = uint8_t>
 __global__ void __launch_bounds__(64)
-k_tf_level1(const float *__restrict__ G, const uint8_t *__restrict__ idx, const float *__restrict__ E, TfLists L, long B, int N,
+k_tf_level1(const float *__restrict__ G, const CT *__restrict__ idx, const float *__restrict__ E, TfLists L, long B, int N,
             int K, int keep, int ntab, int per, float *__restrict__ tabs, const int *__restrict__ nact, unsigned pair_blocks,
             unsigned tab_blocks, int ntab2, int per2, float *__restrict__ tabs2) {
-    __shared__ __attribute__((aligned(16))) float leaf[tf_leaf_lds_floats(KCH)];
-    if (blockIdx.x < pair_blocks) tf_pair1_body<KCH, KC>(blockIdx.x, leaf, G, idx, E, L, B, N, K, keep, nullptr, nact);
-    else if (blockIdx.x < pair_blocks + tab_blocks) tf_table1_body<KCH, KC>(blockIdx.x - pair_blocks, leaf, G, idx, L, B, N, K, ntab, per, tabs, nact);
-    else tf_table1_body<KCH, KC>(blockIdx.x - pair_blocks - tab_blocks, leaf, G, idx, L, B, N, K, ntab2, per2, tabs2, nact);   // (16 codebooks: the tables of level 3 as well)
+    __shared__ __attribute__((aligned(16))) float leaf[tf_leaf_lds_floats(KCH, sizeof(CT))];
+    if (blockIdx.x < pair_blocks) tf_pair1_body<KCH, KC, CT>(blockIdx.x, leaf, G, idx, E, L, B, N, K, keep, nullptr, nact);
+    else if (blockIdx.x < pair_blocks + tab_blocks) tf_table1_body<KCH, KC, CT>(blockIdx.x - pair_blocks, leaf, G, idx, L, B, N, K, ntab, per, tabs, nact);
+    else tf_table1_body<KCH, KC, CT>(blockIdx.x - pair_blocks - tab_blocks, leaf, G, idx, L, B, N, K, ntab2, per2, tabs2, nact);   // (16 codebooks: the tables of level 3 as well)
 }
 
 // copy COUNT tables of KH x KH floats each from global memory (rows of KH) to LDS (rows of KH + 1: the odd row stride keeps the
@@ -839,10 +862,10 @@ k_tf_up(TfLists L, long B, int N, int u, int ntab, int per, const float *__restr
 // LAST: the combine that leaves one group (idx_final != nullptr, keep == 1) as an instantiation of its own -- the winner is a
 // running arg-min over the scores, no score array and no selection: 86 registers -> the 8 waves per SIMD of the other pass kernels
 // (k_tf_comb<16,32> is the last launch of every pass of 8 codebooks).
-template <int KH, int KC, bool LAST>
+template <int KH, int KC, bool LAST, typename CT = uint8_t>
 __global__ void __launch_bounds__(64)
 k_tf_comb(const float *__restrict__ E, TfLists L, long B, int N, int v, int keep, const float *__restrict__ tabs,
-          uint8_t *__restrict__ idx_final, const int *__restrict__ nact) {
+          CT *__restrict__ idx_final, const int *__restrict__ nact) {
     constexpr int MH = KH * KH, RS = KH + 1, TS = tf_tab_stride<KH>();
     constexpr int VPL = (KC * KC / 64 <= 16) ? KC * KC / 64 : 16;
     constexpr int CHUNKS = KC * KC / (64 * VPL);
@@ -878,7 +901,7 @@ k_tf_comb(const float *__restrict__ E, TfLists L, long B, int N, int v, int keep
             sp[u] = VPL * lane + u;
         }
         wave_lds_fence();
-        tf_finish<VPL>(sv, sp, keep, KC, scratch, L, v + 1, b, N, h, idx_final);
+        tf_finish<VPL, CT>(sv, sp, keep, KC, scratch, L, v + 1, b, N, h, idx_final);
     } else if (!LAST) {
         // 4,096 pairs that are NOT the last combine (64 codebooks of more than 16 entries: 64 of them go on): the 64 smallest
         // of every chunk of 1,024, then the 64 smallest of those 4 x 64 -- the same set and order as one selection over
@@ -910,7 +933,7 @@ k_tf_comb(const float *__restrict__ E, TfLists L, long B, int N, int v, int keep
             for (int q = 0; q < 4; ++q)
                 if (q == c) { cv[q] = got ? ov : INFINITY; cp[q] = got ? op : kBigPos; }
         }
-        tf_finish<4>(cv, cp, keep, KC, sel2, L, v + 1, b, N, h, nullptr);
+        tf_finish<4, CT>(cv, cp, keep, KC, sel2, L, v + 1, b, N, h, nullptr);
     } else {
         float bv = INFINITY;
         int bp = kBigPos;
@@ -938,10 +961,10 @@ k_tf_comb(const float *__restrict__ E, TfLists L, long B, int N, int v, int keep
 // waves per vector: the tables take 33 KB of LDS (16 + 16 KB at K >= 32), which leaves room for four workgroups per CU --
 // with a single wave each (the first version) a CU held four waves and the kernel took 1.0 ms at 65,536 vectors.  Wave w
 // loads four of the level-1 tables, builds level-2 table w and scores a quarter of the candidate pairs.
-template <int KC1, int KC2, int KC3>
+template <int KC1, int KC2, int KC3, typename CT = uint8_t>
 __global__ void __launch_bounds__(256)
-k_tf_comb3(const uint8_t *__restrict__ idx, const float *__restrict__ E, TfLists L, long B, int N,
-           const float *__restrict__ tabs, uint8_t *__restrict__ idx_final, const int *__restrict__ nact) {
+k_tf_comb3(const CT *__restrict__ idx, const float *__restrict__ E, TfLists L, long B, int N,
+           const float *__restrict__ tabs, CT *__restrict__ idx_final, const int *__restrict__ nact) {
     constexpr int VPL2 = KC2 * KC2 / 64, M1 = KC1 * KC1;
     constexpr int PW = KC3 * KC3 / 4, VPLW = PW / 64;          // candidate pairs per wave, per lane
     constexpr int RS1 = KC1 + 1, TS1 = tf_tab_stride<KC1>(), RS2 = KC2 + 1, TS2 = KC2 * RS2;      // rows of an odd length: tf_load_tables

@@ -244,10 +244,11 @@ class Quantizer(nn.Module):
         return blob
 
     def _check_domain(self):
-        assert 16 <= self.codebook_size <= 256, (
-            "the index search needs 16 <= codebook_size <= 256 (the reference itself fails below 16, "
-            "quantization.py:506, and needs <= 256 for byte codes, :271)")
+        assert 16 <= self.codebook_size <= 1024, (
+            "the index search needs 16 <= codebook_size <= 1024 (the reference itself fails below 16, "
+            "quantization.py:506; byte codes need <= 256, :271: larger codebooks encode with as_bytes=False)")
         assert self.num_codebooks <= 64, "num_codebooks <= 64 (QuantizerTrainer produces at most 64: quantization.py:614)"
+        assert self.num_codebooks * self.codebook_size <= 16384, "num_codebooks * codebook_size <= 16384 (the Gram matrix: 1 GB)"
         assert self.dim <= 16384, "dim <= 16384 (the i32 accumulators of the fixed-point products, include/mcq.h)"
 
     def _workspace(self, B: int, dev) -> Tensor:
@@ -434,7 +435,7 @@ class Quantizer(nn.Module):
             # debugging aid (synchronises): the kernels mask digits with K - 1 where the reference's gather would
             # raise on an out-of-range index (quantization.py:142)
             assert int(flat.min()) >= 0 and int(flat.max()) < K ** (N // per_row), "codes outside [0, codebook_size)"
-        if flat.dtype == torch.int64 and per_row == N and N in (4, 8, 16) and B >= 16384:
+        if flat.dtype == torch.int64 and per_row == N and N in (4, 8, 16) and B >= 16384 and K <= 256:
             # unpacked int64 indexes of a large batch: as bytes they take the block-staged LDS-resident kernel (the kernels
             # mask a digit with K - 1 either way, and K <= 256: the low byte carries the same digit)
             flat = flat.to(torch.uint8)

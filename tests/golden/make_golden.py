@@ -162,7 +162,7 @@ def encode_cases(q, sd, x, iters_list, out, reorder=False):
         qp, xp = permuted_reference(sd, x, D, K, N)
     for it in iters_list:
         codes = ref_encode(q, x, it, as_bytes=False)
-        out[f"codes_it{it}"] = codes.astype(np.uint8)
+        out[f"codes_it{it}"] = codes.astype(np.uint8 if int(out["K"]) <= 256 else np.uint16)
         if reorder:
             cp = ref_encode(qp, xp, it, as_bytes=False)
             out[f"reorder_noise_it{it}"] = int((cp != codes).any(axis=1).sum())
@@ -171,7 +171,8 @@ def encode_cases(q, sd, x, iters_list, out, reorder=False):
         out[f"margin_it{it}"] = margin.astype(np.float32)
         nm = int((c64 != codes).any(axis=1).sum())
         print(f"   iters={it}: fp64-vs-fp32 differing vectors {nm}/{len(x)}; margin<2e-6: {(margin < 2e-6).sum()}")
-    out["bytes_it%d" % iters_list[-1]] = ref_encode(q, x, iters_list[-1], as_bytes=True)
+    if int(out["K"]) <= 256:      # (encode(as_bytes=True) asserts codebook_size <= 256, quantization.py:271)
+        out["bytes_it%d" % iters_list[-1]] = ref_encode(q, x, iters_list[-1], as_bytes=True)
 
 
 def decode_cases(q, codes, out):
@@ -258,6 +259,14 @@ def main(which):
         # the reference's Quantizer accepts; lists of 64 at the two top levels
         gen_synth("synth_d24_k32_n64", 24, 32, 64, 96, 27, 28, [0, 1, 2])
         gen_synth("synth_d16_k256_n64", 16, 256, 64, 48, 29, 30, [0, 1, 2])
+    if which in ("all", "k512"):
+        # codebooks of 512 and 1,024 entries: Quantizer(codebook_size=...) used with as_bytes=False (quantization.py:35 only
+        # asks for a power of two; the trainer never produces them).  One fixture per shape of the combine tree: 1, 2, 4, 8, 16 codebooks
+        gen_synth("k512_d24_n1", 24, 512, 1, 256, 41, 42, [0, 1, 2])
+        gen_synth("k1024_d24_n2", 24, 1024, 2, 256, 43, 44, [0, 1, 3])
+        gen_synth("k512_d32_n4", 32, 512, 4, 256, 45, 46, [0, 1, 3], x_kind="make_x")
+        gen_synth("k1024_d40_n8", 40, 1024, 8, 256, 47, 48, [0, 1, 5])
+        gen_synth("k512_d16_n16", 16, 512, 16, 128, 49, 50, [0, 1, 2])
     if which in ("all", "stress"):
         # Round 4 ("what's weak" 1): states TRAINED BY THE REFERENCE on frames that are not zero-mean unit-scale
         # Gaussians -- a common offset, one dominant feature, heavy tails -- where the table form's cancellation terms are

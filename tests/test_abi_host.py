@@ -43,7 +43,9 @@ def test_argument_validation_without_launch():
     L = m.lib()
     # unsupported domain and bad arguments are rejected before anything touches the device
     assert L.mcq_encode(None, 4, None, 1.0, 8, 8, 64, 1, None, None, None, 0, None) == m.MCQ_EUNSUPPORTED
-    assert L.mcq_encode(None, 4, None, 1.0, 8, 512, 64, 1, None, None, None, 0, None) == m.MCQ_EUNSUPPORTED
+    assert L.mcq_encode(None, 4, None, 1.0, 8, 2048, 64, 1, None, None, None, 0, None) == m.MCQ_EUNSUPPORTED
+    assert L.mcq_encode(None, 4, None, 1.0, 32, 1024, 64, 1, None, None, None, 0, None) == m.MCQ_EUNSUPPORTED    # Gram matrix past 16,384 rows
+    assert L.mcq_encode(None, 4, None, 1.0, 8, 512, 64, 1, None, None, None, 0, None) == m.MCQ_EINVAL            # supported shape, no output array
     assert L.mcq_encode(None, 4, None, 1.0, 3, 256, 64, 1, None, None, None, 0, None) == m.MCQ_EINVAL
     assert L.mcq_encode(None, -1, None, 1.0, 8, 256, 64, 1, None, None, None, 0, None) == m.MCQ_EINVAL
     assert L.mcq_decode(None, 2, 8, 4, None, 8, 256, 64, None, None) == m.MCQ_EINVAL

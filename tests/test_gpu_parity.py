@@ -59,15 +59,22 @@ def test_bytes_and_decode(name):
     o = oracle_of(fx["state"])
     it = fx["iters"][-1]
     x = torch.from_numpy(fx["x"]).cuda()
-    b = q.encode(x, it)  # as_bytes=True
-    assert b.dtype == torch.uint8
-    assert np.array_equal(b.cpu().numpy(), o.encode(fx["x"], it))
-    ref_bytes = torch.from_numpy(fx[f"bytes_it{it}"]).cuda()
     ref_codes = torch.from_numpy(fx[f"codes_it{it}"].astype(np.int64)).cuda()
+    if fx["K"] <= 256:
+        b = q.encode(x, it)  # as_bytes=True
+        assert b.dtype == torch.uint8
+        assert np.array_equal(b.cpu().numpy(), o.encode(fx["x"], it))
+        ref_bytes_np = fx[f"bytes_it{it}"]
+        ref_bytes = torch.from_numpy(ref_bytes_np).cuda()
+    else:
+        # codebooks of 512 / 1,024 entries: no byte form (quantization.py:271 asserts); the indexes are decoded as they are
+        with pytest.raises(AssertionError):
+            q.encode(x, it)
+        ref_bytes_np, ref_bytes = fx[f"codes_it{it}"], ref_codes
     y = q.decode(ref_bytes)
     assert y.dtype == torch.float32 and tuple(y.shape) == (fx["B"], fx["D"])
     y = y.cpu().numpy()
-    assert np.array_equal(y, o.decode(fx[f"bytes_it{it}"]))            # bit-exact vs the oracle
+    assert np.array_equal(y, o.decode(ref_bytes_np))                   # bit-exact vs the oracle
     assert np.array_equal(y, q.decode(ref_codes).cpu().numpy())        # packed == unpacked int64
     head = fx["decode_head"]
     scale = np.abs(head).max()
@@ -665,3 +672,60 @@ def test_full_size_config_b_with_a_reference_trained_state_and_shifted_frames():
     # the shifted half is far from what the quantizer was trained on: refinement must still not lose against the initial guess
     y5, y0 = q.decode(codes), q.decode(q.encode(xd, 0))
     assert float(((y5 - xd) ** 2).sum()) < float(((y0 - xd) ** 2).sum())
+
+
+# ---------------------------------------------------------------- codebooks of 512 / 1,024 entries
+# Quantizer(codebook_size=512 / 1024) is outside what QuantizerTrainer produces but inside what the reference's Quantizer accepts
+# (quantization.py:35 asks for a power of two; only the byte form needs <= 256, :271).  Entries are held in two bytes on that path
+# (mcq_tf_kernels.h, CT); the fixtures k512_* / k1024_* above pin it to the reference, these cases to the oracle at more shapes.
+@pytest.mark.parametrize("D,K,N,B,it", [(100, 512, 8, 300, 3), (64, 1024, 4, 257, 2), (16, 512, 32, 64, 1), (33, 1024, 16, 96, 2),
+                                         (20, 1024, 1, 130, 1), (512, 512, 2, 64, 5)])
+def test_codebooks_of_512_and_1024_entries_vs_oracle(D, K, N, B, it):
+    sd = gen.synthetic_state(1200 + D + N, D, K, N)
+    q = load_quantizer(sd, D, K, N)
+    o = oracle_of(sd)
+    x = gen.make_gaussian(7201 + D, B, D)
+    xd = torch.from_numpy(x).cuda()
+    got = q.encode(xd, it, as_bytes=False)
+    assert got.dtype == torch.int64
+    want = o.compute_indexes(x, it)
+    assert want.dtype == np.uint16 and int(want.max()) > 255
+    assert np.array_equal(got.cpu().numpy(), want)
+    assert np.array_equal(q.logits_kernel(xd).cpu().numpy(), o.logits(x))
+    assert np.array_equal(q.decode(got).cpu().numpy(), o.decode(want))
+    with pytest.raises(AssertionError):
+        q.encode(xd, it)                                    # as_bytes=True: quantization.py:271
+    # the search from caller-supplied indexes, and fixed-point skipping
+    start = np.random.RandomState(5).randint(0, K, size=(B, N)).astype(np.int64)
+    r1 = q._refine_indexes(xd, torch.from_numpy(start).cuda()).cpu().numpy()
+    assert np.array_equal(r1[:8], np.stack([o.refine_trace(x[i], start[i])["idx"] for i in range(8)]))
+    q.skip_fixed_points = True
+    assert torch.equal(q.encode(xd, max(it, 2), as_bytes=False), torch.from_numpy(o.compute_indexes(x, max(it, 2)).astype(np.int64)).cuda())
+
+
+def test_wide_codebooks_in_chunks_and_the_product_of_two_32_entry_codebooks():
+    D, K, N, B = 64, 512, 8, 70000                          # past the default chunk of 65,536 vectors
+    sd = gen.synthetic_state(1300, D, K, N)
+    q = load_quantizer(sd, D, K, N)
+    o = oracle_of(sd)
+    x = gen.make_gaussian(1301, B, D)
+    xd = torch.from_numpy(x).cuda()
+    got = q.encode(xd, 2, as_bytes=False)
+    rows = np.concatenate([np.arange(65536 - 40, 65536 + 40), np.random.RandomState(2).choice(B, 80, replace=False)])
+    want = o.compute_indexes(x[rows], 2)
+    assert np.array_equal(got.cpu().numpy()[rows], want)
+    assert torch.equal(got[B - 999:], q.encode(xd[B - 999:], 2, as_bytes=False))
+    y = q.decode(got)                                        # 70,000 rows of int64 indexes
+    assert np.array_equal(y.cpu().numpy()[rows], o.decode(want))
+    # get_product_quantizer (:81-112) of 4 x 32 gives 2 x 1,024: same reconstruction for paired indexes, and it encodes
+    sd2 = gen.synthetic_state(1302, 40, 32, 4)
+    q2 = load_quantizer(sd2, 40, 32, 4)
+    p = q2.get_product_quantizer()
+    assert (p.codebook_size, p.num_codebooks) == (1024, 2)
+    x2 = gen.make_gaussian(1303, 200, 40)
+    i2 = q2.encode(torch.from_numpy(x2).cuda(), 2, as_bytes=False)
+    paired = torch.stack([i2[:, 0] * 32 + i2[:, 1], i2[:, 2] * 32 + i2[:, 3]], dim=1)
+    assert torch.allclose(p.decode(paired), q2.decode(i2), rtol=0, atol=1e-5)
+    po = OracleQuantizer(p.centers.detach().cpu().numpy(), float(p.centers_scale), p.to_logits.weight.detach().cpu().numpy(),
+                         p.to_logits.bias.detach().cpu().numpy(), float(p.logits_scale))
+    assert np.array_equal(p.encode(torch.from_numpy(x2).cuda(), 3, as_bytes=False).cpu().numpy(), po.compute_indexes(x2, 3))
