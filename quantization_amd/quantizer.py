@@ -473,13 +473,14 @@ class Quantizer(nn.Module):
         refinement, reconstruction, softmax statistics) and a hand-derived backward (_LossSumsFn)."""
         B = x.shape[0]
         N, K = self.num_codebooks, self.codebook_size
-        if x.is_cuda and not x.requires_grad and B > 0:
+        if x.is_cuda and not x.requires_grad and B > 0 and K <= 256:      # (the fused kernels: what QuantizerTrainer runs)
             self._check_domain()
             blob = self._prepared()          # here, not inside the Function: autograd mode decides the flavour
             return _LossSumsFn.apply(self, x, int(refine_indexes_iters), blob, self._lscale_exp, self._scale_flags,
                                      self.centers, self.centers_scale, self.to_logits.weight, self.to_logits.bias,
                                      self.logits_scale)[:5]
-        # the same sums with the reference's own torch op sequence (x that requires grad; CPU test harness)
+        # the same sums with the reference's own torch op sequence (x that requires grad; codebooks of more than 256 entries:
+        # the index search and decode are the HIP kernels, the rest torch ops; the CPU test harness)
         indexes = self._compute_indexes(x, refine_indexes_iters)
         x_approx = self.decode(indexes)
         num = ((x_approx - x) ** 2).sum()

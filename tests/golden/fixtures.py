@@ -16,7 +16,7 @@ NEAR_TIE = 2e-6
 def names(prefix=""):
     """encode/decode fixtures (the trainer trajectory fixture has its own loader)"""
     return sorted(n for n in (os.path.basename(p)[:-4] for p in glob.glob(os.path.join(HERE, prefix + "*.npz")))
-                  if not n.startswith(("trainer_", "trace_", "jcl_", "downstream_")))
+                  if not n.startswith(("trainer_", "trace_", "jcl_", "downstream_", "loss_")))
 
 
 def trace_names():

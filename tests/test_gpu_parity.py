@@ -729,3 +729,25 @@ def test_wide_codebooks_in_chunks_and_the_product_of_two_32_entry_codebooks():
     po = OracleQuantizer(p.centers.detach().cpu().numpy(), float(p.centers_scale), p.to_logits.weight.detach().cpu().numpy(),
                          p.to_logits.bias.detach().cpu().numpy(), float(p.logits_scale))
     assert np.array_equal(p.encode(torch.from_numpy(x2).cuda(), 3, as_bytes=False).cpu().numpy(), po.compute_indexes(x2, 3))
+
+
+def test_compute_loss_of_a_512_entry_quantizer_follows_the_reference():
+    """compute_loss (:184-242) outside the trainer's shapes: 4 x 512.  The fused loss kernels stop at 256 entries; the module then
+    forms the same sums from its HIP index search / decode and torch ops.  Losses and gradients against the reference's own
+    (tests/golden/make_golden_loss_wide.py)."""
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "loss_k512.npz"))
+    D, K, N, B = (int(z[k]) for k in "DKNB")
+    sd = gen.synthetic_state(int(z["state_seed"]), D, K, N)
+    q = load_quantizer(sd, D, K, N)
+    x = torch.from_numpy(gen.make_x(int(z["x_seed"]), B, D)).cuda()
+    for iters in (0, 2):
+        q.zero_grad()
+        with torch.enable_grad():           # (this module's tests run under no_grad)
+            losses = q.compute_loss(x, iters)
+            (losses[0] + 0.3 * losses[1] + 0.2 * losses[2] + 0.1 * losses[3]).backward()
+        got = np.array([float(v) for v in losses])
+        assert np.allclose(got, z[f"losses_it{iters}"], rtol=1e-4, atol=1e-6), (iters, got, z[f"losses_it{iters}"])
+        for name, p in q.named_parameters():
+            want = z[f"grad_it{iters}.{name}"]
+            g = p.grad.detach().cpu().numpy()
+            assert np.linalg.norm(g - want) <= 1e-3 * np.linalg.norm(want) + 1e-7, (iters, name)
