@@ -66,7 +66,7 @@ def test_rejected_arguments_get_the_same_code():
         assert L.mcq_prepare(*a) == H.mcq_prepare_host(*a), a
 
 
-@pytest.mark.parametrize("name", ["trained_d64_b8_p2", "trained_d64_b8_p1", "synth_d30_k32_n4"])
+@pytest.mark.parametrize("name", ["trained_d64_b8_p2", "trained_d64_b8_p1", "synth_d30_k32_n4", "k512_d32_n4"])
 def test_twins_reproduce_the_reference_fixtures(name):
     fx = fixtures.load(name)
     H = ht.lib()
@@ -82,13 +82,19 @@ def test_twins_reproduce_the_reference_fixtures(name):
     fixtures.check_codes(fx, it, idx, name)
     pack = 2 if K == 16 else 1
     by = np.zeros((B, N // pack), np.uint8)
-    assert H.mcq_encode_host(ht.ptr(x), B, ht.ptr(blob), ls, N, K, D, it, ht.ptr(by), None, ht.ptr(ws), ws.size, None) == 0
-    same = (idx == fx[f"codes_it{it}"]).all(axis=1)
-    assert np.array_equal(by[same], fx[f"bytes_it{it}"][same])
-    # decode of the reference's own bytes: head rows to 1e-5, every row by checksum
     out = np.zeros((B, D), np.float32)
-    ref_bytes = np.ascontiguousarray(fx[f"bytes_it{it}"])
-    assert H.mcq_decode_host(ht.ptr(ref_bytes), 1, ref_bytes.shape[1], B, ht.ptr(blob), N, K, D, ht.ptr(out), None) == 0
+    if K <= 256:
+        assert H.mcq_encode_host(ht.ptr(x), B, ht.ptr(blob), ls, N, K, D, it, ht.ptr(by), None, ht.ptr(ws), ws.size, None) == 0
+        same = (idx == fx[f"codes_it{it}"]).all(axis=1)
+        assert np.array_equal(by[same], fx[f"bytes_it{it}"][same])
+        # decode of the reference's own bytes: head rows to 1e-5, every row by checksum
+        ref_bytes = np.ascontiguousarray(fx[f"bytes_it{it}"])
+        assert H.mcq_decode_host(ht.ptr(ref_bytes), 1, ref_bytes.shape[1], B, ht.ptr(blob), N, K, D, ht.ptr(out), None) == 0
+    else:
+        # codebooks of 512 / 1,024 entries: no byte form (rejected), int64 indexes decode
+        assert H.mcq_encode_host(ht.ptr(x), B, ht.ptr(blob), ls, N, K, D, it, ht.ptr(by), None, ht.ptr(ws), ws.size, None) == -1      # MCQ_EINVAL
+        ref_idx = np.ascontiguousarray(fx[f"codes_it{it}"].astype(np.int64))
+        assert H.mcq_decode_host(ht.ptr(ref_idx), 8, N, B, ht.ptr(blob), N, K, D, ht.ptr(out), None) == 0
     np.testing.assert_allclose(out[:16], fx["decode_head"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(out.astype(np.float64).sum(axis=1), fx["decode_rowsum"], rtol=1e-5, atol=1e-4)
     # refine_indexes twin: one pass from the 0-pass codes gives the 1-pass codes
