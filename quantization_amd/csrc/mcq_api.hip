@@ -1277,7 +1277,8 @@ int mcq_profile_encode(const float *x, long B, const void *prepared, float lscal
                        int refine_iters, void *workspace, size_t workspace_bytes, void *stream, float *ms_out,
                        int *launches_out, int cap) {
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const size_t need = (size_t)B * N;
+    const bool wide = K > 256;                // (entries of more than 256-entry codebooks leave as int64: no byte form)
+    const size_t need = (size_t)B * N * (wide ? 8 : 1);
     uint8_t *dummy = nullptr;                 // the codes of the profiled encodes (this entry point is a measurement tool: it allocates)
     if (hipMalloc(reinterpret_cast<void **>(&dummy), need ? need : 1) != hipSuccess) return MCQ_EINVAL;
     for (int i = 0; i < cap; ++i) { ms_out[i] = 0.f; if (launches_out) launches_out[i] = 0; }
@@ -1286,7 +1287,8 @@ int mcq_profile_encode(const float *x, long B, const void *prepared, float lscal
         Prof prof;
         prof.stream = st;
         prof.only = only;
-        rc = run_encode(x, B, prepared, lscale_exp, N, K, D, refine_iters, dummy, nullptr, workspace, workspace_bytes, st, &prof);
+        rc = run_encode(x, B, prepared, lscale_exp, N, K, D, refine_iters, wide ? nullptr : dummy,
+                        wide ? reinterpret_cast<int64_t *>(dummy) : nullptr, workspace, workspace_bytes, st, &prof);
         (void)hipStreamSynchronize(st);
         for (size_t i = 0; rc == 0 && i < prof.cat.size(); ++i) {
             float ms = 0.f;
