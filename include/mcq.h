@@ -212,8 +212,10 @@ int mcq_recon_fwd(const float *x, const int64_t *idx, long B, const void *prepar
 /* ---- parameter update of QuantizerTrainer.step (:708-715, :722-730) ------------------------
  * mcq_weight_grad: the autograd of Quantizer._logits (:277-279) w.r.t. to_logits: with G = dL/dlogits fp32 [B][M]
  *   (M = N*K, from mcq_loss_bwd) and the frames x fp32 [B][D]:  gW[M][D] = s * G^T x,  gb[M] = column sums of G,
- *   s = exp(10*logits_scale) read from DEVICE memory (scale_dev).  fp32 MFMA over splits of the batch whose partial
- *   tiles (workspace) are added in a fixed order.
+ *   s = exp(10*logits_scale) read from DEVICE memory (scale_dev).  Splits of the batch whose partial tiles (workspace) are
+ *   added in a fixed order; fp32 MFMA, or -- M and D multiples of 128, M >= 1024, B >= 2048 -- six bf16 piece products per
+ *   multiply-add (each operand as three bf16 pieces: fp32-grade, 1e-6 of the largest entry against the fp64 product).
+ *   Deterministic; not part of the bit-exact contract of the index search.
  * mcq_adam_step: torch.optim.Adam's update (weight decay as L2 term, no amsgrad) on one flat bucket of n floats:
  *   parameters p, gradients g, moments m / v; bias_correction1 = 1 - beta1^t and sqrt(1 - beta2^t) formed by the caller.
  * mcq_loss_head: head[4] = {sum num_part, sum den_part, sum chosen_n, batch}: mcq_loss_tail's `sums` from the

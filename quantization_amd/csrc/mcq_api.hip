@@ -1127,6 +1127,21 @@ int mcq_recon_fwd(const float *x, const int64_t *idx, long B, const void *prepar
 
 // ------------------------------------------------------------ parameter update
 namespace {
+// the bf16-piece kernel (k_wgrad_bf3: one workgroup of eight waves per CU, 128 x 128 outputs) takes the large tile-aligned
+// products -- the trainer's second phase -- with about one workgroup per CU and at least 512 rows of the batch per split
+// (dim 512, 2,048 logits, 4,096 frames: 4 splits 70.8 us per call, 8 splits 78.4, 16 splits 90.9; the fp32 kernel 113.9)
+bool wgrad_use_bf3(long B, int M, int D) {
+    static const bool f32_only = getenv("MCQ_WGRAD_F32") && atoi(getenv("MCQ_WGRAD_F32")) != 0;      // tuning hook: same sums to fp32 accuracy either way
+    return !f32_only && (M % kWbM) == 0 && (D % kWbN) == 0 && M >= 1024 && B >= 2048;
+}
+int wgrad_splits_bf3(long B, int M, int D) {
+    const long tiles = (long)(M / kWbM) * (D / kWbN);
+    long s = (256 + tiles / 2) / tiles;
+    const long max_s = B / 512;
+    s = s > max_s ? max_s : s;
+    return (int)(s < 1 ? 1 : s);
+}
+
 int wgrad_splits(long B, int M, int D) {
     const long tiles = (long)((M + kWgM - 1) / kWgM) * ((D + kWgN - 1) / kWgN);
     long s = 2048 / tiles;                 // ~8 workgroups per CU
@@ -1147,13 +1162,18 @@ int mcq_weight_grad(const float *G, const float *x, long B, int M, int D, const 
     if (!G || !x || !scale_dev || !gW || !gb || !workspace) return MCQ_EINVAL;
     if (workspace_bytes < mcq_weight_grad_workspace_bytes(B, M, D)) return MCQ_EWORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int splits = wgrad_splits(B, M, D);
+    const bool bf3 = wgrad_use_bf3(B, M, D);
+    const int splits = bf3 ? wgrad_splits_bf3(B, M, D) : wgrad_splits(B, M, D);      // (never more than the workspace was sized for)
     long rps = (B + splits - 1) / splits;
     rps = (rps + 31) / 32 * 32;
     float *part = static_cast<float *>(workspace);
     float *partb = part + (size_t)splits * M * D;
-    const unsigned grid = (unsigned)(((M + kWgM - 1) / kWgM) * ((D + kWgN - 1) / kWgN) * splits);
-    hipLaunchKernelGGL((k_wgrad_tn<16>), dim3(grid), dim3(256), 0, st, G, x, B, M, D, rps, part, partb);   // (32-row stages: 129 vs 115 us)
+    if (bf3) {
+        hipLaunchKernelGGL(k_wgrad_bf3, dim3((unsigned)((M / kWbM) * (D / kWbN) * splits)), dim3(512), 0, st, G, x, B, M, D, rps, part, partb);
+    } else {
+        const unsigned grid = (unsigned)(((M + kWgM - 1) / kWgM) * ((D + kWgN - 1) / kWgN) * splits);
+        hipLaunchKernelGGL((k_wgrad_tn<16>), dim3(grid), dim3(256), 0, st, G, x, B, M, D, rps, part, partb);   // (32-row stages: 129 vs 115 us)
+    }
     MCQ_LAUNCH_CHECK();
     const long MN = (long)M * D;
     hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((MN / 4 + 255) / 256)), dim3(256), 0, st, part, partb, splits, MN, M,

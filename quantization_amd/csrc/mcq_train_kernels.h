@@ -142,6 +142,177 @@ k_wgrad_tn(const float *__restrict__ G /*[B][M]*/, const float *__restrict__ X /
     }
 }
 
+// ------------------------------------------------- dW, db on the bf16 matrix cores
+// The same partial tiles as k_wgrad_tn for tile-aligned shapes (M and Nf multiples of 128: the trainer's second phase, where
+// this product is the largest kernel of a step).  Every fp32 operand is cut into THREE bf16 pieces by truncation (a = a0 + a1 +
+// a2 + e, |e| < 2^-24 |a|: the pieces are the top 16 bits of a, of a - a0 and of a - a0 - a1, each difference exact in fp32), and
+// the six piece products of weight >= 2^-16 run as v_mfma_f32_32x32x16_bf16 with fp32 accumulation: fp32-grade results (the
+// dropped products are below 2^-24 of a term) at a sixteenth of the fp32 MFMA's time per product.  The gradient is not part of
+// the parity contract of the index search (tests bound it against the fp64 product).
+// Layout: the MFMA wants eight consecutive b (the contraction axis) per lane, memory has b as the SLOW axis of both operands.  A
+// thread therefore loads one column: eight consecutive b of one m (or n) with eight dword loads, each coalesced across the wave
+// (lanes = consecutive columns), splits them and writes the three pieces as one ds_write_b128 per plane into [column][b] images
+// (rows of 32 + 8 bf16: the ds_read_b128 of sixteen rows then fall on 64 distinct banks).  Two LDS buffers, one barrier per
+// stage of 32 b: a wave splits and writes stage st + 1 beside its MFMAs of stage st, the loads run two stages ahead; 123 KB of
+// LDS: one workgroup of eight waves per CU.
+constexpr int kWbRow = 40;                                  // bf16 per LDS row
+constexpr int kWbStage = 32;                                // b per stage
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// eight fp32 -> three planes of eight bf16 (element i in half i % 2 of dword i / 2)
+__device__ __forceinline__ void bf3_split8(const float (&v)[8], u32x4 &p0, u32x4 &p1, u32x4 &p2) {
+    uint32_t b0[8], b1[8], b2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        b0[i] = __float_as_uint(v[i]);
+        const float r1 = v[i] - __uint_as_float(b0[i] & 0xffff0000u);
+        b1[i] = __float_as_uint(r1);
+        const float r2 = r1 - __uint_as_float(b1[i] & 0xffff0000u);
+        b2[i] = __float_as_uint(r2);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {       // the top halves of elements 2j (low) and 2j + 1 (high)
+        p0[j] = __builtin_amdgcn_perm(b0[2 * j + 1], b0[2 * j], 0x07060302u);
+        p1[j] = __builtin_amdgcn_perm(b1[2 * j + 1], b1[2 * j], 0x07060302u);
+        p2[j] = __builtin_amdgcn_perm(b2[2 * j + 1], b2[2 * j], 0x07060302u);
+    }
+}
+
+constexpr int kWbM = 128, kWbN = 128;                       // outputs per workgroup: eight waves of 64 (m) x 32 (n)
+
+__global__ void __launch_bounds__(512)
+k_wgrad_bf3(const float *__restrict__ G /*[B][M]*/, const float *__restrict__ X /*[B][Nf]*/, long B, int M, int Nf,
+            long rows_per_split, float *__restrict__ gW /*part [splits][M][Nf]*/, float *__restrict__ gb /*partb [splits][M]*/) {
+    __shared__ __attribute__((aligned(16))) __bf16 ldsA[2][3][kWbM * kWbRow];      // [buffer][plane][m][b]
+    __shared__ __attribute__((aligned(16))) __bf16 ldsB[2][3][kWbN * kWbRow];      // [buffer][plane][n][b]
+    __shared__ float colsum[4][kWbM];
+    const int MT = M / kWbM, NT = Nf / kWbN;
+    const int tile = blockIdx.x % (MT * NT), split = blockIdx.x / (MT * NT);
+    const int mt = tile % MT, nt = tile / MT;
+    G += split * rows_per_split * M;
+    X += split * rows_per_split * Nf;
+    B = (B - split * rows_per_split < rows_per_split) ? B - split * rows_per_split : rows_per_split;
+    gW += (size_t)split * M * Nf;
+    gb += (size_t)split * M;
+    const int m0 = kWbM * mt, n0 = kWbN * nt;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    // staging: thread t holds the octet t / 128 of a stage for column m0 + t % 128 of G and for column n0 + t % 128 of x
+    const int sc = tid & 127, so = tid >> 7;
+    const float *ga = G + m0 + sc, *xb = X + n0 + sc;
+    float fa[8], fb[8], ga2[8], gb2[8];      // two register sets: the loads run TWO stages ahead of their use
+    float csum = 0.f;
+    // load(st) only ISSUES the loads of stage st (rows past the end of the split are read from its last row and dropped in
+    // store(): a select on the loaded value here made the compiler wait for every load before the MFMAs of the stage in front)
+    auto load = [&](long st, float (&fa)[8], float (&fb)[8]) {
+        const float *gs = ga + st * kWbStage * M, *xs = xb + st * kWbStage * Nf;
+        const int lim = (int)(B - st * kWbStage) - 1;              // last valid row of the stage (>= 0)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = 8 * so + i;
+            const uint32_t rc = (uint32_t)(r < lim ? r : lim);
+            fa[i] = gs[rc * (uint32_t)M];
+            fb[i] = xs[rc * (uint32_t)Nf];
+        }
+    };
+    auto store = [&](long st, float (&fa)[8], float (&fb)[8]) {
+        const int buf = (int)(st & 1);
+        const int lim = (int)(B - st * kWbStage) - 1;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const bool ok = 8 * so + i <= lim;
+            fa[i] = ok ? fa[i] : 0.f;
+            fb[i] = ok ? fb[i] : 0.f;
+        }
+        u32x4 p0, p1, p2;
+        const int at = sc * kWbRow + 8 * so;
+        bf3_split8(fa, p0, p1, p2);
+        *reinterpret_cast<u32x4 *>(&ldsA[buf][0][at]) = p0;
+        *reinterpret_cast<u32x4 *>(&ldsA[buf][1][at]) = p1;
+        *reinterpret_cast<u32x4 *>(&ldsA[buf][2][at]) = p2;
+        bf3_split8(fb, p0, p1, p2);
+        *reinterpret_cast<u32x4 *>(&ldsB[buf][0][at]) = p0;
+        *reinterpret_cast<u32x4 *>(&ldsB[buf][1][at]) = p1;
+        *reinterpret_cast<u32x4 *>(&ldsB[buf][2][at]) = p2;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) csum = csum + fa[i];      // b ascending within the thread's octet
+    };
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const long nst = (B + kWbStage - 1) / kWbStage;
+    // fragment addresses: lane l feeds row (column of the image) l % 32 with the octet l / 32 of a 16-b step
+    const int fr = lane & 31, fo = lane >> 5;
+    // the fragments of the second 16-b step are requested before the MFMAs of the first (one exposed LDS round trip per stage
+    // instead of two: with the reads in front of their own MFMAs they were the largest item of the kernel, 32 of 66 us)
+    auto frags = [&](int buf, int kk, bf16x8 (&a)[2][3], bf16x8 (&b)[3]) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                a[t][p] = *reinterpret_cast<const bf16x8 *>(&ldsA[buf][p][(64 * wm + 32 * t + fr) * kWbRow + 16 * kk + 8 * fo]);
+            b[p] = *reinterpret_cast<const bf16x8 *>(&ldsB[buf][p][(32 * wn + fr) * kWbRow + 16 * kk + 8 * fo]);
+        }
+    };
+    auto six = [&](const bf16x8 (&a)[2][3], const bf16x8 (&b)[3]) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {      // the small products first
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][0], b[2], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][1], b[1], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][2], b[0], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][0], b[1], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][1], b[0], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][0], b[0], acc[t], 0, 0, 0);
+        }
+    };
+    auto mfmas = [&](int buf) {
+        bf16x8 a0[2][3], b0[3], a1[2][3], b1[3];
+        frags(buf, 0, a0, b0);
+        frags(buf, 1, a1, b1);
+        six(a0, b0);
+        six(a1, b1);
+    };
+    // Stage st + 1 is split and written into the OTHER buffer beside the MFMAs of stage st (its loads were issued two stages
+    // back); one barrier per stage.  Stages in pairs: even ones through (fa, fb), odd ones through (ga2, gb2).  The body is
+    // branch-free (a stage past the end re-reads the last one and stores zeros) so that the scheduler may deal the VALU work
+    // of the split between the MFMAs.
+    const long last = nst - 1;
+    if (nst > 0) {
+        load(0, fa, fb);
+        load(nst > 1 ? 1 : last, ga2, gb2);
+        store(0, fa, fb);
+        load(nst > 2 ? 2 : last, fa, fb);
+    }
+    __syncthreads();
+    for (long st = 0; st < nst; st += 2) {
+        mfmas(0);
+        store(st + 1, ga2, gb2);
+        load(st + 3 < nst ? st + 3 : last, ga2, gb2);
+        __syncthreads();
+        mfmas(1);
+        store(st + 2, fa, fb);
+        load(st + 4 < nst ? st + 4 : last, fa, fb);
+        __syncthreads();
+    }
+    // lane l, element r: row m = 64 wm + 32 t + 8 (r / 4) + 4 (l / 32) + r % 4, column n = 32 wn + l % 32
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + 64 * wm + 32 * t + 8 * (r >> 2) + 4 * fo + (r & 3);
+            gW[(long)m * Nf + n0 + 32 * wn + fr] = acc[t][r];
+        }
+    if (nt == 0) {     // column sums of this G slab: the four octet classes in order
+        colsum[so][sc] = csum;
+        __syncthreads();
+        if (tid < kWbM) gb[m0 + tid] = ((colsum[0][tid] + colsum[1][tid]) + colsum[2][tid]) + colsum[3][tid];
+    }
+}
+
 // gW[i] = s * (part[0][i] + part[1][i] + ...), gb likewise without the factor: splits ascending
 __global__ void __launch_bounds__(256)
 k_wgrad_reduce(const float *__restrict__ part, const float *__restrict__ partb, int splits, long MN, int M,
