@@ -227,9 +227,11 @@ def test_adam_kernel_matches_torch_adam():
         assert float((p.detach() - q.detach()).abs().max()) <= 3e-8, float((p.detach() - q.detach()).abs().max())
 
 
-@pytest.mark.parametrize("B,N,K,D", [(4096, 8, 256, 512), (600, 4, 256, 256), (333, 8, 16, 40), (65, 2, 16, 30), (1000, 16, 16, 96)])
+@pytest.mark.parametrize("B,N,K,D", [(4096, 8, 256, 512), (600, 4, 256, 256), (333, 8, 16, 40), (65, 2, 16, 30), (1000, 16, 16, 96),
+                                     (4001, 4, 256, 256), (2500, 16, 256, 128), (2048, 8, 128, 1024)])
 def test_weight_grad_kernel_matches_matmul(B, N, K, D):
-    """mcq_weight_grad (fp32 MFMA, fused scale / column sums) against the library formulation s * G^T x, G.sum(0)."""
+    """mcq_weight_grad (fused scale / column sums) against the library formulation s * G^T x, G.sum(0): the fp32-MFMA kernel and
+    -- the large tile-aligned shapes, with a ragged last stage among them -- the bf16-piece kernel (k_wgrad_bf3)."""
     from quantization_amd import _lib
     L = _lib.lib()
     dev = torch.device("cuda:0")
