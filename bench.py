@@ -3,13 +3,16 @@
 dim=512, 8 codebooks of 256 entries, 5 refinement passes (BASELINE.json metric).
 
     python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus N ...        (no launcher: bench.py starts its N ranks itself through torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" is one Quantizer.encode() of the per-GPU batch (65,536 synthetic Gaussian
 vectors already resident in HBM; uint8 codes written to HBM).  With N GPUs every rank
 encodes its own shard -- no collective on the data path (weak scaling).  Rank 0 prints
-ONE JSON line.  `roofline` is for the dominant kernel, from per-launch HIP events on the
-launch stream (mcq_profile_encode); `cpu_baseline` times the torch-CPU restatement of the
+ONE JSON line.  `roofline` is for the dominant kernel: its launch time from HIP events on the
+launch stream (mcq_profile_encode), its counters (L1 <- L2 requests, HBM-side bytes) read live by
+rocprofv3 --pmc child runs of this command (--no-pmc-check: from the committed passes); a table
+kernel is priced against what binds it, the L2 -> L1 path (`bound`: "l2"); `cpu_baseline` times the torch-CPU restatement of the
 reference's op sequence (oracle/torch_port.py) on this host's cores on a bounded sample.
 Secondary objects: `parity` (sampled rows vs the oracle, the 4,096 reference-fixture rows),
 `configs` (BASELINE configs A, D and config C's per-GPU shard), `decode`, `trainer_step`,
@@ -89,6 +92,167 @@ def kernel_work(B, D, N, K):
         "residual_energies": (0.0, B * (N + N * 4.0 + 8), B * (N * N + N) * 4.0),       # E, R from the tables
         "encode_tail": (0.0, B * N * 2.0, 0.0),
     }
+
+
+# kernel-name prefixes of the launch categories (rocprofv3's Kernel_Name without `void mcq::`), for the --pmc passes
+CATEGORY_KERNELS = {"logits_product_argmax": "k_fgemm<1>", "xc_product": "k_fgemm<0>", "frames_to_limbs": "k_fix_rows<",
+                    "residual_energies": "k_tf_er<", "stage0_tables": "k_tf_stage0", "combine_level0": "k_tf_pair0<",
+                    "combine_level1": "k_tf_pair1<", "tables_level1": "k_tf_table1<", "combine_level2": "k_tf_comb<",
+                    "level1_combines_and_tables": "k_tf_level1<", "tables_upper_levels": "k_tf_up<",
+                    "combine_upper_levels": "k_tf_comb3<"}
+
+
+def profile_kernels(L, q, x, B, D, N, K, iters, dev, reps=3):
+    """{category: launches, avg ms, work figures} of one encode: mcq_profile_encode (HIP events on the launch stream)."""
+    with torch.no_grad():          # inference flavour of the derived state (host-side scale factors)
+        blob = q._prepared()
+    ws = q._workspace(B, dev)
+    CAP = 32
+    ms = (ctypes.c_float * CAP)()
+    cnt = (ctypes.c_int * CAP)()
+    acc, launches = np.zeros(CAP), np.zeros(CAP, np.int64)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    ncat = 0
+    for _ in range(reps):
+        ncat = L.mcq_profile_encode(x.data_ptr(), B, blob.data_ptr(), q._lscale_exp, N, K, D, iters, ws.data_ptr(),
+                                    ws.numel(), st, ms, cnt, CAP)
+        assert ncat > 0, ncat
+        acc[:ncat] += np.array(ms[:ncat])
+        launches[:ncat] = np.array(cnt[:ncat])
+    acc /= reps
+    work = kernel_work(B, D, N, K)
+    kernels = {}
+    for i in range(ncat):
+        if launches[i] == 0:
+            continue
+        name = L.mcq_profile_category_name(i).decode()
+        fl, by, tb = work[name]
+        avg_ms = max(acc[i], 1e-9) / launches[i]
+        kernels[name] = {"launches_per_encode": int(launches[i]), "avg_ms": round(float(avg_ms), 4),
+                         "ms_per_encode": round(float(acc[i]), 3)}
+        if fl > 0:
+            tf_ = fl / (avg_ms * 1e-3) / 1e12
+            kernels[name].update(gflop_per_launch=round(fl / 1e9, 2), f32_equivalent_tflops=round(tf_, 2),
+                                 i8_tops=round(LIMB_PRODUCTS * tf_, 1), frac_of_i8_mfma_peak=round(LIMB_PRODUCTS * tf_ / PEAK_I8_MFMA_TOPS, 4),
+                                 hbm_gbyte_per_launch=round(by / 1e9, 3))
+        else:
+            kernels[name].update(hbm_gbyte_per_launch=round(by / 1e9, 3), hbm_gbytes_per_s=round(by / (avg_ms * 1e-3) / 1e9, 1))
+            if tb > 0:
+                kernels[name].update(table_gbyte_per_launch=round(tb / 1e9, 3), table_gbytes_per_s_from_l2=round(tb / (avg_ms * 1e-3) / 1e9, 1))
+    return kernels
+
+
+def pmc_live(D, N, B, iters, budget_s=200.0):
+    """Counters of THIS command's kernels, read by rocprofv3 child runs of it (kernel-trace + one counter group per run:
+    TCP_TCC_READ_REQ / FETCH_SIZE / WRITE_SIZE; no other trace domain).  {category: {...}} or None when rocprofv3 is not
+    there or the budget ran out before the first pass.  Bytes as MI355X_MICROARCH.md corrects them for gfx950:
+    HBM-side bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB, one L1 <- L2 request = one 128-byte line."""
+    import collections
+    import csv
+    import glob
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    out_root = tempfile.mkdtemp(prefix="mcq_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    vals = collections.defaultdict(lambda: collections.defaultdict(list))
+    t0 = time.time()
+    done = []
+    for tag, counters in (("tcp", ["TCP_TCC_READ_REQ_sum"]), ("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"])):
+        left = budget_s - (time.time() - t0)
+        if left < 30:
+            break
+        cmd = [exe, "--kernel-trace", "--pmc"] + counters + ["--output-format", "csv", "-d", os.path.join(out_root, tag), "--",
+               sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-profile",
+               "--no-secondary", "--no-pmc-check", "--dim", str(D), "--num-codebooks", str(N), "--batch-per-gpu", str(B),
+               "--refine-iters", str(iters)]
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=left)
+        except (subprocess.TimeoutExpired, OSError):
+            break
+        if r.returncode != 0:
+            continue
+        for f in glob.glob(os.path.join(out_root, tag, "**", "*counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                n = re.sub(r"\(.*", "", row["Kernel_Name"]).replace("void ", "").replace("mcq::", "")
+                vals[n][row["Counter_Name"]].append(float(row["Counter_Value"]))
+        done.append(tag)
+    shutil.rmtree(out_root, ignore_errors=True)
+    if not done:
+        return None
+    out = {}
+    for cat, prefix in CATEGORY_KERNELS.items():
+        names = [n for n in vals if n.startswith(prefix)]
+        if not names:
+            continue
+        def mean(counter):
+            v = [x_ for n_ in names for x_ in vals[n_][counter]]
+            return (sum(v) / len(v), len(v)) if v else (None, 0)
+        rq, nl = mean("TCP_TCC_READ_REQ_sum")
+        fk, _ = mean("FETCH_SIZE")
+        wk, _ = mean("WRITE_SIZE")
+        out[cat] = {"kernel": names[0], "launches_averaged": nl,
+                    "traffic_bytes": None if fk is None or wk is None else int(round((2 * fk + wk) * 1024)),
+                    "l2_read_requests": None if rq is None else int(round(rq)),
+                    "l2_read_request_bytes": None if rq is None else int(round(rq * 128))}
+    out["_passes"] = done
+    out["_seconds"] = round(time.time() - t0, 1)
+    return out
+
+
+def pmc_committed(dom_name, D, N, K, B, iters):
+    """the newest committed --pmc passes of the same command (profiles/rNN_pmc_traffic*.json), when the live read is off"""
+    import glob
+    tag = "" if (D, N, K, B, iters) == (512, 8, 256, 65536, 5) else f"_d{D}_n{N}"
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r??_pmc_traffic{tag}.json")))
+    if not files or (tag == "" and (D, N, K, B, iters) != (512, 8, 256, 65536, 5)):
+        return None, None
+    pmc = json.load(open(files[-1]))
+    if dom_name not in pmc:
+        return None, None
+    return pmc[dom_name], "committed: profiles/%s (separate --pmc runs of this command; not counters of this run)" % os.path.basename(files[-1])
+
+
+def roofline_of(dom_name, kern, work, pmc, pmc_src):
+    """`roofline` of the dominant launch category.  A product: i8 MFMA operations against the dense i8 peak.  A table kernel
+    has no FLOPs and its HBM bytes are small: what binds it is the L2 -> L1 path, priced by the 128-byte LINES its 4-byte gathers
+    move (TCP_TCC_READ_REQ x 128 B) against the L2 peak -- `frac` -- with the useful bytes beside it (`useful_frac`) and the HBM
+    figures as the sub-object `hbm`."""
+    dom_fl, dom_by, dom_tb = work
+    dom_ms = kern["avg_ms"]
+    traffic = pmc.get("traffic_bytes") if pmc else None
+    lines = pmc.get("l2_read_request_bytes") if pmc else None
+    if dom_fl > 0:
+        achieved = LIMB_PRODUCTS * dom_fl / (dom_ms * 1e-3) / 1e12
+        return {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 1), "peak": PEAK_I8_MFMA_TOPS,
+                "unit": "TFLOP/s", "frac": round(achieved / PEAK_I8_MFMA_TOPS, 4), "traffic": traffic,
+                "traffic_source": pmc_src, "gop_per_launch": round(LIMB_PRODUCTS * dom_fl / 1e9, 2),
+                "avg_launch_ms": round(float(dom_ms), 4),
+                "note": "i8 MFMA operations (ten limb products per multiply-add of the exact fixed-point product) against "
+                        "the dense i8 peak; unit reads TOP/s"}
+    hbm_ach = dom_by / (dom_ms * 1e-3) / 1e9
+    hbm = {"achieved": round(hbm_ach, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(hbm_ach / PEAK_HBM_GBPS, 4),
+           "gbyte_per_launch": round(dom_by / 1e9, 3),
+           "note": "algorithmic HBM bytes (per-vector inputs, lists and tables written and read back) / launch time"}
+    useful = dom_tb / (dom_ms * 1e-3) / 1e9
+    if lines:
+        ach = lines / (dom_ms * 1e-3) / 1e9
+        return {"bound": "l2", "kernel": dom_name, "achieved": round(ach, 1), "peak": PEAK_L2_GBPS, "unit": "GB/s",
+                "frac": round(ach / PEAK_L2_GBPS, 4), "useful_frac": round(useful / PEAK_L2_GBPS, 4),
+                "line_gbyte_per_launch": round(lines / 1e9, 3), "useful_table_gbyte_per_launch": round(dom_tb / 1e9, 3),
+                "lines_per_useful_byte": round(lines / max(dom_tb, 1.0), 2),
+                "traffic": traffic, "traffic_source": pmc_src, "avg_launch_ms": round(float(dom_ms), 4), "hbm": hbm,
+                "note": "a table kernel: no FLOPs to price, HBM far from its peak.  What binds it is the L2 -> L1 path: every 4-byte "
+                        "Gram gather that misses the L1 moves a 128-byte line.  achieved = TCP_TCC_READ_REQ x 128 B per launch / the "
+                        "launch time measured here (HIP events), peak = the aggregate L2 -> L1 rate of MI355X_MICROARCH.md; "
+                        "useful_frac prices only the entries used; traffic = HBM-side bytes (2*FETCH_SIZE + WRITE_SIZE) x 1024"}
+    return dict(hbm, bound="hbm", kernel=dom_name, traffic=traffic, traffic_source=pmc_src, avg_launch_ms=round(float(dom_ms), 4),
+                l2={"useful_table_gbyte_per_launch": round(dom_tb / 1e9, 3), "l2_frac_useful": round(useful / PEAK_L2_GBPS, 4),
+                    "note": "no L1 <- L2 request counter for this shape: the L2 line figure is not priced"})
 
 
 def load_quantizer(state, D, K, N, dev):
@@ -196,6 +360,21 @@ def trainer_leg(dev, D, N, batch, p_iters, process_group=None, data_parallel=Fal
     return ms, nparam
 
 
+def self_launch(n):
+    """Re-run this command under torch.distributed.run with n ranks on 127.0.0.1 (a free port); returns its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # the host driver only supports dmabuf IPC (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -213,11 +392,34 @@ def main():
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary figures (other configs, skipping mode, host-resident / fp16 input, decode, "
                          "trainer): every kernel launch of the run then has the headline shape (for rocprofv3 averages)")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="form the process group, report the ranks seen and leave (covers the self-launch on a CPU-only box)")
+    ap.add_argument("--no-pmc-check", action="store_true",
+                    help="do not run the rocprofv3 --pmc child that reads the dominant kernel's L1 <- L2 requests live")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, torch.distributed.run
+        # on the loopback address), pass every argument through and leave with the launcher's exit code
+        sys.exit(self_launch(args.gpus))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.rendezvous_only:
+        # the launch path alone (no device needed): every rank joins the group and reports in; rank 0 prints what it saw
+        import torch.distributed as dist
+        dist.init_process_group("gloo" if not torch.cuda.is_available() else args.backend)
+        seen = [None] * world
+        dist.all_gather_object(seen, {"rank": rank, "local_rank": local_rank, "pid": os.getpid()})
+        if rank == 0:
+            print(json.dumps({"rendezvous": world, "gpus": args.gpus, "backend": dist.get_backend(),
+                              "ranks": sorted(r["rank"] for r in seen), "pids": len({r["pid"] for r in seen})}), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+        return
     assert torch.cuda.is_available(), "bench.py measures the HIP path: it needs an MI355X"
     if args.single_device:
         local_rank = 0
@@ -259,13 +461,18 @@ def main():
         barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+    per_rank_dt = [dt]
     if dist is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)
+        per_rank_dt = [float(e.item()) for e in every]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
     # ---- data-parallel trainer (BASELINE config E): every rank takes part in the collectives
     dp = None
+    dp_failed = False
     if dist is not None and not args.no_secondary:
         dp = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend()}
         try:      # (a failure here must not take the headline line with it)
@@ -276,16 +483,23 @@ def main():
                 dp[tag] = {"per_gpu_batch": per_gpu, "global_batch": per_gpu * world,
                            "phase1_ms_per_step": round(float(tt[0]), 3), "phase2_ms_per_step": round(float(tt[1]), 3),
                            "all_reduce_bytes_per_step_phase2": 4 * nparam + 4 * (N * K * 2 + 4)}
-        except Exception as e:      # noqa: BLE001
+        except Exception as e:      # noqa: BLE001  (reported in the line AND in the exit code, after the line is out)
             dp["error"] = f"{type(e).__name__}: {e}"[:300]
+            dp_failed = True
         dp["note"] = ("QuantizerTrainer.step, data_parallel=True: the flat gradient bucket all-reduced (RCCL) in two parts -- "
                       "the centers' gradient while the classifier's backward still runs, the rest after it -- + one small "
                       "forward all-reduce of the batch sums per step; max over ranks")
 
+    if dist is not None:      # a failure of the trainer leg on ANY rank fails the run (after the headline line is printed)
+        f = torch.tensor([1.0 if dp_failed else 0.0], device=dev)
+        dist.all_reduce(f, op=dist.ReduceOp.MAX)
+        dp_failed = bool(f.item() > 0)
     if rank != 0:
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
+        if dp_failed:
+            sys.exit(3)
         return
 
     # ---- parity (outside the timed region): sampled rows vs the CPU oracle, fixture rows vs the reference
@@ -299,91 +513,26 @@ def main():
         parity["vs_reference_fixture"] = fixture_parity(q, dev, iters)
 
     # ---- per-kernel HIP-event timing on the launch stream (same inputs, same process): mcq_profile_encode enqueues exactly
-    # what Quantizer.encode enqueues, with an event pair round every launch
+    # what Quantizer.encode enqueues, with an event pair round the launches of one category per profiled encode
     L = _lib.lib()
-    with torch.no_grad():          # inference flavour of the derived state (host-side scale factors)
-        blob = q._prepared()
-    ws = q._workspace(B, dev)
-    CAP = 32
-    ms = (ctypes.c_float * CAP)()
-    cnt = (ctypes.c_int * CAP)()
-    acc, launches = np.zeros(CAP), np.zeros(CAP, np.int64)
-    reps = 3
     st = torch.cuda.current_stream(dev).cuda_stream
-    ncat = 0
-    for _ in range(0 if args.no_profile else reps):
-        ncat = L.mcq_profile_encode(x.data_ptr(), B, blob.data_ptr(), q._lscale_exp, N, K, D, iters, ws.data_ptr(),
-                                    ws.numel(), st, ms, cnt, CAP)
-        assert ncat > 0, ncat
-        acc[:ncat] += np.array(ms[:ncat])
-        launches[:ncat] = np.array(cnt[:ncat])
-    acc /= reps
-    work = kernel_work(B, D, N, K)
-    kernels = {}
-    for i in range(ncat):
-        if launches[i] == 0:
-            continue
-        name = L.mcq_profile_category_name(i).decode()
-        fl, by, tb = work[name]
-        avg_ms = max(acc[i], 1e-9) / launches[i]
-        kernels[name] = {"launches_per_encode": int(launches[i]), "avg_ms": round(float(avg_ms), 4),
-                         "ms_per_encode": round(float(acc[i]), 3)}
-        if fl > 0:
-            tf_ = fl / (avg_ms * 1e-3) / 1e12
-            kernels[name].update(gflop_per_launch=round(fl / 1e9, 2), f32_equivalent_tflops=round(tf_, 2),
-                                 i8_tops=round(LIMB_PRODUCTS * tf_, 1), frac_of_i8_mfma_peak=round(LIMB_PRODUCTS * tf_ / PEAK_I8_MFMA_TOPS, 4),
-                                 hbm_gbyte_per_launch=round(by / 1e9, 3))
-        else:
-            kernels[name].update(hbm_gbyte_per_launch=round(by / 1e9, 3), hbm_gbytes_per_s=round(by / (avg_ms * 1e-3) / 1e9, 1))
-            if tb > 0:
-                kernels[name].update(table_gbyte_per_launch=round(tb / 1e9, 3), table_gbytes_per_s_from_l2=round(tb / (avg_ms * 1e-3) / 1e9, 1))
+    kernels = {} if args.no_profile else profile_kernels(L, q, x, B, D, N, K, iters, dev)
     kernels_sum_ms = round(float(sum(v["ms_per_encode"] for v in kernels.values())), 3)
-    # the dominant kernel = the category with the largest time per encode (what rocprofv3 --stats puts on top)
+    # the dominant kernel = the category with the largest time per encode (what rocprofv3 --stats puts on top).  Its counters:
+    # read LIVE by a rocprofv3 --pmc child of this very command (one pass per counter group, as MI355X_MICROARCH.md prescribes:
+    # counters cannot be read from inside the timed process), else from the newest committed passes of the same command
     roofline = None
+    pmc_all = None
     if kernels:
         dom_name = max(kernels, key=lambda n: kernels[n]["ms_per_encode"])
-        dom_fl, dom_by, dom_tb = work[dom_name]
-        dom_ms = kernels[dom_name]["avg_ms"]
-        # HBM-side traffic of that kernel: the committed rocprofv3 --pmc passes of this same workload and launch sequence
-        # (counters cannot be collected from inside the timed process); null for other shapes
-        traffic, traffic_note, l2_req_bytes = None, None, None
-        import glob as _glob
-        pmc_files = sorted(_glob.glob(os.path.join(ROOT, "profiles", "r??_pmc_traffic.json")))     # the newest round's passes
-        pmc_file = pmc_files[-1] if pmc_files else ""
-        if (D, N, K, B, iters) == (512, 8, 256, 65536, 5) and pmc_file:
-            pmc = json.load(open(pmc_file))
-            if dom_name in pmc:
-                traffic = pmc[dom_name]["traffic_bytes"]
-                l2_req_bytes = pmc[dom_name].get("l2_read_request_bytes")
-                traffic_note = ("bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 of kernel %s, profiles/%s (a separate "
-                                "--pmc run of this command; not a counter of the timed run)" % (pmc[dom_name]["kernel"], os.path.basename(pmc_file)))
-        if dom_fl > 0:
-            achieved = LIMB_PRODUCTS * dom_fl / (dom_ms * 1e-3) / 1e12
-            roofline = {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 1), "peak": PEAK_I8_MFMA_TOPS,
-                        "unit": "TFLOP/s", "frac": round(achieved / PEAK_I8_MFMA_TOPS, 4), "traffic": traffic,
-                        "traffic_note": traffic_note, "gop_per_launch": round(LIMB_PRODUCTS * dom_fl / 1e9, 2),
-                        "avg_launch_ms": round(float(dom_ms), 4),
-                        "note": "i8 MFMA operations (ten limb products per multiply-add of the exact fixed-point product) against "
-                                "the dense i8 peak; unit reads TOP/s"}
-        else:
-            achieved = dom_by / (dom_ms * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": PEAK_HBM_GBPS,
-                        "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBPS, 4), "traffic": traffic,
-                        "traffic_note": traffic_note, "gbyte_per_launch": round(dom_by / 1e9, 3),
-                        "avg_launch_ms": round(float(dom_ms), 4),
-                        "l2": {"useful_table_gbyte_per_launch": round(dom_tb / 1e9, 3),
-                               "useful_gbytes_per_s": round(dom_tb / (dom_ms * 1e-3) / 1e9, 1),
-                               "l2_frac_useful": round(dom_tb / (dom_ms * 1e-3) / 1e9 / PEAK_L2_GBPS, 4),
-                               "line_gbyte_per_launch": None if l2_req_bytes is None else round(l2_req_bytes / 1e9, 3),
-                               "l2_frac_lines": None if l2_req_bytes is None else round(l2_req_bytes / (dom_ms * 1e-3) / 1e9 / PEAK_L2_GBPS, 4),
-                               "peak_gb_per_s": PEAK_L2_GBPS,
-                               "note": "what bounds a table kernel: 4-byte Gram entries gathered from the XCD's L2; every gather "
-                                       "that misses the L1 moves a 128-byte line (TCP_TCC_READ_REQ x 128 B of the same --pmc "
-                                       "passes = line_*), so the L2 -> L1 path carries 10-15x the useful bytes"},
-                        "note": "a table kernel: no FLOPs to price.  `achieved` prices the bytes it must exchange with HBM (per-vector "
-                                "inputs, lists and tables written and read back) against the HBM peak; `l2` prices what actually "
-                                "bounds it.  The two matrix-core products (logits, x.C) are in `kernels` with their fraction of the "
-                                "i8-MFMA peak"}
+        pmc, pmc_src = None, None
+        if world == 1 and not args.no_pmc_check and not args.no_secondary:
+            pmc_all = pmc_live(D, N, B, iters)
+            if pmc_all and dom_name in pmc_all:
+                pmc, pmc_src = pmc_all[dom_name], "live: rocprofv3 --kernel-trace --pmc child runs of this command (bench.py pmc_live)"
+        if pmc is None:
+            pmc, pmc_src = pmc_committed(dom_name, D, N, K, B, iters)
+        roofline = roofline_of(dom_name, kernels[dom_name], kernel_work(B, D, N, K)[dom_name], pmc, pmc_src)
 
     fpv = reference_flops_per_vector(D, N, K, iters)
     exec_fpv = 2 * 2.0 * D * N * K          # the logits and x.C products only (each multiply-add = ten i8 limb products)
@@ -394,15 +543,19 @@ def main():
                                iters * sum(_w[n_][2] + (_w[n_][1] if n_ == "stage0_tables" else 0.0) for n_ in _pass_names) / (PEAK_L2_GBPS * 1e9)) * 1e3, 3)
     # the same floor with the table passes priced by the 128-byte LINES their gathers move from L2 to L1 (what the L2 serves:
     # one line per channel and clock whatever part of it is used), from the committed --pmc passes of this workload
-    line_floor_ms = None
-    if (D, N, K, B, iters) == (512, 8, 256, 65536, 5):
+    line_floor_ms, line_floor_src = None, None
+    _pmc = pmc_all
+    if _pmc is not None:
+        line_floor_src = "live"
+    elif (D, N, K, B, iters) == (512, 8, 256, 65536, 5):
         import glob as _glob2
         _pf = sorted(_glob2.glob(os.path.join(ROOT, "profiles", "r??_pmc_traffic.json")))
         if _pf:
-            _pmc = json.load(open(_pf[-1]))
-            _lines = sum(_pmc.get(n_, {}).get("l2_read_request_bytes", 0) for n_ in _pass_names)
-            if _lines > 0:
-                line_floor_ms = round((LIMB_PRODUCTS * exec_fpv * B / (PEAK_I8_MFMA_TOPS * 1e12) + iters * _lines / (PEAK_L2_GBPS * 1e9)) * 1e3, 3)
+            _pmc, line_floor_src = json.load(open(_pf[-1])), "committed: profiles/" + os.path.basename(_pf[-1])
+    if _pmc:
+        _lines = sum((_pmc.get(n_, {}).get("l2_read_request_bytes") or 0) for n_ in _pass_names)
+        if _lines > 0:
+            line_floor_ms = round((LIMB_PRODUCTS * exec_fpv * B / (PEAK_I8_MFMA_TOPS * 1e12) + iters * _lines / (PEAK_L2_GBPS * 1e9)) * 1e3, 3)
     value = world * B * args.steps / dt
     out = {
         "metric": "vectors encoded/sec at dim=512, 8 codebooks; uint8 codes bit-exact vs ref",
@@ -413,10 +566,14 @@ def main():
                                f"refine_indexes_iters={iters}, batch={B} fp32 Gaussian vectors per GPU "
                                f"(BASELINE.json configs[1]), seeded synthetic codebooks",
                    "global_batch": world * B, "parallelism": f"batch-sharded x{world}, no collective"},
+        "ranks": {"rccl_ranks": world, "backend": (dist.get_backend() if dist is not None else "none (one process)"),
+                  "launcher": os.environ.get("TORCHELASTIC_RUN_ID") and "torch.distributed.run" or "plain python",
+                  "per_rank_vectors_per_s": [round(B * args.steps / t_, 1) for t_ in per_rank_dt],
+                  "note": "value = all ranks' vectors / the slowest rank's time (barrier + synchronize on both sides)"},
         "parity": parity,
         "whole_encode": {"kernels_sum_ms": kernels_sum_ms,
                          "executed_floor_ms": executed_floor_ms, "frac_of_floor": round(executed_floor_ms / (dt / args.steps * 1e3), 4),
-                         "line_floor_ms": line_floor_ms,
+                         "line_floor_ms": line_floor_ms, "line_floor_counters": line_floor_src,
                          "frac_of_line_floor": None if line_floor_ms is None else round(line_floor_ms / (dt / args.steps * 1e3), 4),
                          "line_floor_note": "as executed_floor_ms, but the table passes move the 128-byte lines their 4-byte gathers "
                                             "touch (TCP_TCC_READ_REQ x 128 B per launch, profiles/rNN_pmc_traffic.json) at the L2 peak: "
@@ -486,6 +643,14 @@ def main():
                           "frac_of_f32_mfma_peak_reference_flops": round(b_ / t_enc * f_ / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                           "decode_gb_per_s": round(b_ * (n_ + 4 * d_) / t_dec / 1e9, 1),
                           "decode_frac": round(b_ * (n_ + 4 * d_) / t_dec / 1e9 / PEAK_HBM_GBPS, 4)}
+            if b_ <= 65536 and not args.no_profile:
+                # the shape's own dominant launch and what bounds it (SURVEY 8d for the named shapes, not only the headline one):
+                # launch times measured here; counters from the committed --pmc passes of that shape (profiles/r05_config_*)
+                kk = profile_kernels(L, qc, xc_, b_, d_, n_, 256, 5, dev, reps=1)
+                dn = max(kk, key=lambda n__: kk[n__]["ms_per_encode"])
+                pm, pm_src = pmc_committed(dn, d_, n_, 256, b_, 5)
+                cfgs[name]["roofline"] = roofline_of(dn, kk[dn], kernel_work(b_, d_, n_, 256)[dn], pm, pm_src)
+                cfgs[name]["kernels_ms_per_encode"] = {k_: v_["ms_per_encode"] for k_, v_ in kk.items()}
             del xc_, cc
             if qc is not q:
                 del qc
@@ -546,6 +711,8 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if dp_failed:
+        sys.exit(3)
 
 
 if __name__ == "__main__":
