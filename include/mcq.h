@@ -24,7 +24,8 @@
  *    bytes_per_frame <= 32, quantization/quantization.py:614; `prepared` holds the N*K x N*K Gram matrix).
  *    K = 512 / 1024 (Quantizer(codebook_size=...) with as_bytes=False, :35): the index search, mcq_refine_indexes,
  *    mcq_logits and mcq_decode (int64 codes); every uint8 output must be NULL there (MCQ_EINVAL otherwise), and the
- *    trainer's entry points (mcq_logits_argmax, mcq_loss_*, mcq_recon_fwd, ...) answer MCQ_EUNSUPPORTED.  Any
+ *    trainer's entry points (mcq_logits_argmax, mcq_logits_refine, mcq_logits_refine_codes, mcq_loss_*, mcq_recon_fwd,
+ *    mcq_decode_backward_u8(_ex), ...) answer MCQ_EUNSUPPORTED.  Any
  *    dim 1 <= D <= 16384 (rows are zero-padded to a multiple of 16 inside `prepared`; the i32 accumulators
  *    of the fixed-point products bound D).  The reference crashes for K < 16
  *    (quantization/quantization.py:506) and needs K <= 256 for byte output (:271).

@@ -549,10 +549,6 @@ static void refine_one_table(const mcq_oracle *o, const float *x, const float *x
     for (int v = 0; v < nlev; v++) { free(L.S[v]); free(L.pos[v]); }
 }
 
-static void refine_any(const mcq_oracle *o, const float *x, const float *xc, mcq_code *idx, scratch *s, mcq_trace *tr) {
-    refine_one_table(o, x, xc, idx, s, tr);
-}
-
 /* _compute_indexes for a batch (:281-305).  idx: uint16 [B][N] (codebooks of up to 1,024 entries). */
 int mcq_oracle_compute_indexes(const mcq_oracle *o, const float *x, long B, int iters, mcq_code *idx,
                                int nthreads) {
@@ -577,7 +573,7 @@ int mcq_oracle_compute_indexes(const mcq_oracle *o, const float *x, long B, int 
             const int xe = frame_limbs_centered(o, x + (size_t)b * D, xl, s.xpad);
             init_indexes(o, xl, xe, id, acc);
             if (iters > 0) compute_xc(o, xl, xe, xc);
-            for (int it = 0; it < iters; it++) refine_any(o, x + (size_t)b * D, xc, id, &s, NULL);
+            for (int it = 0; it < iters; it++) refine_one_table(o, x + (size_t)b * D, xc, id, &s, NULL);
         }
         free(acc); free(xl); free(xc); scratch_free(&s);
     }
@@ -602,7 +598,7 @@ int mcq_oracle_refine(const mcq_oracle *o, const float *x, long B, int iters, mc
 #pragma omp for schedule(dynamic, 8)
         for (long b = 0; b < B; b++) {
             if (iters > 0) compute_xc(o, xl, frame_limbs_centered(o, x + (size_t)b * D, xl, s.xpad), xc);
-            for (int it = 0; it < iters; it++) refine_any(o, x + (size_t)b * D, xc, idx + (size_t)b * N, &s, NULL);
+            for (int it = 0; it < iters; it++) refine_one_table(o, x + (size_t)b * D, xc, idx + (size_t)b * N, &s, NULL);
         }
         free(xc); free(xl); scratch_free(&s);
     }
@@ -618,7 +614,7 @@ int mcq_oracle_refine_trace(const mcq_oracle *o, const float *x, mcq_code *idx, 
     int8_t *xl = (int8_t *)malloc((size_t)4 * o->Dp);
     ensure_gram(o);
     compute_xc(o, xl, frame_limbs_centered(o, x, xl, s.xpad), xc);
-    refine_any(o, x, xc, idx, &s, &tr);
+    refine_one_table(o, x, xc, idx, &s, &tr);
     free(xc); free(xl);
     scratch_free(&s);
     return 0;

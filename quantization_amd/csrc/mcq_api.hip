@@ -183,7 +183,7 @@ struct Prof {
     // 9-11 % longer than the timed one), so mcq_profile_encode runs one encode per category and times only that category's
     // launches in it; two timed launches that follow each other share the event between them.
     void begin(int category) {
-        if (only >= 0 && category != only) return;
+        if (only >= 0 && category != only) { open = -1; return; }      // (a launch that is not timed separates two that are)
         if (ev.empty() || open != (int)ev.size() - 1) {
             hipEvent_t e;
             (void)hipEventCreate(&e);
@@ -192,6 +192,7 @@ struct Prof {
         }
         open = (int)ev.size() - 1;
     }
+    void untimed() { open = -1; }             // something was enqueued outside every category: the next interval takes a fresh event
     void end(int category) {
         if (only >= 0 && category != only) { open = -1; return; }
         hipEvent_t e;
@@ -547,6 +548,7 @@ int run_encode_t(const float *x, long B, const void *prepared, float lscale, int
             hipLaunchKernelGGL(k_import_indexes<CT>, dim3((unsigned)((Bc * N + 255) / 256)), dim3(256), 0, st,
                                init_idx + lo * N, Bc * N, K, w.idx);
             MCQ_LAUNCH_CHECK();
+            if (prof) prof->untimed();
         } else {
             if (prof) prof->begin(CAT_LOGITS);
             rc = launch_logits(w.xf, w.xe, Bc, P, N, K, D, lscale,
@@ -568,6 +570,7 @@ int run_encode_t(const float *x, long B, const void *prepared, float lscale, int
         if (skip) {
             hipError_t e = hipMemsetAsync(w.cnt, 0, 64 * sizeof(int), st);
             if (e != hipSuccess) return (int)e;
+            if (prof) prof->untimed();
         }
         bool wrote_direct = false;
         // E / R of pass it + 1 can be formed by the wave that emits the indexes of pass it (tf_emit), which saves that pass
@@ -926,7 +929,8 @@ int mcq_decode_backward(const float *grad_out, const int64_t *idx, long B, int N
 
 int mcq_decode_backward_u8(const float *grad_out, const uint8_t *codes, long B, int N, int K, int D, float *gC,
                            void *stream) {
-    if (N <= 0 || K <= 0 || K > 256 || D <= 0 || B < 0 || !gC) return MCQ_EINVAL;
+    if (K > 256) return MCQ_EUNSUPPORTED;       // (byte codes: the trainer's entry points stay at K <= 256, include/mcq.h)
+    if (N <= 0 || K <= 0 || D <= 0 || B < 0 || !gC) return MCQ_EINVAL;
     if (B > 0 && (!grad_out || !codes)) return MCQ_EINVAL;
     return launch_decode_backward<uint8_t>(grad_out, codes, B, N, K, D, gC, (long)D, 0L, N, static_cast<hipStream_t>(stream));
 }
@@ -1036,6 +1040,7 @@ int mcq_logits_refine(const float *x, long B, const void *prepared, float lscale
 int mcq_logits_refine_codes(const float *x, long B, const void *prepared, float lscale_exp, int N, int K, int D, int refine_iters,
                             float *logits_out, int64_t *idx_out, uint8_t *codes_out, void *workspace, size_t workspace_bytes,
                             void *stream, unsigned flags) {
+    if (K > 256) return MCQ_EUNSUPPORTED;       // a trainer entry point (stored logits for the fused loss kernels): K <= 256
     if (B > 0 && (!logits_out || !idx_out)) return MCQ_EINVAL;
     return run_encode(x, B, prepared, lscale_exp, N, K, D, refine_iters, nullptr, idx_out, workspace, workspace_bytes,
                       static_cast<hipStream_t>(stream), nullptr, nullptr, flags & ~MCQ_ENCODE_SKIP_FIXED_POINTS, logits_out,
@@ -1227,7 +1232,8 @@ long mcq_decode_backward_waves(int N, int K, int D) { return (long)N * K * db_ch
 
 int mcq_decode_backward_u8_ex(const float *grad_out, const uint8_t *codes, long B, int N, int K, int D, float *gC,
                               const float *sa, const float *sb, float sc, const float *dotw, float *dot_part, void *stream) {
-    if (N <= 0 || K <= 0 || K > 256 || D <= 0 || B < 0 || !gC) return MCQ_EINVAL;
+    if (K > 256) return MCQ_EUNSUPPORTED;
+    if (N <= 0 || K <= 0 || D <= 0 || B < 0 || !gC) return MCQ_EINVAL;
     if (B > 0 && (!grad_out || !codes)) return MCQ_EINVAL;
     if ((dotw == nullptr) != (dot_part == nullptr)) return MCQ_EINVAL;
     // the caller sized dot_part by mcq_decode_backward_waves: the wide kernel must be the one that runs when D % 4 == 0
@@ -1300,7 +1306,9 @@ int mcq_profile_encode(const float *x, long B, const void *prepared, float lscal
     const bool wide = K > 256;                // (entries of more than 256-entry codebooks leave as int64: no byte form)
     const size_t need = (size_t)B * N * (wide ? 8 : 1);
     uint8_t *dummy = nullptr;                 // the codes of the profiled encodes (this entry point is a measurement tool: it allocates)
-    if (hipMalloc(reinterpret_cast<void **>(&dummy), need ? need : 1) != hipSuccess) return MCQ_EINVAL;
+    if (!ms_out || cap <= 0) return MCQ_EINVAL;
+    const hipError_t me = hipMalloc(reinterpret_cast<void **>(&dummy), need ? need : 1);
+    if (me != hipSuccess) return (int)me;
     for (int i = 0; i < cap; ++i) { ms_out[i] = 0.f; if (launches_out) launches_out[i] = 0; }
     int rc = 0;
     for (int only = 0; only < CAT_COUNT && rc == 0; ++only) {      // one encode per category: see Prof

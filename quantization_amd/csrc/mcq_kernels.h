@@ -151,6 +151,11 @@ __device__ __forceinline__ u64 wave_kth_lane_key(u64 k, int target, int win = 0)
     u64 kp;
     int rr;
     do {                          // every round removes at least the pivot's lane from the candidates: <= 64 rounds
+#ifdef MCQ_DEBUG_SELECT
+        // debug builds (hipcc -DMCQ_DEBUG_SELECT; __graft_entry__.build(debug_select=True)): the invariant below, checked.  An
+        // empty candidate mask means two equal keys reached the selection -- trap instead of spinning on ctz(0)
+        if (cm == 0) __builtin_trap();
+#endif
         const int pl = __builtin_ctzll(cm);      // (cm != 0 here; __ffsll's zero case cost two scalar instructions per round)
         kp = readlane_u64(k, pl);
         const u64 ltm = __ballot(k < kp), gtm = __ballot(k > kp);      // (keys are unique: the lanes above the pivot, from a second
@@ -199,6 +204,11 @@ __device__ __forceinline__ void wave_select_fast(const float (&v)[VPL], const in
         // survivors -- more than 64 of them only if those lanes hold nearly all their keys below T0, in which case the exact
         // cnt-th minimum is taken after all: at most cnt * VPL <= 64 survive that)
         u64 T0 = wave_kth_lane_key(lmin, target, MCQ_SEL_WIN);
+        // (T0 == kKeyMax: fewer than cnt lanes hold a candidate.  Every candidate then survives -- at most (cnt - 1) * VPL < 64 of
+        // them -- and the non-candidates, whose key IS kKeyMax, must not: the bound becomes kKeyMax - 1 (a candidate's key is
+        // below it: its low word is a position), and the retry below, which would return kKeyMax again, is skipped)
+        const bool few = (T0 == kKeyMax);
+        if (few) T0 = kKeyMax - 1;
         int base;
         for (int attempt = 0;; ++attempt) {
             base = 0;
@@ -210,7 +220,7 @@ __device__ __forceinline__ void wave_select_fast(const float (&v)[VPL], const in
                 if (sel && dst < 64) ldsA[dst] = key[i];
                 base += __popcll(m);
             }
-            if (base <= 64 || attempt > 0) break;
+            if (base <= 64 || attempt > 0 || few) break;
             T0 = wave_kth_lane_key(lmin, target);
         }
         const int c0 = base < 64 ? base : 64;

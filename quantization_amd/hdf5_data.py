@@ -34,7 +34,10 @@ class MiniHdf5File:
 
     def __init__(self, filename: str):
         with open(filename, "rb") as f:      # mapped, not read: a dataset is only paged in when it is copied out
-            self.buf = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
+            try:
+                self.buf = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
+            except ValueError as e:          # (an empty file cannot be mapped)
+                raise Hdf5FormatError(f"{filename}: not an HDF5 file ({e})") from None
         b = self.buf
         base = -1
         off = 0
@@ -102,6 +105,8 @@ class MiniHdf5File:
 
     def _name(self, heap_data: int, off: int) -> str:
         e = self.buf.find(b"\0", heap_data + off)
+        if e < 0:
+            raise Hdf5FormatError("unterminated name in a local heap")
         return self.buf[heap_data + off:e].decode("utf-8")
 
     def _group_entries(self, btree: int, heap_data: int, out: List[Tuple[str, int]]):
@@ -121,6 +126,21 @@ class MiniHdf5File:
             self._group_entries(self._off(q), heap_data, out)
             q += self.O + self.L
         return
+
+    def close(self):
+        """unmap the file (views handed out by read() must be copied before)"""
+        if self.buf is not None:
+            try:
+                self.buf.close()
+            except BufferError:      # a caller still holds a view of the mapping: it goes with the last view
+                pass
+            self.buf = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
     def datasets(self) -> Dict[str, int]:
         """name -> object header address of the root group's members, in the group's (name-sorted) order."""
@@ -239,6 +259,19 @@ class _Archive:
             self._h5, self._mini = None, MiniHdf5File(filename)
             self.names = self._mini.keys()
 
+    def close(self):
+        if self._h5 is not None:
+            self._h5.close()
+        if self._mini is not None:
+            self._mini.close()
+        self._h5 = self._mini = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
     def shape(self, name: str) -> Tuple[int, ...]:
         return tuple(self._h5[name].shape) if self._h5 is not None else self._mini.shape(name)
 
@@ -254,21 +287,22 @@ def read_hdf5_data(filename: str) -> Tuple[torch.Tensor, torch.Tensor]:
     np.random.seed gives the reference's split), the first 5 % of the shuffled rows -- 10,000 at most -- as `valid`, the rest as
     `train`.  Both are CPU tensors viewing that one matrix."""
     logging.info(f"Opening file {filename}")
-    archive = _Archive(filename)
-    # one pass over the headers: how many frames each dataset brings (everything but the last axis), one common feature dimension
-    shapes = [archive.shape(name) for name in archive.names]
-    dims = {sh[-1] for sh in shapes}
-    assert len(dims) <= 1, "Dataset must have consistent dimension (last element of shape"
-    dim = dims.pop() if dims else -1
-    counts = [int(np.prod(sh[:-1], dtype=np.int64)) for sh in shapes]
-    starts = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
-    total = int(starts[-1])
-    logging.info(f"read_data: tot_frames = {total}")
-    frames = np.empty((total, dim), dtype=np.float16)
-    for name, lo, n in zip(archive.names, starts[:-1], counts):             # second pass: the data, dataset after dataset
-        block = archive.rows(name, dim)
-        assert block.shape[0] == n, (name, block.shape, n)
-        frames[lo:lo + n] = block
+    with _Archive(filename) as archive:      # (closed -- file unmapped -- once the frames are copied out)
+        # one pass over the headers: how many frames each dataset brings (everything but the last axis), one common feature dimension
+        shapes = [archive.shape(name) for name in archive.names]
+        dims = {sh[-1] for sh in shapes}
+        assert len(dims) <= 1, "Dataset must have consistent dimension (last element of shape"
+        dim = dims.pop() if dims else -1
+        counts = [int(np.prod(sh[:-1], dtype=np.int64)) for sh in shapes]
+        starts = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        total = int(starts[-1])
+        logging.info(f"read_data: tot_frames = {total}")
+        frames = np.empty((total, dim), dtype=np.float16)
+        for name, lo, n in zip(archive.names, starts[:-1], counts):             # second pass: the data, dataset after dataset
+            block = archive.rows(name, dim)
+            assert block.shape[0] == n, (name, block.shape, n)
+            frames[lo:lo + n] = block
+            del block
     np.random.shuffle(frames)
     n_valid = min(int(0.05 * total), 10000)      # (the reference slices with the float itself: module docstring)
     logging.info(f"read_data: train_frames={total - n_valid}, valid_frames={n_valid}")

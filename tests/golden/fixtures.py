@@ -50,8 +50,9 @@ def check_codes(fx, it, codes, what):
                             f"first at {np.flatnonzero(hard)[:5]}")
     # near-tie differences must stay rare, or the comparison means nothing.  Where the fixture holds the reference's OWN
     # reorder noise (its codes against those of its feature-permuted run, make_golden.py::permuted_reference) that is the
-    # yardstick: no more than two vectors above it; otherwise a flat 0.05 %
+    # yardstick: no more than ONE vector above it; otherwise a flat 0.05 %
     key = f"reorder_noise_it{it}"
-    limit = int(fx[key]) + 2 if key in fx else max(2, 0.0005 * len(ref))
+    # (+ 1, and never more than 0.5 % of the rows whatever a regenerated fixture stores)
+    limit = min(int(fx[key]) + 1, max(2, int(0.005 * len(ref)))) if key in fx else max(2, 0.0005 * len(ref))
     assert bad.sum() <= limit, f"{what}: {int(bad.sum())} near-tie differences of {len(ref)} (limit {limit})"
     return int(bad.sum())

@@ -51,6 +51,14 @@ def test_argument_validation_without_launch():
     assert L.mcq_decode(None, 2, 8, 4, None, 8, 256, 64, None, None) == m.MCQ_EINVAL
     assert L.mcq_decode(None, 1, 3, 4, None, 8, 256, 64, None, None) == m.MCQ_EINVAL
     assert L.mcq_prepare(None, 1.0, None, None, 8, 256, 64, None, None) == m.MCQ_EINVAL
+    # the trainer's entry points stay at K <= 256 (include/mcq.h): wider codebooks are UNSUPPORTED there, not "invalid"
+    assert L.mcq_logits_refine(None, 4, None, 1.0, 4, 512, 64, 1, None, None, None, 0, None, 0) == m.MCQ_EUNSUPPORTED
+    assert L.mcq_logits_refine_codes(None, 4, None, 1.0, 4, 512, 64, 1, None, None, None, None, 0, None, 0) == m.MCQ_EUNSUPPORTED
+    assert L.mcq_decode_backward_u8(None, None, 4, 4, 512, 64, None, None) == m.MCQ_EUNSUPPORTED
+    assert L.mcq_decode_backward_u8_ex(None, None, 4, 4, 512, 64, None, None, None, 1.0, None, None, None) == m.MCQ_EUNSUPPORTED
+    assert L.mcq_decode_backward_u8(None, None, 4, 4, 256, 64, None, None) == m.MCQ_EINVAL
+    assert L.mcq_loss_fwd(None, None, 4, 4, 512, None, None, None, None, None, 0, None) == m.MCQ_EUNSUPPORTED
+    assert L.mcq_profile_encode(None, 4, None, 1.0, 8, 256, 64, 1, None, 0, None, None, None, 0) == m.MCQ_EINVAL     # no output array
 
 
 def test_module_api_surface_and_state_dict():

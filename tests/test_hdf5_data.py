@@ -44,9 +44,17 @@ def test_read_hdf5_data_from_a_file(monkeypatch):
 def test_split_equals_the_reference(monkeypatch):
     exp = json.load(open(os.path.join(G, "hdf5_split_expected.json")))
     sets = synthetic_archive()
+    closed = []
+
     class FakeArchive:                      # the datasets handed over in memory: the test is about stack / shuffle / split
         def __init__(self, fn):
             self.names = list(sets.keys())
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *exc):
+            closed.append(True)
 
         def shape(self, k):
             return sets[k].shape
@@ -57,6 +65,7 @@ def test_split_equals_the_reference(monkeypatch):
     monkeypatch.setattr(hdf5_data, "_Archive", FakeArchive)
     np.random.seed(exp["seed"])
     train, valid = read_hdf5_data("in-memory")
+    assert closed == [True]                 # the archive is released once the frames are copied out
     assert list(train.shape) == exp["train_shape"] and list(valid.shape) == exp["valid_shape"]
     assert str(train.dtype) == exp["dtype"]
     assert hashlib.sha256(train.contiguous().numpy().tobytes()).hexdigest() == exp["train_sha256"]
@@ -65,9 +74,17 @@ def test_split_equals_the_reference(monkeypatch):
 
 def test_inconsistent_dim_asserts(monkeypatch):
     sets = {"a": np.zeros((4, 8), np.float16), "b": np.zeros((4, 6), np.float16)}
+    closed = []
+
     class FakeArchive:                      # the datasets handed over in memory: the test is about stack / shuffle / split
         def __init__(self, fn):
             self.names = list(sets.keys())
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *exc):
+            closed.append(True)
 
         def shape(self, k):
             return sets[k].shape
@@ -85,3 +102,26 @@ def test_not_an_hdf5_file(tmp_path):
     p.write_bytes(b"not hdf5" * 100)
     with pytest.raises(Hdf5FormatError):
         MiniHdf5File(str(p))
+
+
+def test_broken_files_raise_the_format_error(tmp_path):
+    from quantization_amd.hdf5_data import Hdf5FormatError, MiniHdf5File
+    empty = tmp_path / "empty.h5"
+    empty.write_bytes(b"")
+    with pytest.raises(Hdf5FormatError):
+        MiniHdf5File(str(empty))
+    junk = tmp_path / "junk.h5"
+    junk.write_bytes(b"x" * 4096)
+    with pytest.raises(Hdf5FormatError):
+        MiniHdf5File(str(junk))
+
+
+def test_the_archive_is_closed_after_reading(tmp_path):
+    import glob
+    from quantization_amd.hdf5_data import MiniHdf5File
+    src = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "hdf5", "*.hdf5")) +
+                 glob.glob(os.path.join(os.path.dirname(__file__), "golden", "hdf5", "*.h5")))[0]
+    with MiniHdf5File(src) as f:
+        names = f.keys()
+        a = np.array(f.read(names[0]))       # a copy: the mapping can go
+    assert f.buf is None and a.size > 0
