@@ -285,6 +285,11 @@ def main(which):
         # a state trained by the reference at the BASELINE dim (config B / E shape): 200 + 200 iterations of 256 frames
         gen_trained("trained_d512_b8", D=512, bytes_per_frame=8, p1=200, p2=200, batch=256, seed=16, n_test=2048,
                     x_kind="make_x", iters_list=(0, 1, 5), reorder=True, keep=("p2",))
+    if which in ("all", "d512_offset"):
+        # Round 5 ("what's weak" 1): the offset case AT THE HEADLINE DIM -- the reference trained on frames with a
+        # common offset of 10, dim 512 / 8 bytes, 200 + 200 iterations, 2,048 held-out rows with margins and reorder noise
+        gen_trained("stress_mean10_d512_b8", D=512, bytes_per_frame=8, p1=200, p2=200, batch=256, seed=17, n_test=2048,
+                    x_kind="mean10", iters_list=(0, 1, 5), reorder=True, keep=("p2",))
     if which in ("all", "configs"):
         # BASELINE.json config shapes (A, B, D) with seeded synthetic states
         gen_synth("config_a_d256_n4", 256, 256, 4, 1024, 101, 102, [0, 1, 5])

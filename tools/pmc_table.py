@@ -6,7 +6,7 @@ root = sys.argv[1]
 flt = sys.argv[2] if len(sys.argv) > 2 else "mcq::"
 tab = collections.defaultdict(lambda: collections.defaultdict(list))
 dur = collections.defaultdict(list)
-for f in glob.glob(os.path.join(root, "*", "*", "*counter_collection.csv")):
+for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
         if flt not in n: continue
