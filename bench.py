@@ -102,6 +102,16 @@ CATEGORY_KERNELS = {"logits_product_argmax": "k_fgemm<1>", "xc_product": "k_fgem
                     "combine_upper_levels": "k_tf_comb3<"}
 
 
+def category_kernels(N):
+    """the map for a run whose every launch has N codebooks: with 16 the cousin tables of level 3 are a k_tf_table1 launch of
+    their own (category tables_upper_levels); the level-2 ones ride in k_tf_level1"""
+    m = dict(CATEGORY_KERNELS)
+    if N == 16:
+        m["tables_upper_levels"] = "k_tf_table1<"
+        del m["tables_level1"]
+    return m
+
+
 def profile_kernels(L, q, x, B, D, N, K, iters, dev, reps=3):
     """{category: launches, avg ms, work figures} of one encode: mcq_profile_encode (HIP events on the launch stream)."""
     with torch.no_grad():          # inference flavour of the derived state (host-side scale factors)
@@ -120,12 +130,16 @@ def profile_kernels(L, q, x, B, D, N, K, iters, dev, reps=3):
         acc[:ncat] += np.array(ms[:ncat])
         launches[:ncat] = np.array(cnt[:ncat])
     acc /= reps
-    work = kernel_work(B, D, N, K)
+    # a large per-vector workspace share cuts the batch into chunks (dim 1024 / 16 codebooks: two of 32,768): every launch
+    # then covers one chunk, and so must the work figures it is priced with
+    names = [L.mcq_profile_category_name(i).decode() for i in range(ncat)]
+    chunks = max(1, int(launches[names.index("frames_to_limbs")])) if "frames_to_limbs" in names else 1
+    work = kernel_work(B // chunks, D, N, K)
     kernels = {}
     for i in range(ncat):
         if launches[i] == 0:
             continue
-        name = L.mcq_profile_category_name(i).decode()
+        name = names[i]
         fl, by, tb = work[name]
         avg_ms = max(acc[i], 1e-9) / launches[i]
         kernels[name] = {"launches_per_encode": int(launches[i]), "avg_ms": round(float(avg_ms), 4),
@@ -139,6 +153,7 @@ def profile_kernels(L, q, x, B, D, N, K, iters, dev, reps=3):
             kernels[name].update(hbm_gbyte_per_launch=round(by / 1e9, 3), hbm_gbytes_per_s=round(by / (avg_ms * 1e-3) / 1e9, 1))
             if tb > 0:
                 kernels[name].update(table_gbyte_per_launch=round(tb / 1e9, 3), table_gbytes_per_s_from_l2=round(tb / (avg_ms * 1e-3) / 1e9, 1))
+        kernels[name]["vectors_per_launch"] = B // chunks
     return kernels
 
 
@@ -185,7 +200,7 @@ def pmc_live(D, N, B, iters, budget_s=200.0):
     if not done:
         return None
     out = {}
-    for cat, prefix in CATEGORY_KERNELS.items():
+    for cat, prefix in category_kernels(N).items():
         names = [n for n in vals if n.startswith(prefix)]
         if not names:
             continue
@@ -532,7 +547,7 @@ def main():
                 pmc, pmc_src = pmc_all[dom_name], "live: rocprofv3 --kernel-trace --pmc child runs of this command (bench.py pmc_live)"
         if pmc is None:
             pmc, pmc_src = pmc_committed(dom_name, D, N, K, B, iters)
-        roofline = roofline_of(dom_name, kernels[dom_name], kernel_work(B, D, N, K)[dom_name], pmc, pmc_src)
+        roofline = roofline_of(dom_name, kernels[dom_name], kernel_work(kernels[dom_name]["vectors_per_launch"], D, N, K)[dom_name], pmc, pmc_src)
 
     fpv = reference_flops_per_vector(D, N, K, iters)
     exec_fpv = 2 * 2.0 * D * N * K          # the logits and x.C products only (each multiply-add = ten i8 limb products)
@@ -649,7 +664,7 @@ def main():
                 kk = profile_kernels(L, qc, xc_, b_, d_, n_, 256, 5, dev, reps=1)
                 dn = max(kk, key=lambda n__: kk[n__]["ms_per_encode"])
                 pm, pm_src = pmc_committed(dn, d_, n_, 256, b_, 5)
-                cfgs[name]["roofline"] = roofline_of(dn, kk[dn], kernel_work(b_, d_, n_, 256)[dn], pm, pm_src)
+                cfgs[name]["roofline"] = roofline_of(dn, kk[dn], kernel_work(kk[dn]["vectors_per_launch"], d_, n_, 256)[dn], pm, pm_src)
                 cfgs[name]["kernels_ms_per_encode"] = {k_: v_["ms_per_encode"] for k_, v_ in kk.items()}
             del xc_, cc
             if qc is not q:

@@ -424,6 +424,22 @@ const char *const kCatNames[CAT_COUNT] = {
         }                                                                                                    \
         if (!s_) hipLaunchKernelGGL(BIGK, grid, block, 0, st, __VA_ARGS__);                                  \
     } while (0)
+// the level-1 table builders in their lean form (mcq_tf_kernels.h, tf_table1_lean: one-byte entries, lists of 16); LEANK is the
+// same kernel with LEAN = true.  MCQ_TABLE1_LEAN=1 selects it (tuning hook; identical results, see table1_lean())
+#define MCQ_TF_LAUNCH3(SMALLK, BIGK, LEANK, grid, block, ...)                                                \
+    do {                                                                                                     \
+        bool s_ = false;                                                                                     \
+        if constexpr (sizeof(CT) == 1) {                                                                     \
+            if (small) { hipLaunchKernelGGL(SMALLK, grid, block, 0, st, __VA_ARGS__); s_ = true; }           \
+            else if (table1_lean()) { hipLaunchKernelGGL(LEANK, grid, block, 0, st, __VA_ARGS__); s_ = true; } \
+        }                                                                                                    \
+        if (!s_) hipLaunchKernelGGL(BIGK, grid, block, 0, st, __VA_ARGS__);                                  \
+    } while (0)
+
+inline bool table1_lean() {      // opt-in: measured equal at 8 codebooks, 2 % slower at 16 (profiles/r05_ab_table1_lean.txt)
+    static const bool on = getenv("MCQ_TABLE1_LEAN") && atoi(getenv("MCQ_TABLE1_LEAN")) != 0;
+    return on;
+}
 
 template <typename CT>
 int run_tf_combines(const float *G, const CT *idx_cur, CT *idx_new, const WorkspaceT<CT> &w, const TfLists &L, long B, int N,
@@ -453,7 +469,7 @@ int run_tf_combines(const float *G, const CT *idx_cur, CT *idx_new, const Worksp
         const int ntab3 = fuse_l3 ? 16 : 1, per3 = fuse_l3 ? 4 : 1;
         const dim3 grid(pair_blocks + tab_blocks + (fuse_l3 ? (unsigned)(B * ntab3) : 0u));
         if (prof) prof->begin(CAT_LEVEL1_FUSED);
-        MCQ_TF_LAUNCH2((k_tf_level1<8, 8, CT>), (k_tf_level1<16, 16, CT>), grid, dim3(64), G, idx_cur, w.E, L, B, N, K, keep, ntab1, per1, w.tabs[0],
+        MCQ_TF_LAUNCH3((k_tf_level1<8, 8, CT>), (k_tf_level1<16, 16, CT>), (k_tf_level1<16, 16, CT, true>), grid, dim3(64), G, idx_cur, w.E, L, B, N, K, keep, ntab1, per1, w.tabs[0],
                        nact, pair_blocks, tab_blocks, ntab3, per3, w.tabs[1]);
         MCQ_LAUNCH_CHECK();
         if (prof) prof->end(CAT_LEVEL1_FUSED);
@@ -462,7 +478,7 @@ int run_tf_combines(const float *G, const CT *idx_cur, CT *idx_new, const Worksp
         CT *fin = (N == 4) ? idx_new : nullptr;
         const dim3 grid((unsigned)(B * (N / 4)));
         if (prof) prof->begin(CAT_LEVEL1);
-        MCQ_TF_LAUNCH2((k_tf_pair1<8, 8, CT>), (k_tf_pair1<16, 16, CT>), grid, dim3(64), G, idx_cur, w.E, L, B, N, K, keep, fin, nact);
+        MCQ_TF_LAUNCH3((k_tf_pair1<8, 8, CT>), (k_tf_pair1<16, 16, CT>), (k_tf_pair1<16, 16, CT, true>), grid, dim3(64), G, idx_cur, w.E, L, B, N, K, keep, fin, nact);
         MCQ_LAUNCH_CHECK();
         if (prof) prof->end(CAT_LEVEL1);
     }
@@ -475,7 +491,7 @@ int run_tf_combines(const float *G, const CT *idx_cur, CT *idx_new, const Worksp
         const int cat_tab = (v == 2) ? CAT_TABLES : CAT_TABLES_UP, cat_comb = (v == 2) ? CAT_COMBINE : CAT_COMBINE_UP;
         if (!(fuse_l1 && v == 2) && !(fuse_l3 && v == 3)) {     // (these tables came with the level-1 combines)
             if (prof) prof->begin(cat_tab);
-            MCQ_TF_LAUNCH2((k_tf_table1<8, 8, CT>), (k_tf_table1<16, 16, CT>), dim3((unsigned)(B * ntab1)), dim3(64), G, idx_cur, L, B, N, K, ntab1, per1,
+            MCQ_TF_LAUNCH3((k_tf_table1<8, 8, CT>), (k_tf_table1<16, 16, CT>), (k_tf_table1<16, 16, CT, true>), dim3((unsigned)(B * ntab1)), dim3(64), G, idx_cur, L, B, N, K, ntab1, per1,
                            w.tabs[0], nact);
             MCQ_LAUNCH_CHECK();
             if (prof) prof->end(cat_tab);
@@ -505,6 +521,7 @@ int run_tf_combines(const float *G, const CT *idx_cur, CT *idx_new, const Worksp
     return 0;
 }
 #undef MCQ_TF_LAUNCH2
+#undef MCQ_TF_LAUNCH3
 
 template <typename CT>
 int run_encode_t(const float *x, long B, const void *prepared, float lscale, int N, int K, int D, int iters,

@@ -188,7 +188,9 @@ k_tf_stage0(const float *__restrict__ G, const float *__restrict__ XC, const tf_
 #pragma unroll
         for (int i = 0; i < VPL; ++i) { xcv[i] = xc[i]; qv[i] = q[i]; }
     }
-    const float Rv = R[b * N + n];
+    // (b is the same for the whole wave, which the compiler cannot see: through readfirstlane this one float is a scalar load
+    // instead of a vector load every lane takes part in)
+    const float Rv = R[(long)__builtin_amdgcn_readfirstlane((int)b) * N + n];
     __builtin_amdgcn_sched_barrier(0);                      // (the scheduler otherwise sinks the x.C read below the Gram reads)
     // the vector's N index bytes: one scalar load per 8 of them (the vector is the same for the whole wave) instead of N - 1
     // byte loads per lane; the Gram row addresses are then scalar too
@@ -672,10 +674,124 @@ __device__ __forceinline__ void tf_table1(const float *__restrict__ G, const CT 
     }
 }
 
+
+// ------------------------------------------------ level-1 tables, lean form (round 5; opt-in: MCQ_TABLE1_LEAN=1)
+// An experiment that is kept because of what it rules out.  k_tf_level1 issues 522 VALU instructions per wave, and 522 x 4
+// clocks x its waves / 4 SIMDs equals its duration to 1.5 % (profiles/r04_pmc_counters.txt): it looked bound by VALU issue.
+// tf_table1 above spends most of those instructions on bookkeeping -- a division per gathered entry to unflatten the compact
+// |A| x |B| grid, four lane-role borders per wave, compares and selects round every LDS access.  This form builds the same
+// tables, entry by entry from the same expression (so the same bits: tests/test_gpu_parity.py runs both), with the lanes laid out
+// so that nearly every address is `a constant of the lane + an immediate`:
+//   * lane = 16 r + c covers compact row 4 it + r, compact column c of a leaf: slot (table, it) gathers a 4 x |B| stripe --
+//     no division, the row entries of a stripe are one LDS byte read shared by the two tables of the same row codebook, the
+//     column entries two reads per wave; a gather's address is one add of a row part and a column part
+//   * the borders of all four tables are two gathers: quarter q of the wave = table q, lane c of the quarter = compact row
+//     (u = G[s_i][o_m], read through the symmetry of G as above) resp. compact column (v = G[o_n][s_j]); the four corner
+//     values w = G[o_n][o_m] have wave-uniform addresses: scalar loads
+//   * ((g - u) - v) + w is formed with u, v from LDS at immediate offsets and stored at an immediate offset
+// HALF the VALU instructions (k_tf_table1: 607 -> 302 static, k_tf_level1 2,659 -> 1,298) -- and the same time: 378.1 against
+// 377.9 us per launch at 8 x 256 / 65,536 vectors, 22.9 against 22.4 ms per encode at 16 x 256 (same box, interleaved:
+// profiles/r05_ab_table1_lean.txt).  The kernel does not wait for its VALU count; nor for the number of L1 accesses (r05_ab_l1_diet.txt).
+// One-byte entries, lists of 16 (K >= 32, <= 256).
+__device__ __forceinline__ void tf_table1_lean(const float *__restrict__ G, const uint8_t *__restrict__ idx, const TfLists &L,
+                                               long b, int N, int K, int X, int Y, float *leaf /* LDS [4][LS] + bytes */,
+                                               float (&t)[4]) {
+    constexpr int KCH = 16, KC = 16, RS = KCH + 1, BO = KCH * RS, LS = BO + 36;
+    const int lane = lane_id();
+    const uint8_t *id = idx + b * N;
+    const uint8_t *ent = L.ent;
+    const int G1 = N >> 1;
+    const uint8_t *px = L.pos[1] + ((b * G1 + X) * KC) * 2, *py = L.pos[1] + ((b * G1 + Y) * KC) * 2;
+    uint8_t *cent = reinterpret_cast<uint8_t *>(leaf + 4 * LS);     // [4][16] compact list -> codebook entry
+    uint8_t *crank = cent + 64;                                     // [4][16] candidate -> compact rank of its leaf
+    const int NK = N * K;
+    const int nksh = __builtin_ctz((unsigned)NK);
+    const int w = lane >> 4, c = lane & 15;
+    const int cb = (w < 2) ? 2 * X + w : 2 * Y + (w - 2);           // this quarter's codebook
+    int mypos = (w < 2 ? px : py)[2 * c + (w & 1)];
+    int myent = ent[(b * N + cb) * KCH + c];
+    int oldv = id[cb];
+    asm volatile("" : "+v"(mypos), "+v"(myent), "+v"(oldv));
+    int oldq[4];
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) oldq[qq] = __builtin_amdgcn_readlane(oldv, 16 * qq);
+    uint32_t m = 1u << mypos;
+    m |= (uint32_t)dpp_i<0x121>((int)m);
+    m |= (uint32_t)dpp_i<0x122>((int)m);
+    m |= (uint32_t)dpp_i<0x124>((int)m);
+    m |= (uint32_t)dpp_i<0x128>((int)m);
+    crank[lane] = (uint8_t)__popc(m & ((1u << mypos) - 1u));
+    if ((m >> c) & 1u) cent[w * 16 + __popc(m & ((1u << c) - 1u))] = (uint8_t)myent;
+    int nn[4];                                                      // |A| of codebooks 2X, 2X+1; |B| of 2Y, 2Y+1
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) nn[qq] = __popc((uint32_t)__builtin_amdgcn_readlane((int)m, 16 * qq));
+    wave_lds_fence();
+    const uint32_t rown0 = (uint32_t)(2 * X * K), colm0 = (uint32_t)(2 * Y * K);
+    // ---- borders: quarter w = table (a = w >> 1, cc = w & 1), lane c = compact row / column
+    const bool hi_a = (lane & 32) != 0, hi_c = (lane & 16) != 0;
+    const uint32_t rownL = rown0 + (hi_a ? (uint32_t)K : 0u), colmL = colm0 + (hi_c ? (uint32_t)K : 0u);
+    const uint32_t onL = (uint32_t)(hi_a ? oldq[1] : oldq[0]), omL = (uint32_t)(hi_c ? oldq[3] : oldq[2]);
+    // (compact slots beyond |A| / |B| hold stale bytes: kept inside the codebook, their values are never used)
+    const uint32_t km = (uint32_t)(K - 1);
+    const uint32_t eu = cent[((lane >> 5) << 4) + c] & km, ev = cent[32 + (((lane >> 4) & 1) << 4) + c] & km;
+    // u: G[s_i][o_m] read as G[o_m][s_i] (bit-identical: G is symmetric); v: G[o_n][s_j]
+    const float bu = G[((colmL + omL) << nksh) + rownL + eu];
+    const float bvv = G[((rownL + onL) << nksh) + colmL + ev];
+    float wq[4];
+#pragma unroll
+    for (int tb = 0; tb < 4; ++tb) {
+        const int a = tb >> 1, cc = tb & 1;
+        wq[tb] = G[((size_t)(rown0 + a * K + oldq[a]) << nksh) + colm0 + cc * K + oldq[2 + cc]];      // wave-uniform address
+    }
+    // ---- core gathers: slot (tb, it) = rows 4 it .. 4 it + 3 of table tb, all its columns
+    const uint32_t ec0 = cent[32 + c], ec1 = cent[48 + c];
+    const uint32_t colp[2] = {colm0 + ec0, colm0 + (uint32_t)K + ec1};
+    const bool cok[2] = {c < nn[2], c < nn[3]};
+    float g[4][4];
+    bool on[4][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const bool rok = 4 * it + w < nn[a];
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) { on[2 * a + cc][it] = rok && cok[cc]; g[2 * a + cc][it] = 0.f; }
+            if (4 * it < nn[a]) {             // wave-uniform
+                const uint32_t er = cent[a * 16 + 4 * it + w];
+                const uint32_t rowp = (rown0 + (uint32_t)(a * K) + er) << nksh;
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc)
+                    if (on[2 * a + cc][it]) g[2 * a + cc][it] = G[rowp + colp[cc]];
+            }
+        }
+    leaf[w * LS + BO + c] = bu;               // (beyond |A| / |B|: never read)
+    leaf[w * LS + BO + 16 + c] = bvv;
+    wave_lds_fence();
+#pragma unroll
+    for (int tb = 0; tb < 4; ++tb) {
+        const int a = tb >> 1;
+        float *lt = leaf + tb * LS;
+        const float vj = lt[BO + 16 + c];
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+            if (4 * it < nn[a]) {             // wave-uniform
+                if (on[tb][it]) lt[(4 * it + w) * RS + c] = ((g[tb][it] - lt[BO + 4 * it + w]) - vj) + wq[tb];
+            }
+    }
+    wave_lds_fence();
+    const int i = lane >> 2, j0 = 4 * (lane & 3);
+    const int ri0 = crank[i], ri1 = crank[16 + i];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int rj0 = crank[32 + j0 + v], rj1 = crank[48 + j0 + v];
+        t[v] = ((leaf[ri0 * RS + rj0] + leaf[LS + ri0 * RS + rj1]) + leaf[2 * LS + ri1 * RS + rj0]) + leaf[3 * LS + ri1 * RS + rj1];
+    }
+}
+
 constexpr int tf_leaf_lds_floats(int KCH, int code_bytes = 1) { return 4 * (KCH * (KCH + 1) + 36) + 16 + 16 * code_bytes; }
 
 // combine of level 1: siblings X = 2g, Y = 2g + 1 (pairs of codebooks).  One wave per (b, g).
-template <int KCH, int KC, typename CT = uint8_t>
+template <int KCH, int KC, typename CT = uint8_t, bool LEAN = false>
 __device__ __forceinline__ void tf_pair1_body(unsigned bid, float *leaf, const float *__restrict__ G, const CT *__restrict__ idx,
                                               const float *__restrict__ E, const TfLists &L, long B, int N, int K, int keep,
                                               CT *__restrict__ idx_final, const int *__restrict__ nact) {
@@ -698,7 +814,8 @@ __device__ __forceinline__ void tf_pair1_body(unsigned bid, float *leaf, const f
 #pragma unroll
     for (int v = 0; v < VPL; ++v) so[v] = L.S[1][(b * G1 + Y) * KC + j0 + v];
     float t[VPL];
-    tf_table1<KCH, KC, CT>(G, idx, L, b, N, K, X, Y, leaf, t);
+    if constexpr (LEAN && KCH == 16 && KC == 16 && sizeof(CT) == 1) tf_table1_lean(G, idx, L, b, N, K, X, Y, leaf, t);
+    else tf_table1<KCH, KC, CT>(G, idx, L, b, N, K, X, Y, leaf, t);
     float sv[VPL];
     int sp[VPL];
 #pragma unroll
@@ -710,18 +827,18 @@ __device__ __forceinline__ void tf_pair1_body(unsigned bid, float *leaf, const f
     tf_finish<VPL, CT>(sv, sp, keep, KC, scratch, L, 2, b, N, g, idx_final);
 }
 
-template <int KCH, int KC, typename CT = uint8_t>
+template <int KCH, int KC, typename CT = uint8_t, bool LEAN = false>
 __global__ void __launch_bounds__(64)
 k_tf_pair1(const float *__restrict__ G, const CT *__restrict__ idx, const float *__restrict__ E, TfLists L, long B,
            int N, int K, int keep, CT *__restrict__ idx_final, const int *__restrict__ nact) {
     __shared__ __attribute__((aligned(16))) float leaf[tf_leaf_lds_floats(KCH, sizeof(CT))];
-    tf_pair1_body<KCH, KC, CT>(blockIdx.x, leaf, G, idx, E, L, B, N, K, keep, idx_final, nact);
+    tf_pair1_body<KCH, KC, CT, LEAN>(blockIdx.x, leaf, G, idx, E, L, B, N, K, keep, idx_final, nact);
 }
 
 // T_1 of COUSIN pairs under the siblings of a higher level -> tabs[b][t][KC*KC].  One wave per (b, t); workgroup id
 // mod ntab = t, so an XCD reads the leaf blocks of its own tables only.  Under sibling pair g each side has `per`
 // level-1 groups: t = (g * per + a) * per + c  ->  X = 2 g per + a,  Y = (2 g + 1) per + c.
-template <int KCH, int KC, typename CT = uint8_t>
+template <int KCH, int KC, typename CT = uint8_t, bool LEAN = false>
 __device__ __forceinline__ void tf_table1_body(unsigned bid, float *leaf, const float *__restrict__ G, const CT *__restrict__ idx,
                                                const TfLists &L, long B, int N, int K, int ntab, int per, float *__restrict__ tabs,
                                                const int *__restrict__ nact) {
@@ -735,7 +852,8 @@ __device__ __forceinline__ void tf_table1_body(unsigned bid, float *leaf, const 
     const int c = t & (per - 1), a = (t >> psh) & (per - 1), g = t >> (2 * psh);
     const int X = 2 * g * per + a, Y = (2 * g + 1) * per + c;
     float tv[VPL];
-    tf_table1<KCH, KC, CT>(G, idx, L, b, N, K, X, Y, leaf, tv);
+    if constexpr (LEAN && KCH == 16 && KC == 16 && sizeof(CT) == 1) tf_table1_lean(G, idx, L, b, N, K, X, Y, leaf, tv);
+    else tf_table1<KCH, KC, CT>(G, idx, L, b, N, K, X, Y, leaf, tv);
     float *dst = tabs + ((size_t)(b * ntab + t) * (KC * KC) + VPL * lane);
     if constexpr (VPL == 4) {
         __builtin_nontemporal_store((f32x4){tv[0], tv[1], tv[2], tv[3]}, reinterpret_cast<f32x4 *>(dst));
@@ -745,26 +863,26 @@ __device__ __forceinline__ void tf_table1_body(unsigned bid, float *leaf, const 
     }
 }
 
-template <int KCH, int KC, typename CT = uint8_t>
+template <int KCH, int KC, typename CT = uint8_t, bool LEAN = false>
 __global__ void __launch_bounds__(64)
 k_tf_table1(const float *__restrict__ G, const CT *__restrict__ idx, TfLists L, long B, int N, int K, int ntab,
             int per, float *__restrict__ tabs, const int *__restrict__ nact) {
     __shared__ __attribute__((aligned(16))) float leaf[tf_leaf_lds_floats(KCH, sizeof(CT))];
-    tf_table1_body<KCH, KC, CT>(blockIdx.x, leaf, G, idx, L, B, N, K, ntab, per, tabs, nact);
+    tf_table1_body<KCH, KC, CT, LEAN>(blockIdx.x, leaf, G, idx, L, B, N, K, ntab, per, tabs, nact);
 }
 
 // The sibling combines of level 1 and the cousin tables the level-2 combine needs, in ONE launch: both read the level-1 lists
 // and nothing of each other; the workgroup-to-XCD mapping of both kinds is what it is in their own launches (the pair
 // blocks are a multiple of 8).
-template <int KCH, int KC, typename CT = uint8_t>
+template <int KCH, int KC, typename CT = uint8_t, bool LEAN = false>
 __global__ void __launch_bounds__(64)
 k_tf_level1(const float *__restrict__ G, const CT *__restrict__ idx, const float *__restrict__ E, TfLists L, long B, int N,
             int K, int keep, int ntab, int per, float *__restrict__ tabs, const int *__restrict__ nact, unsigned pair_blocks,
             unsigned tab_blocks, int ntab2, int per2, float *__restrict__ tabs2) {
     __shared__ __attribute__((aligned(16))) float leaf[tf_leaf_lds_floats(KCH, sizeof(CT))];
-    if (blockIdx.x < pair_blocks) tf_pair1_body<KCH, KC, CT>(blockIdx.x, leaf, G, idx, E, L, B, N, K, keep, nullptr, nact);
-    else if (blockIdx.x < pair_blocks + tab_blocks) tf_table1_body<KCH, KC, CT>(blockIdx.x - pair_blocks, leaf, G, idx, L, B, N, K, ntab, per, tabs, nact);
-    else tf_table1_body<KCH, KC, CT>(blockIdx.x - pair_blocks - tab_blocks, leaf, G, idx, L, B, N, K, ntab2, per2, tabs2, nact);   // (16 codebooks: the tables of level 3 as well)
+    if (blockIdx.x < pair_blocks) tf_pair1_body<KCH, KC, CT, LEAN>(blockIdx.x, leaf, G, idx, E, L, B, N, K, keep, nullptr, nact);
+    else if (blockIdx.x < pair_blocks + tab_blocks) tf_table1_body<KCH, KC, CT, LEAN>(blockIdx.x - pair_blocks, leaf, G, idx, L, B, N, K, ntab, per, tabs, nact);
+    else tf_table1_body<KCH, KC, CT, LEAN>(blockIdx.x - pair_blocks - tab_blocks, leaf, G, idx, L, B, N, K, ntab2, per2, tabs2, nact);   // (16 codebooks: the tables of level 3 as well)
 }
 
 // copy COUNT tables of KH x KH floats each from global memory (rows of KH) to LDS (rows of KH + 1: the odd row stride keeps the

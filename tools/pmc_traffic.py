@@ -5,7 +5,8 @@ import collections, csv, glob, json, os, re, sys
 root = sys.argv[1]
 DIM, NCB = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (512, 8)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from bench import CATEGORY_KERNELS as KERNELS      # category -> kernel-name prefix (the same map bench.py's live read uses)
+from bench import category_kernels      # category -> kernel-name prefix (the same map bench.py's live read uses)
+KERNELS = category_kernels(NCB)
 vals = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
