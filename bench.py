@@ -720,6 +720,26 @@ def main():
     if world == 1:
         ms_t, _ = trainer_leg(dev, D, N, 4096, 60)
         out["trainer_step"] = dict(ms_t, batch=4096, note="QuantizerTrainer.step, fused (autograd-free) path, free-running")
+        # BASELINE config E at its length: the trainer's DEFAULT schedule (10,000 + 10,000 iterations, quantization.py:581-583),
+        # batches of 4,096 fresh Gaussian frames (tests/test_gpu_trainer_long.py checks what such a run converges to)
+        from quantization_amd import QuantizerTrainer
+        random.seed(0)
+        torch.manual_seed(0)
+        tr = QuantizerTrainer(dim=D, bytes_per_frame=N, device=dev)
+        gq = torch.Generator(device=dev)
+        gq.manual_seed(1)
+        torch.cuda.synchronize()
+        t5 = time.perf_counter()
+        nsteps = 0
+        while not tr.done():
+            tr.step(torch.randn(4096, D, device=dev, generator=gq))
+            nsteps += 1
+        torch.cuda.synchronize()
+        tot = time.perf_counter() - t5
+        out["trainer_step"]["config_e"] = {"steps": nsteps, "trainer_total_s": round(tot, 2), "ms_per_step": round(tot / nsteps * 1e3, 4),
+                                           "frames_per_s": round(nsteps * 4096 / tot, 1),
+                                           "note": "QuantizerTrainer(dim=512, bytes_per_frame=8) with its default 10,000 + 10,000 iterations "
+                                                   "on one GPU, 4,096 frames per step, frame generation included"}
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(state, D)
     print(json.dumps(out), flush=True)

@@ -751,3 +751,39 @@ def test_compute_loss_of_a_512_entry_quantizer_follows_the_reference():
             want = z[f"grad_it{iters}.{name}"]
             g = p.grad.detach().cpu().numpy()
             assert np.linalg.norm(g - want) <= 1e-3 * np.linalg.norm(want) + 1e-7, (iters, name)
+
+
+def test_lean_level1_tables_give_the_same_codes():
+    """MCQ_TABLE1_LEAN=1 (mcq_tf_kernels.h, tf_table1_lean: the level-1 tables with half the VALU instructions; opt-in because it
+    is no faster) is read once per process, so the variant runs in a child: every shape whose combine tree has level-1 tables
+    over lists of 16 (4, 8 and 16 codebooks of 64 and 256 entries), bit-exact against the oracle."""
+    import subprocess
+    import sys
+    code = r'''
+import sys
+import numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from golden import fixtures
+from oracle.oracle import OracleQuantizer
+from quantization_amd import Quantizer
+for name in ("config_a_d256_n4", "trained_d64_b8_p2", "synth_d40_k64_n8", "synth_d64_k256_n16", "stress_mean10_d64_b8_p2"):
+    fx = fixtures.load(name)
+    st = fx["state"]
+    q = Quantizer(fx["D"], fx["K"], fx["N"])
+    sd = q.state_dict()
+    for k, v in st.items():
+        sd[k] = torch.from_numpy(np.asarray(v))
+    q.load_state_dict(sd)
+    q = q.cuda()
+    o = OracleQuantizer(st["centers"], float(st["centers_scale"]), st["to_logits.weight"], st["to_logits.bias"], float(st["logits_scale"]))
+    x = torch.from_numpy(fx["x"]).cuda()
+    for it in (1, 5):
+        with torch.no_grad():
+            got = q.encode(x, it, as_bytes=False).cpu().numpy()
+        want = o.compute_indexes(fx["x"], it)
+        assert np.array_equal(got, want), (name, it, int((got != want).any(axis=1).sum()))
+print("lean ok")
+''' % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, MCQ_TABLE1_LEAN="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "lean ok" in r.stdout, r.stderr[-3000:]
