@@ -1312,6 +1312,22 @@ int mcq_test_select(const float *scores, int cases, int per_lane, int cnt, float
     return e == hipSuccess ? 0 : (int)e;
 }
 
+#ifdef MCQ_STAMPS
+// debug build only (-DMCQ_STAMPS, tools/exp_stamps.py): the phase stamps of the sampled waves, [kernel][wave][slot] u64 -> host
+int mcq_debug_stamps(unsigned long long *host_dst, long count, int clear) {
+    const long total = (long)kStampKernels * kStampWaves * kStampSlots;
+    if (count > total) count = total;
+    if (hipDeviceSynchronize() != hipSuccess) return MCQ_EINVAL;
+    if (host_dst && count > 0 &&
+        hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_stamps), (size_t)count * 8, 0, hipMemcpyDeviceToHost) != hipSuccess) return MCQ_EINVAL;
+    if (clear) {
+        void *p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_stamps)) != hipSuccess || hipMemset(p, 0, (size_t)total * 8) != hipSuccess) return MCQ_EINVAL;
+    }
+    return (int)kStampSlots;
+}
+#endif
+
 const char *mcq_profile_category_name(int category) {
     return (category >= 0 && category < CAT_COUNT) ? kCatNames[category] : nullptr;
 }

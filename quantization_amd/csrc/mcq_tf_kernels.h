@@ -49,6 +49,32 @@ __device__ __forceinline__ float shfl_f(float v, int src) {
     return __int_as_float(__builtin_amdgcn_ds_bpermute(src << 2, __float_as_int(v)));
 }
 
+// Phase stamps of sampled waves (a DEBUG build only: hipcc -DMCQ_STAMPS, tools/exp_stamps.py): s_memtime at the phase boundaries
+// of the three large pass kernels, every 64th workgroup, read back through mcq_debug_stamps.  Compiled out otherwise (an empty
+// struct whose calls vanish); it never changes a result.
+#ifdef MCQ_STAMPS
+constexpr int kStampSlots = 8, kStampWaves = 1 << 14, kStampKernels = 4;
+__device__ unsigned long long g_stamps[kStampKernels * kStampWaves * kStampSlots];
+struct Stamps {
+    unsigned long long t[kStampSlots];
+    __device__ __forceinline__ Stamps() { for (int i = 0; i < kStampSlots; ++i) t[i] = 0; t[0] = __builtin_amdgcn_s_memtime(); }
+    // everything requested so far has arrived when the stamp is taken (the build exists to see where a wave's time goes)
+    __device__ __forceinline__ void at(int k) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); t[k] = __builtin_amdgcn_s_memtime(); }
+    __device__ __forceinline__ void flush(int kernel, unsigned wg, int every) {
+        if (wg % (unsigned)every != 0 || (threadIdx.x & 63) != 0 || (threadIdx.x >> 6) != 0) return;
+        const unsigned slot = (wg / (unsigned)every) & (kStampWaves - 1);
+        unsigned long long *d = g_stamps + ((size_t)kernel * kStampWaves + slot) * kStampSlots;
+        t[kStampSlots - 1] = __builtin_amdgcn_s_memtime();
+        for (int i = 0; i < kStampSlots; ++i) d[i] = t[i];
+    }
+};
+#else
+struct Stamps {
+    __device__ __forceinline__ void at(int) {}
+    __device__ __forceinline__ void flush(int, unsigned, int) {}
+};
+#endif
+
 // (|x|^2, the constant of E, is formed by k_fix_rows while it turns the frames into limb planes)
 
 // --------------------------------------------------------------------- E, R
@@ -148,6 +174,7 @@ k_tf_stage0(const float *__restrict__ G, const float *__restrict__ XC, const tf_
     constexpr int NK = N * K;
     constexpr int CH = (N - 1 < 8) ? (N > 1 ? N - 1 : 1) : 8;    // row segments in flight
     __shared__ u64 sel[4][kSelectLdsU64];
+    Stamps stp;
     if (nact) B = *nact;
     // workgroup -> (vector quad, codebook): id mod 8 = the XCD.  Up to 8 codebooks: n = id mod N.  More: the launch runs
     // in N / 8 phases, phase ph covering the codebooks 8 ph .. 8 ph + 7 for every vector, so that an XCD works on ONE column
@@ -243,9 +270,12 @@ k_tf_stage0(const float *__restrict__ G, const float *__restrict__ XC, const tf_
         sv[i] = act ? (Rv + qv[i]) + 2.0f * X : INFINITY;
         sp[i] = act ? k0 + i : kBigPos;
     }
+    stp.at(1);                                  // all rows in, scores formed
     float ov;
     int op;
     wave_select_fast<VPL>(sv, sp, keep, K, sel[threadIdx.x >> 6], ov, op);
+    stp.at(2);                                  // selection done
+    stp.flush(0, blockIdx.x, 16);
     if (N == 1) {                                             // the best entry is the result (:468-469)
         if (lane == 0) idx_final[b] = (CT)op;
         return;
@@ -450,6 +480,7 @@ k_tf_pair0(const float *__restrict__ G, const CT *__restrict__ idx, const float 
            int N, int K, int keep, CT *__restrict__ idx_final, const int *__restrict__ nact) {
     constexpr int VPL = KC * KC / 64;
     __shared__ u64 scratch[kSelectLdsU64];
+    Stamps stp;
     if (nact) B = *nact;
     const int Gout = N >> 1;
     const int g = (int)(blockIdx.x & (unsigned)(Gout - 1));
@@ -465,6 +496,7 @@ k_tf_pair0(const float *__restrict__ G, const CT *__restrict__ idx, const float 
 #pragma unroll
     for (int v = 0; v < VPL; ++v) so[v] = L.S[0][(b * N + m) * KC + j0 + v];
     float d[VPL];
+    stp.at(1);                                  // lists and scores in
     tf_leaf<KC, CT>(G, N * K, K, n, m, en, em, idx[b * N + n], idx[b * N + m], d);
     float sv[VPL];
     int sp[VPL];
@@ -473,7 +505,10 @@ k_tf_pair0(const float *__restrict__ G, const CT *__restrict__ idx, const float 
         sv[v] = ((se + so[v]) - Eb) + 2.0f * d[v];
         sp[v] = VPL * lane + v;
     }
+    stp.at(2);                                  // leaf table gathered, scores formed
     tf_finish<VPL, CT>(sv, sp, keep, KC, scratch, L, 1, b, N, g, idx_final);
+    stp.at(3);                                  // selection done, list written
+    stp.flush(1, blockIdx.x, 64);
 }
 
 // ------------------------------------------------------------ level-1 tables
@@ -489,7 +524,7 @@ k_tf_pair0(const float *__restrict__ G, const CT *__restrict__ idx, const float 
 template <int KCH, int KC, typename CT = uint8_t>
 __device__ __forceinline__ void tf_table1(const float *__restrict__ G, const CT *__restrict__ idx, const TfLists &L,
                                           long b, int N, int K, int X, int Y, float *leaf /* LDS [4][KCH*KCH + 64] */,
-                                          float (&t)[KC * KC / 64]) {
+                                          float (&t)[KC * KC / 64], Stamps &stp) {
     constexpr int VPLH = KCH * KCH / 64, VPL = KC * KC / 64, MH = KCH * KCH;
     const int lane = lane_id();
     const CT *id = idx + b * N;
@@ -516,6 +551,7 @@ __device__ __forceinline__ void tf_table1(const float *__restrict__ G, const CT 
         int myent = ent[(b * N + cb) * KCH + c];                    // entry at level-0 position c of that codebook
         int oldv = id[cb];                                          // current entry of this quarter's codebook
         asm volatile("" : "+v"(mypos), "+v"(myent), "+v"(oldv));
+        stp.at(1);                                                  // list bytes in
         int oldq[4];                                                // current entries of codebooks 2X, 2X+1, 2Y, 2Y+1
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) oldq[qq] = __builtin_amdgcn_readlane(oldv, 16 * qq);
@@ -576,6 +612,7 @@ __device__ __forceinline__ void tf_table1(const float *__restrict__ G, const CT 
                 }
             }
         }
+        stp.at(2);                                                  // masks exchanged, every Gram gather back
 #pragma unroll
         for (int tb = 0; tb < 4; ++tb)
             if (lane <= na_[tb] + nc_[tb]) leaf[tb * LS + BO + lane] = bv[tb];
@@ -599,6 +636,7 @@ __device__ __forceinline__ void tf_table1(const float *__restrict__ G, const CT 
             t[v] = ((leaf[ri0 * RS + rj0] + leaf[LS + ri0 * RS + rj1]) + leaf[2 * LS + ri1 * RS + rj0]) +
                    leaf[3 * LS + ri1 * RS + rj1];
         }
+        stp.at(3);                                                  // leaf tables assembled in LDS, level-1 entries summed
         return;
     } else if constexpr (KCH * KCH == 64) {
         // lists of 8 (16-entry codebooks): a leaf table is one core entry and one border entry per lane.  The four tables
@@ -800,6 +838,7 @@ __device__ __forceinline__ void tf_pair1_body(unsigned bid, float *leaf, const f
     // 7.3 KB per single-wave workgroup, i.e. 29 instead of 22 waves per CU
     static_assert(tf_leaf_lds_floats(KCH, sizeof(CT)) * 4 >= kSelectLdsU64 * 8, "");
     u64 *scratch = reinterpret_cast<u64 *>(leaf);
+    Stamps stp;
     if (nact) B = *nact;
     const int Gout = N >> 2;
     const int g = (int)(bid & (unsigned)(Gout - 1));
@@ -815,7 +854,7 @@ __device__ __forceinline__ void tf_pair1_body(unsigned bid, float *leaf, const f
     for (int v = 0; v < VPL; ++v) so[v] = L.S[1][(b * G1 + Y) * KC + j0 + v];
     float t[VPL];
     if constexpr (LEAN && KCH == 16 && KC == 16 && sizeof(CT) == 1) tf_table1_lean(G, idx, L, b, N, K, X, Y, leaf, t);
-    else tf_table1<KCH, KC, CT>(G, idx, L, b, N, K, X, Y, leaf, t);
+    else tf_table1<KCH, KC, CT>(G, idx, L, b, N, K, X, Y, leaf, t, stp);
     float sv[VPL];
     int sp[VPL];
 #pragma unroll
@@ -825,6 +864,8 @@ __device__ __forceinline__ void tf_pair1_body(unsigned bid, float *leaf, const f
     }
     wave_lds_fence();                                   // the table reads are done before the selection writes there
     tf_finish<VPL, CT>(sv, sp, keep, KC, scratch, L, 2, b, N, g, idx_final);
+    stp.at(4);                                          // selection done, list written
+    stp.flush(2, bid, 64);
 }
 
 template <int KCH, int KC, typename CT = uint8_t, bool LEAN = false>
@@ -843,6 +884,7 @@ __device__ __forceinline__ void tf_table1_body(unsigned bid, float *leaf, const 
                                                const TfLists &L, long B, int N, int K, int ntab, int per, float *__restrict__ tabs,
                                                const int *__restrict__ nact) {
     constexpr int VPL = KC * KC / 64;
+    Stamps stp;
     if (nact) B = *nact;
     const int t = (int)(bid & (unsigned)(ntab - 1));
     const long b = (long)(bid >> __builtin_ctz((unsigned)ntab));
@@ -853,7 +895,7 @@ __device__ __forceinline__ void tf_table1_body(unsigned bid, float *leaf, const 
     const int X = 2 * g * per + a, Y = (2 * g + 1) * per + c;
     float tv[VPL];
     if constexpr (LEAN && KCH == 16 && KC == 16 && sizeof(CT) == 1) tf_table1_lean(G, idx, L, b, N, K, X, Y, leaf, tv);
-    else tf_table1<KCH, KC, CT>(G, idx, L, b, N, K, X, Y, leaf, tv);
+    else tf_table1<KCH, KC, CT>(G, idx, L, b, N, K, X, Y, leaf, tv, stp);
     float *dst = tabs + ((size_t)(b * ntab + t) * (KC * KC) + VPL * lane);
     if constexpr (VPL == 4) {
         __builtin_nontemporal_store((f32x4){tv[0], tv[1], tv[2], tv[3]}, reinterpret_cast<f32x4 *>(dst));
@@ -861,6 +903,8 @@ __device__ __forceinline__ void tf_table1_body(unsigned bid, float *leaf, const 
 #pragma unroll
         for (int v = 0; v < VPL; ++v) dst[v] = tv[v];
     }
+    stp.at(4);                                          // table stored
+    stp.flush(3, bid, 64);
 }
 
 template <int KCH, int KC, typename CT = uint8_t, bool LEAN = false>
