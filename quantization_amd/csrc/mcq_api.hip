@@ -451,7 +451,19 @@ int run_tf_combines(const float *G, const CT *idx_cur, CT *idx_new, const Worksp
         CT *fin = (N == 2) ? idx_new : nullptr;
         const dim3 grid((unsigned)(B * (N / 2)));
         if (prof) prof->begin(CAT_LEVEL0);
-        MCQ_TF_LAUNCH2((k_tf_pair0<8, CT>), (k_tf_pair0<16, CT>), grid, dim3(64), G, idx_cur, w.E, L, B, N, K, keep, fin, nact);
+        bool looped = false;
+        if constexpr (sizeof(CT) == 1) {
+            // opt-in experiment (MCQ_PAIR0_LOOP=1): persistent waves that prefetch their next item's inputs (mcq_tf_kernels.h)
+            static const int loop_waves = getenv("MCQ_PAIR0_LOOP") ? atoi(getenv("MCQ_PAIR0_LOOP")) : 0;
+            if (loop_waves > 0 && !small && N >= 4 && N <= 16 && nact == nullptr && B * (N / 2) < (1L << 31)) {
+                const unsigned items = (unsigned)(B * (N / 2));
+                unsigned waves = loop_waves == 1 ? 8192u : (unsigned)loop_waves * 256u;      // (1: what the chip holds; else waves per CU)
+                if (waves > items) waves = (items + 7u) & ~7u;
+                hipLaunchKernelGGL(k_tf_pair0_loop, dim3(waves), dim3(64), 0, st, G, idx_cur, w.E, L, items, N, K, keep);
+                looped = true;
+            }
+        }
+        if (!looped) MCQ_TF_LAUNCH2((k_tf_pair0<8, CT>), (k_tf_pair0<16, CT>), grid, dim3(64), G, idx_cur, w.E, L, B, N, K, keep, fin, nact);
         MCQ_LAUNCH_CHECK();
         if (prof) prof->end(CAT_LEVEL0);
     }

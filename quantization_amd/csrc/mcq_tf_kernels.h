@@ -511,6 +511,90 @@ k_tf_pair0(const float *__restrict__ G, const CT *__restrict__ idx, const float 
     stp.flush(1, blockIdx.x, 64);
 }
 
+// Level 0 as a persistent loop WITH PREFETCH (round 5 experiment, opt-in: MCQ_PAIR0_LOOP=1).  The phase stamps say a k_tf_pair0
+// wave waits 2.2 k of its 10.9 k clocks for its first inputs (lists the previous launch wrote: they come from beyond the L2).
+// Here 8,192 waves -- what the chip holds -- each walk their items (same sibling pair, same XCD: the stride is a multiple of 8
+// and of the number of pairs) and request the next item's inputs right after the current item's gathers, so that they arrive
+// during its selection (the ISA waits for the gathers with vmcnt(6): the six prefetch loads stay in flight).  Same arithmetic,
+// same codes -- and 0.204 against 0.166 ms per launch at 65,536 vectors, with 16, 24 or 32 waves per CU alike (round 4 measured the
+// same for a loop without prefetch): a wave that lives on does not overlap its phases with its neighbours' the way a stream of
+// fresh waves does.  Kept as the measured answer to "hide the first-input latency".  One-byte entries, lists of 16, not the
+// last combine.
+struct P0In {
+    int e_i, e_b, old_n, old_m;
+    uint32_t w4;
+    float se, Eb;
+    f32x4 so;
+};
+__device__ __forceinline__ P0In p0_load(const uint8_t *__restrict__ idx, const float *__restrict__ E, const TfLists &L, unsigned item,
+                                        int N, int gsh, int lane) {
+    constexpr int KC = 16;
+    const int g = (int)(item & ((1u << gsh) - 1u));
+    const long b = (long)(item >> gsh);
+    const int n = 2 * g, m = n + 1;
+    const uint8_t *en = L.ent + (b * N + n) * KC, *em = en + KC;
+    const int i = lane >> 2, j0 = 4 * (lane & 3);
+    const int bl = lane < 2 * KC ? lane : 2 * KC;
+    P0In r;
+    r.e_i = en[i];
+    r.e_b = *(bl < KC ? en + bl : em + (bl < 2 * KC ? bl - KC : 0));
+    r.w4 = *reinterpret_cast<const uint32_t *>(em + j0);
+    r.old_n = idx[b * N + n];
+    r.old_m = idx[b * N + m];
+    r.se = L.S[0][(b * N + n) * KC + i];
+    r.so = *reinterpret_cast<const f32x4 *>(L.S[0] + (b * N + m) * KC + j0);
+    r.Eb = E[b];
+    return r;
+}
+
+__global__ void __launch_bounds__(64)
+k_tf_pair0_loop(const float *__restrict__ G, const uint8_t *__restrict__ idx, const float *__restrict__ E, TfLists L, unsigned items,
+                int N, int K, int keep) {
+    constexpr int KC = 16;
+    __shared__ u64 scratch[kSelectLdsU64];
+    const int lane = lane_id();
+    const int gsh = __builtin_ctz((unsigned)(N >> 1));
+    const int nksh = __builtin_ctz((unsigned)(N * K));
+    const unsigned stride = gridDim.x;
+    unsigned item = blockIdx.x;
+    if (item >= items) return;
+    const int i = lane >> 2, j0 = 4 * (lane & 3);
+    const int bl = lane < 2 * KC ? lane : 2 * KC;
+    P0In cur = p0_load(idx, E, L, item, N, gsh, lane);
+    for (;;) {
+        const int g = (int)(item & ((1u << gsh) - 1u));
+        const long b = (long)(item >> gsh);
+        const uint32_t rown = (uint32_t)(2 * g * K), colm = rown + (uint32_t)K;
+        // the leaf table of tf_leaf, from the inputs in `cur`
+        const uint32_t si = rown + (uint32_t)cur.e_i;
+        const uint32_t br = bl < KC ? rown + (uint32_t)cur.e_b : rown + (uint32_t)cur.old_n;
+        const uint32_t bc = (bl >= KC && bl < 2 * KC) ? colm + (uint32_t)cur.e_b : colm + (uint32_t)cur.old_m;
+        float gq[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) gq[v] = G[(si << nksh) + colm + ((cur.w4 >> (8 * v)) & 0xffu)];
+        const float bv = G[(br << nksh) + bc];
+        // the next item's inputs: requested behind the gathers, needed only after this item's selection
+        // (unconditionally -- the last iteration re-reads its own item: behind a branch the compiler cannot count the loads in
+        // flight and waits for all of them before it uses the gathers)
+        const unsigned nxt = item + stride;
+        const P0In nx = p0_load(idx, E, L, nxt < items ? nxt : item, N, gsh, lane);
+        const float u = shfl_f(bv, i), w = shfl_f(bv, 2 * KC);
+        float sv[4];
+        int sp[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const float vj = shfl_f(bv, KC + j0 + v);
+            const float d = ((gq[v] - u) - vj) + w;
+            sv[v] = ((cur.se + cur.so[v]) - cur.Eb) + 2.0f * d;
+            sp[v] = 4 * lane + v;
+        }
+        tf_finish<4, uint8_t>(sv, sp, keep, KC, scratch, L, 1, b, N, g, nullptr);
+        if (nxt >= items) break;
+        cur = nx;
+        item = nxt;
+    }
+}
+
 // ------------------------------------------------------------ level-1 tables
 // T_1[X][Y] of two groups of two codebooks (X < Y) over their lists of KC candidates, each entry the sum of four
 // leaf-table entries.  Lane holds positions p = VPL*lane + v.

@@ -753,10 +753,13 @@ def test_compute_loss_of_a_512_entry_quantizer_follows_the_reference():
             assert np.linalg.norm(g - want) <= 1e-3 * np.linalg.norm(want) + 1e-7, (iters, name)
 
 
-def test_lean_level1_tables_give_the_same_codes():
-    """MCQ_TABLE1_LEAN=1 (mcq_tf_kernels.h, tf_table1_lean: the level-1 tables with half the VALU instructions; opt-in because it
-    is no faster) is read once per process, so the variant runs in a child: every shape whose combine tree has level-1 tables
-    over lists of 16 (4, 8 and 16 codebooks of 64 and 256 entries), bit-exact against the oracle."""
+@pytest.mark.parametrize("hook", ["MCQ_TABLE1_LEAN", "MCQ_PAIR0_LOOP"])
+def test_opt_in_kernel_variants_give_the_same_codes(hook):
+    """The two round-5 experiments that are kept behind environment hooks because they are no faster (LAB_NOTEBOOK.md):
+    MCQ_TABLE1_LEAN=1 (tf_table1_lean: the level-1 tables with a third fewer VALU instructions) and MCQ_PAIR0_LOOP=1
+    (k_tf_pair0_loop: level 0 as persistent waves that prefetch their next item).  The hooks are read once per process, so a
+    variant runs in a child: every shape whose combine tree has level-1 tables over lists of 16 (4, 8 and 16 codebooks of 64
+    and 256 entries), bit-exact against the oracle."""
     import subprocess
     import sys
     code = r'''
@@ -784,6 +787,6 @@ for name in ("config_a_d256_n4", "trained_d64_b8_p2", "synth_d40_k64_n8", "synth
         assert np.array_equal(got, want), (name, it, int((got != want).any(axis=1).sum()))
 print("lean ok")
 ''' % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    env = dict(os.environ, MCQ_TABLE1_LEAN="1")
+    env = dict(os.environ, **{hook: "1"})
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "lean ok" in r.stdout, r.stderr[-3000:]
