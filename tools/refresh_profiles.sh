@@ -2,7 +2,7 @@
 # copy the summaries of one tools/final_profiles.sh run (gpurun_out/<dir>) into profiles/ as the round's set
 # usage: tools/refresh_profiles.sh gpurun_out/final_r03 [r03]
 set -eu
-S=$1; R=${2:-r03}; P=$(dirname $0)/../profiles
+S=$1; R=${2:-r05}; P=$(dirname $0)/../profiles
 tail -1 $S/bench.json > $P/${R}_bench.json
 tail -1 $S/bench_under_rocprof.json > $P/${R}_bench_under_rocprof.json
 tail -1 $S/bench_dp2.json > $P/${R}_bench_dp2_dryrun.json
