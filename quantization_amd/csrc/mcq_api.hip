@@ -463,6 +463,16 @@ int run_tf_combines(const float *G, const CT *idx_cur, CT *idx_new, const Worksp
                 looped = true;
             }
         }
+        if constexpr (sizeof(CT) == 1) {
+            // opt-in experiment (MCQ_PAIR0_MULTI=2|4): that many sibling pairs of a vector per wave, their memory phases overlapped
+            static const int ipw = getenv("MCQ_PAIR0_MULTI") ? atoi(getenv("MCQ_PAIR0_MULTI")) : 0;
+            if (!looped && (ipw == 2 || ipw == 4) && !small && N >= 2 * ipw && N <= 64 && nact == nullptr) {
+                const dim3 mg((unsigned)(B * (N / 2) / ipw));
+                if (ipw == 2) hipLaunchKernelGGL(k_tf_pair0_multi<2>, mg, dim3(64), 0, st, G, idx_cur, w.E, L, B, N, K, keep);
+                else hipLaunchKernelGGL(k_tf_pair0_multi<4>, mg, dim3(64), 0, st, G, idx_cur, w.E, L, B, N, K, keep);
+                looped = true;
+            }
+        }
         if (!looped) MCQ_TF_LAUNCH2((k_tf_pair0<8, CT>), (k_tf_pair0<16, CT>), grid, dim3(64), G, idx_cur, w.E, L, B, N, K, keep, fin, nact);
         MCQ_LAUNCH_CHECK();
         if (prof) prof->end(CAT_LEVEL0);

@@ -595,6 +595,59 @@ k_tf_pair0_loop(const float *__restrict__ G, const uint8_t *__restrict__ idx, co
     }
 }
 
+// Level 0 with IPW sibling pairs of a vector per wave (round 5 experiment, opt-in: MCQ_PAIR0_MULTI=2|4).  A k_tf_pair0 wave's
+// life is two dependent memory phases (first inputs 2.2 k clocks, gathers 3.4 k) and a selection (4.8 k); here the memory phases of
+// IPW independent items overlap completely -- every input of all items is requested, then every gather, and only the selections
+// run one after the other -- at the price of registers (50 VGPRs for two items, 70 for four: 8 / 7 waves per SIMD).  Same arithmetic
+// per item, same codes -- and slower: 0.188 (two items) / 0.170 (four) against 0.158 ms per launch at 65,536 vectors on one box,
+// 0.192 / 0.174 against 0.159 at 16 codebooks, 21.9 / 23.6 against 17.4 us at 4,096 vectors.  With the loop above that makes three
+// ways of giving a wave more than one item, all of them slower than one item per fresh wave.
+template <int IPW>
+__global__ void __launch_bounds__(64)
+k_tf_pair0_multi(const float *__restrict__ G, const uint8_t *__restrict__ idx, const float *__restrict__ E, TfLists L, long B,
+                 int N, int K, int keep) {
+    constexpr int KC = 16;
+    __shared__ u64 scratch[kSelectLdsU64];
+    const int lane = lane_id();
+    const int Gout = N >> 1;
+    const int gsh = __builtin_ctz((unsigned)Gout);
+    const int nksh = __builtin_ctz((unsigned)(N * K));
+    const unsigned item0 = blockIdx.x * IPW;                 // IPW consecutive pairs of ONE vector (IPW divides N / 2)
+    const long b = (long)(item0 >> gsh);
+    if (b >= B) return;
+    const int g0 = (int)(item0 & (unsigned)(Gout - 1));
+    const int i = lane >> 2, j0 = 4 * (lane & 3);
+    const int bl = lane < 2 * KC ? lane : 2 * KC;
+    P0In in[IPW];
+#pragma unroll
+    for (int q = 0; q < IPW; ++q) in[q] = p0_load(idx, E, L, item0 + q, N, gsh, lane);
+    float gq[IPW][4], bv[IPW];
+#pragma unroll
+    for (int q = 0; q < IPW; ++q) {
+        const uint32_t rown = (uint32_t)(2 * (g0 + q) * K), colm = rown + (uint32_t)K;
+        const uint32_t si = rown + (uint32_t)in[q].e_i;
+        const uint32_t br = bl < KC ? rown + (uint32_t)in[q].e_b : rown + (uint32_t)in[q].old_n;
+        const uint32_t bc = (bl >= KC && bl < 2 * KC) ? colm + (uint32_t)in[q].e_b : colm + (uint32_t)in[q].old_m;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) gq[q][v] = G[(si << nksh) + colm + ((in[q].w4 >> (8 * v)) & 0xffu)];
+        bv[q] = G[(br << nksh) + bc];
+    }
+#pragma unroll
+    for (int q = 0; q < IPW; ++q) {
+        const float u = shfl_f(bv[q], i), w = shfl_f(bv[q], 2 * KC);
+        float sv[4];
+        int sp[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const float vj = shfl_f(bv[q], KC + j0 + v);
+            const float d = ((gq[q][v] - u) - vj) + w;
+            sv[v] = ((in[q].se + in[q].so[v]) - in[q].Eb) + 2.0f * d;
+            sp[v] = 4 * lane + v;
+        }
+        tf_finish<4, uint8_t>(sv, sp, keep, KC, scratch, L, 1, b, N, g0 + q, nullptr);
+    }
+}
+
 // ------------------------------------------------------------ level-1 tables
 // T_1[X][Y] of two groups of two codebooks (X < Y) over their lists of KC candidates, each entry the sum of four
 // leaf-table entries.  Lane holds positions p = VPL*lane + v.

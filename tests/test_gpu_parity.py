@@ -753,11 +753,12 @@ def test_compute_loss_of_a_512_entry_quantizer_follows_the_reference():
             assert np.linalg.norm(g - want) <= 1e-3 * np.linalg.norm(want) + 1e-7, (iters, name)
 
 
-@pytest.mark.parametrize("hook", ["MCQ_TABLE1_LEAN", "MCQ_PAIR0_LOOP"])
+@pytest.mark.parametrize("hook", ["MCQ_TABLE1_LEAN=1", "MCQ_PAIR0_LOOP=1", "MCQ_PAIR0_MULTI=2", "MCQ_PAIR0_MULTI=4"])
 def test_opt_in_kernel_variants_give_the_same_codes(hook):
-    """The two round-5 experiments that are kept behind environment hooks because they are no faster (LAB_NOTEBOOK.md):
-    MCQ_TABLE1_LEAN=1 (tf_table1_lean: the level-1 tables with a third fewer VALU instructions) and MCQ_PAIR0_LOOP=1
-    (k_tf_pair0_loop: level 0 as persistent waves that prefetch their next item).  The hooks are read once per process, so a
+    """The round-5 experiments that are kept behind environment hooks because they are no faster (LAB_NOTEBOOK.md):
+    MCQ_TABLE1_LEAN=1 (tf_table1_lean: the level-1 tables with a third fewer VALU instructions), MCQ_PAIR0_LOOP=1
+    (k_tf_pair0_loop: level 0 as persistent waves that prefetch their next item) and MCQ_PAIR0_MULTI=2|4 (k_tf_pair0_multi: that
+    many sibling pairs of a vector per wave, memory phases overlapped).  The hooks are read once per process, so a
     variant runs in a child: every shape whose combine tree has level-1 tables over lists of 16 (4, 8 and 16 codebooks of 64
     and 256 entries), bit-exact against the oracle."""
     import subprocess
@@ -787,6 +788,6 @@ for name in ("config_a_d256_n4", "trained_d64_b8_p2", "synth_d40_k64_n8", "synth
         assert np.array_equal(got, want), (name, it, int((got != want).any(axis=1).sum()))
 print("lean ok")
 ''' % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    env = dict(os.environ, **{hook: "1"})
+    env = dict(os.environ, **dict([hook.split("=")]))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "lean ok" in r.stdout, r.stderr[-3000:]
