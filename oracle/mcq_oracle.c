@@ -36,7 +36,8 @@
  *   sumsq64 = 64 partial fmaf chains, partial l over the float4 groups q with
  *             (q mod 64) == l in increasing q, then the xor butterfly
  *             p[l] += p[l^m] for m = 32,16,8,4,2,1 (a wave64 reduction).
- *   selections are by (value, position) ascending, lowest position on ties.
+ *   selections keep the smallest keys by (value, position), lowest position on ties, and list them in ascending
+ *   position (select_smallest).
  *
  * CENTERING (round 4).  The search is invariant under taking a fixed vector mu_n out of every entry of codebook n and
  * mu = sum_n mu_n out of the frame: x - sum_n c_n = (x - mu) - sum_n (c_n - mu_n), and every delta c - old is unchanged.
@@ -253,20 +254,32 @@ static int key_less(float v1, int p1, float v2, int p2) {
     return (v1 < v2) || (v1 == v2 && p1 < p2);
 }
 
-/* the `cnt` smallest of S[0..M) by (value, position), ascending.  Repeated
- * "smallest key greater than the previous one"; mirrors the wave-level
- * extraction of the HIP kernels, including what happens to non-finite keys. */
+/* The sort-and-truncate of :470-503 as a SET: the `cnt` smallest of S[0..M) by (value, position) -- lowest position on
+ * equal values -- LISTED IN ASCENDING POSITION (round 6; until then: in ascending (value, position) order).
+ * The reference keeps the first K_cutoff entries of an ascending sort; the order inside that shortlist only assigns the
+ * candidates' positions for the next combine, every pair's score is computed independently of it and the last step is an
+ * arg-min (SURVEY.md section 7 and probe B.8: the reference reproduces its own codes with every shortlist shuffled), and
+ * torch.sort is not even stable on ties (probe B.6).  So only the set is specified by the reference; listing it by position
+ * lets a wave hand its survivors over where they lie (prefix counts) instead of ranking them against each other.
+ * Order matters on EXACT fp32 ties of later scores only (lowest pair position wins there, as before).
+ * Selection itself: repeated "smallest key greater than the previous one" (what happens to non-finite keys is whatever
+ * that gives: NaN keys are never taken; a list that runs out of candidates is padded with (INF, M - 1)). */
 static void select_smallest(const float *S, int M, int cnt, int *pos_out, float *val_out) {
     float pv = -INFINITY; int pp = -1;
+    int n = 0;
     for (int j = 0; j < cnt; j++) {
         float bv = INFINITY; int bp = M;
         for (int p = 0; p < M; p++) {
             float v = S[p];
             if (key_less(pv, pp, v, p) && key_less(v, p, bv, bp)) { bv = v; bp = p; }
         }
-        if (bp >= M) bp = M - 1;  /* only reachable with NaN keys */
-        pos_out[j] = bp; val_out[j] = bv; pv = bv; pp = bp;
+        if (bp >= M) break;       /* out of candidates (fewer than cnt keys that are not NaN) */
+        /* insert by position */
+        int i = n++;
+        while (i > 0 && pos_out[i - 1] > bp) { pos_out[i] = pos_out[i - 1]; val_out[i] = val_out[i - 1]; i--; }
+        pos_out[i] = bp; val_out[i] = bv; pv = bv; pp = bp;
     }
+    for (; n < cnt; n++) { pos_out[n] = M - 1; val_out[n] = INFINITY; }
 }
 
 typedef struct {

@@ -424,23 +424,6 @@ const char *const kCatNames[CAT_COUNT] = {
         }                                                                                                    \
         if (!s_) hipLaunchKernelGGL(BIGK, grid, block, 0, st, __VA_ARGS__);                                  \
     } while (0)
-// the level-1 table builders in their lean form (mcq_tf_kernels.h, tf_table1_lean: one-byte entries, lists of 16); LEANK is the
-// same kernel with LEAN = true.  MCQ_TABLE1_LEAN=1 selects it (tuning hook; identical results, see table1_lean())
-#define MCQ_TF_LAUNCH3(SMALLK, BIGK, LEANK, grid, block, ...)                                                \
-    do {                                                                                                     \
-        bool s_ = false;                                                                                     \
-        if constexpr (sizeof(CT) == 1) {                                                                     \
-            if (small) { hipLaunchKernelGGL(SMALLK, grid, block, 0, st, __VA_ARGS__); s_ = true; }           \
-            else if (table1_lean()) { hipLaunchKernelGGL(LEANK, grid, block, 0, st, __VA_ARGS__); s_ = true; } \
-        }                                                                                                    \
-        if (!s_) hipLaunchKernelGGL(BIGK, grid, block, 0, st, __VA_ARGS__);                                  \
-    } while (0)
-
-inline bool table1_lean() {      // opt-in: measured equal at 8 codebooks, 2 % slower at 16 (profiles/r05_ab_table1_lean.txt)
-    static const bool on = getenv("MCQ_TABLE1_LEAN") && atoi(getenv("MCQ_TABLE1_LEAN")) != 0;
-    return on;
-}
-
 template <typename CT>
 int run_tf_combines(const float *G, const CT *idx_cur, CT *idx_new, const WorkspaceT<CT> &w, const TfLists &L, long B, int N,
                     int K, const int *nact, hipStream_t st, Prof *prof) {
@@ -451,29 +434,7 @@ int run_tf_combines(const float *G, const CT *idx_cur, CT *idx_new, const Worksp
         CT *fin = (N == 2) ? idx_new : nullptr;
         const dim3 grid((unsigned)(B * (N / 2)));
         if (prof) prof->begin(CAT_LEVEL0);
-        bool looped = false;
-        if constexpr (sizeof(CT) == 1) {
-            // opt-in experiment (MCQ_PAIR0_LOOP=1): persistent waves that prefetch their next item's inputs (mcq_tf_kernels.h)
-            static const int loop_waves = getenv("MCQ_PAIR0_LOOP") ? atoi(getenv("MCQ_PAIR0_LOOP")) : 0;
-            if (loop_waves > 0 && !small && N >= 4 && N <= 16 && nact == nullptr && B * (N / 2) < (1L << 31)) {
-                const unsigned items = (unsigned)(B * (N / 2));
-                unsigned waves = loop_waves == 1 ? 8192u : (unsigned)loop_waves * 256u;      // (1: what the chip holds; else waves per CU)
-                if (waves > items) waves = (items + 7u) & ~7u;
-                hipLaunchKernelGGL(k_tf_pair0_loop, dim3(waves), dim3(64), 0, st, G, idx_cur, w.E, L, items, N, K, keep);
-                looped = true;
-            }
-        }
-        if constexpr (sizeof(CT) == 1) {
-            // opt-in experiment (MCQ_PAIR0_MULTI=2|4): that many sibling pairs of a vector per wave, their memory phases overlapped
-            static const int ipw = getenv("MCQ_PAIR0_MULTI") ? atoi(getenv("MCQ_PAIR0_MULTI")) : 0;
-            if (!looped && (ipw == 2 || ipw == 4) && !small && N >= 2 * ipw && N <= 64 && nact == nullptr) {
-                const dim3 mg((unsigned)(B * (N / 2) / ipw));
-                if (ipw == 2) hipLaunchKernelGGL(k_tf_pair0_multi<2>, mg, dim3(64), 0, st, G, idx_cur, w.E, L, B, N, K, keep);
-                else hipLaunchKernelGGL(k_tf_pair0_multi<4>, mg, dim3(64), 0, st, G, idx_cur, w.E, L, B, N, K, keep);
-                looped = true;
-            }
-        }
-        if (!looped) MCQ_TF_LAUNCH2((k_tf_pair0<8, CT>), (k_tf_pair0<16, CT>), grid, dim3(64), G, idx_cur, w.E, L, B, N, K, keep, fin, nact);
+        MCQ_TF_LAUNCH2((k_tf_pair0<8, CT>), (k_tf_pair0<16, CT>), grid, dim3(64), G, idx_cur, w.E, L, B, N, K, keep, fin, nact);
         MCQ_LAUNCH_CHECK();
         if (prof) prof->end(CAT_LEVEL0);
     }
@@ -491,7 +452,7 @@ int run_tf_combines(const float *G, const CT *idx_cur, CT *idx_new, const Worksp
         const int ntab3 = fuse_l3 ? 16 : 1, per3 = fuse_l3 ? 4 : 1;
         const dim3 grid(pair_blocks + tab_blocks + (fuse_l3 ? (unsigned)(B * ntab3) : 0u));
         if (prof) prof->begin(CAT_LEVEL1_FUSED);
-        MCQ_TF_LAUNCH3((k_tf_level1<8, 8, CT>), (k_tf_level1<16, 16, CT>), (k_tf_level1<16, 16, CT, true>), grid, dim3(64), G, idx_cur, w.E, L, B, N, K, keep, ntab1, per1, w.tabs[0],
+        MCQ_TF_LAUNCH2((k_tf_level1<8, 8, CT>), (k_tf_level1<16, 16, CT>), grid, dim3(64), G, idx_cur, w.E, L, B, N, K, keep, ntab1, per1, w.tabs[0],
                        nact, pair_blocks, tab_blocks, ntab3, per3, w.tabs[1]);
         MCQ_LAUNCH_CHECK();
         if (prof) prof->end(CAT_LEVEL1_FUSED);
@@ -500,7 +461,7 @@ int run_tf_combines(const float *G, const CT *idx_cur, CT *idx_new, const Worksp
         CT *fin = (N == 4) ? idx_new : nullptr;
         const dim3 grid((unsigned)(B * (N / 4)));
         if (prof) prof->begin(CAT_LEVEL1);
-        MCQ_TF_LAUNCH3((k_tf_pair1<8, 8, CT>), (k_tf_pair1<16, 16, CT>), (k_tf_pair1<16, 16, CT, true>), grid, dim3(64), G, idx_cur, w.E, L, B, N, K, keep, fin, nact);
+        MCQ_TF_LAUNCH2((k_tf_pair1<8, 8, CT>), (k_tf_pair1<16, 16, CT>), grid, dim3(64), G, idx_cur, w.E, L, B, N, K, keep, fin, nact);
         MCQ_LAUNCH_CHECK();
         if (prof) prof->end(CAT_LEVEL1);
     }
@@ -513,7 +474,7 @@ int run_tf_combines(const float *G, const CT *idx_cur, CT *idx_new, const Worksp
         const int cat_tab = (v == 2) ? CAT_TABLES : CAT_TABLES_UP, cat_comb = (v == 2) ? CAT_COMBINE : CAT_COMBINE_UP;
         if (!(fuse_l1 && v == 2) && !(fuse_l3 && v == 3)) {     // (these tables came with the level-1 combines)
             if (prof) prof->begin(cat_tab);
-            MCQ_TF_LAUNCH3((k_tf_table1<8, 8, CT>), (k_tf_table1<16, 16, CT>), (k_tf_table1<16, 16, CT, true>), dim3((unsigned)(B * ntab1)), dim3(64), G, idx_cur, L, B, N, K, ntab1, per1,
+            MCQ_TF_LAUNCH2((k_tf_table1<8, 8, CT>), (k_tf_table1<16, 16, CT>), dim3((unsigned)(B * ntab1)), dim3(64), G, idx_cur, L, B, N, K, ntab1, per1,
                            w.tabs[0], nact);
             MCQ_LAUNCH_CHECK();
             if (prof) prof->end(cat_tab);
@@ -543,7 +504,6 @@ int run_tf_combines(const float *G, const CT *idx_cur, CT *idx_new, const Worksp
     return 0;
 }
 #undef MCQ_TF_LAUNCH2
-#undef MCQ_TF_LAUNCH3
 
 template <typename CT>
 int run_encode_t(const float *x, long B, const void *prepared, float lscale, int N, int K, int D, int iters,

@@ -12,7 +12,7 @@
 //   * every sum of squares is 64 per-lane fmaf chains over the float4 groups
 //     q = lane, lane+64, ... followed by the xor butterfly 32,16,8,4,2,1;
 //   * everything else is a single IEEE fp32 operation in the order the oracle writes it;
-//   * selections order candidates by (value, position), lowest position on ties.
+//   * selections keep the smallest candidates by (value, position), lowest position on ties, listed in ascending position.
 // Compile with -ffp-contract=off: only explicit fmaf()/MFMA fuse.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -100,13 +100,19 @@ __device__ __forceinline__ void wave_select(const float (&v)[VPL], const int (&p
     }
 }
 
-// ---- fast selection -----------------------------------------------------------
-// Same result as wave_select() for finite scores, ~5x fewer instructions: every
-// candidate becomes one unique 64-bit key (order-preserving map of the fp32 score in
-// the high word, position in the low word), a ballot-driven quickselect finds the
-// cnt-th smallest key T, the cnt keys <= T are compacted through LDS and ranked
-// against each other.  Scores are never -0 (sums of squares and x - x are +0), so
-// integer order of the keys equals (value, position) order.
+// ---- selection, set form (round 6) ----------------------------------------------
+// The sort-and-truncate of quantization.py:470-503 keeps the `cnt` smallest candidates; the reference needs the SET only
+// (oracle/mcq_oracle.c::select_smallest), so the spec lists it in ascending POSITION and a wave hands its
+// survivors over where they lie: no ranking of the survivors against each other, no sorted hand-over through LDS.
+//   wave_select_set:  the cnt smallest of the wave's VPL*64 keys by (value, position), lowest position on equal values.
+//   Result: every selected element sits in exactly one lane (`has`), with its index `dst` in the ascending-position list;
+//   the caller stores it there.  Returns the number of selected elements (cnt, or the number of candidates if fewer).
+// How: (a) one key per lane (64 candidates): an exact quickselect on the order-preserving 32-bit image of the score -- candidate
+// sets are wave-uniform 64-bit masks on the scalar unit -- gives the threshold; equal scores across the boundary go to the lowest
+// lanes; dst is a prefix count of the mask.  No LDS.  (b) several keys per lane: the cnt-th smallest (within a window) of the 64
+// per-lane MINIMA bounds the answer; the survivors (about 1.5 cnt) are compacted, in position order (prefix counts over the
+// slots' ballots), through 512 bytes of wave-private LDS into one per lane, and (a) runs on them.  (c) anything else (more
+// than 64 survivors, positions that are not lane-major): an exact quickselect over all slots, then the same hand-over.
 typedef unsigned long long u64;
 constexpr u64 kKeyMax = ~0ull;
 // fp16 ingestion (MCQ_ENCODE_X_FP16): x rows are _Float16 in HBM and widen to fp32 in the load path;
@@ -116,9 +122,9 @@ __device__ __forceinline__ f32x4 load_h4(const void *p) {
     return __builtin_convertvector(*reinterpret_cast<const f16x4 *>(p), f32x4);
 }
 #ifndef MCQ_SEL_WIN
-#define MCQ_SEL_WIN 4      // window of the selection's bound (wave_kth_lane_key); 0 = the exact key
+#define MCQ_SEL_WIN 4      // window of the bound on the lane minima (wave_kth_u32): any minimum with cnt - 1 .. cnt + 3 smaller ones
 #endif
-constexpr int kSelectLdsU64 = 208;  // per-wave LDS scratch of wave_select_fast, in u64 (136 survivors + 64 results)
+constexpr int kSelectLdsU64 = 64;   // per-wave LDS scratch of wave_select_set, in u64: one (score, position) slot per lane
 
 __device__ __forceinline__ uint32_t ord32(float v) {
     const uint32_t b = __float_as_uint(v);
@@ -136,192 +142,173 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
+// number of set bits of m below this lane, + base
+__device__ __forceinline__ int mbcnt64(u64 m, int base = 0) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, base));
+}
 
-// The key with exactly `target` smaller keys among the 64 per-lane keys `k` (unique; kKeyMax = no key): a quickselect whose
-// candidate set is a wave-uniform 64-bit mask handled by scalar instructions.  One round = first candidate as the pivot,
-// one ballot, one popcount; written as a do-while with both successor masks formed unconditionally (the while-with-break
-// form compiled to 22 instructions and four branches per round, this one to about 14 and one).  kKeyMax when there are
-// fewer than target + 1 keys.
-// `win` > 0: ANY key with target .. target + win smaller ones will do (the caller only needs an upper bound of the target-th
-// key that not many more keys lie below): the loop stops at the first pivot that lands in the window -- about two rounds of seven
-// earlier for win = 4.
-__device__ __forceinline__ u64 wave_kth_lane_key(u64 k, int target, int win = 0) {
-    u64 cm = __ballot(k != kKeyMax);
-    if (__popcll(cm) <= target) return kKeyMax;
-    u64 kp;
-    int rr;
-    do {                          // every round removes at least the pivot's lane from the candidates: <= 64 rounds
+// Quickselect over one 32-bit key per lane.  `cm`: the lanes that hold a key (the others hold 0xffffffff and are never a pivot);
+// more than `target` of them.  Returns a key kp with  n_lt(kp) <= target + win  and  n_le(kp) > target  (n_lt / n_le: keys below /
+// not above kp), and the masks of the last round.  win = 0: THE key with at most `target` keys below it and more than `target`
+// not above it (equal keys allowed: the caller settles them).  One round = first candidate as the pivot, two ballots, two
+// popcounts; the key sought is never dropped (a pivot with too many keys below it keeps the lanes below it, any other pivot that
+// is not accepted has n_le <= target and keeps the lanes above it), and every round drops at least the pivot's lane.
+__device__ __forceinline__ uint32_t wave_kth_u32(uint32_t k, u64 cm, int target, int win, u64 &ltm, u64 &lem) {
+    uint32_t kp;
+    const int hi = target + win;
 #ifdef MCQ_DEBUG_SELECT
-        // debug builds (hipcc -DMCQ_DEBUG_SELECT; __graft_entry__.build(debug_select=True)): the invariant below, checked.  An
-        // empty candidate mask means two equal keys reached the selection -- trap instead of spinning on ctz(0)
+    // debug builds (hipcc -DMCQ_DEBUG_SELECT; __graft_entry__.build(debug_select=True)): the same loop in C with the invariant
+    // above CHECKED -- trap instead of spinning on ctz(0)
+    for (;;) {
         if (cm == 0) __builtin_trap();
+        const int pl = __builtin_ctzll(cm);
+        kp = (uint32_t)__builtin_amdgcn_readlane((int)k, pl);
+        ltm = __ballot(k < kp);
+        lem = __ballot(k <= kp);
+        if (__popcll(ltm) > hi) { cm &= ltm; continue; }
+        if (__popcll(lem) > target) break;
+        cm &= ~lem;
+    }
+#else
+    // The loop as the ISA it should be: written in C (either as one loop condition over two flags or as the two branches above)
+    // the compiler materialises both flags as 64-bit masks and selects between the successor masks -- 19 to 27 instructions a
+    // round; here 9 when the pivot is too high (one vector compare), 13 otherwise.
+    // (the candidate mask is COPIED into a register pair of the block's own: handed over as an in/out operand, a mask that is
+    // __ballot(true) reaches the block as the exec register itself, and the loop would narrow the wave's exec mask)
+    int t0;
+    u64 cmw;
+    asm("s_mov_b64 %[cm], %[cmin]\n\t"
+        "1:\n\t"
+        "s_ff1_i32_b64 %[t0], %[cm]\n\t"
+        "v_readlane_b32 %[kp], %[k], %[t0]\n\t"
+        "s_nop 1\n\t"
+        "v_cmp_gt_u32_e64 %[lt], %[kp], %[k]\n\t"
+        "s_bcnt1_i32_b64 %[t0], %[lt]\n\t"
+        "s_cmp_gt_u32 %[t0], %[hi]\n\t"
+        "s_cbranch_scc1 2f\n\t"
+        "v_cmp_ge_u32_e64 %[le], %[kp], %[k]\n\t"
+        "s_bcnt1_i32_b64 %[t0], %[le]\n\t"
+        "s_cmp_gt_u32 %[t0], %[tg]\n\t"
+        "s_cbranch_scc1 3f\n\t"
+        "s_andn2_b64 %[cm], %[cm], %[le]\n\t"
+        "s_branch 1b\n\t"
+        "2:\n\t"
+        "s_and_b64 %[cm], %[cm], %[lt]\n\t"
+        "s_branch 1b\n\t"
+        "3:"
+        : [kp] "=&s"(kp), [lt] "=&s"(ltm), [le] "=&s"(lem), [t0] "=&s"(t0), [cm] "=&s"(cmw)
+        : [k] "v"(k), [hi] "s"(hi), [tg] "s"(target), [cmin] "s"(cm)
+        : "scc");
 #endif
-        const int pl = __builtin_ctzll(cm);      // (cm != 0 here; __ffsll's zero case cost two scalar instructions per round)
-        kp = readlane_u64(k, pl);
-        const u64 ltm = __ballot(k < kp), gtm = __ballot(k > kp);      // (keys are unique: the lanes above the pivot, from a second
-        rr = __popcll(ltm);                                            // vector compare instead of two more scalar mask operations)
-        cm &= (rr > target) ? ltm : gtm;
-    } while ((unsigned)(rr - target) > (unsigned)win);
-    // INVARIANT the loop's exit rests on: the keys are UNIQUE (every caller packs the candidate's position into the low word), so
-    // the key with exactly `target` smaller ones exists among the candidates and is reached before they run out.  A guard on
-    // cm != 0 (equal keys would empty the mask first) was tried on the advisor's suggestion: two more scalar instructions in a loop
-    // of fourteen, run seven times per selection, fourteen selections per vector and pass -- k_tf_stage0 268 -> 279 us, k_tf_pair0
-    // 174 -> 179 us on one box; the invariant is asserted where the keys are built instead (tests/test_gpu_parity.py::
-    // test_wave_selection_paths drives ties through every path: equal SCORES give distinct keys).
     return kp;
 }
 
-template <int VPL>
-__device__ __forceinline__ void wave_select_fast(const float (&v)[VPL], const int (&p)[VPL], int cnt, int M,
-                                                 u64 *lds /* kSelectLdsU64 per wave */, float &out_v, int &out_p) {
+// d + bit `lane` of the wave-uniform mask m, as ONE instruction (add with carry-in; the compiler's own form of d + (s ? 1 : 0) is a
+// select and an add)
+__device__ __forceinline__ int add_lane_bit(int d, u64 m) {
+    int r;
+    u64 carry_out;
+    asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(r), "=&s"(carry_out) : "v"(d), "s"(m));
+    return r;
+}
+
+// The cnt smallest of the 32-bit keys `ko` (one per lane of `valid`, more than cnt of them; the other lanes hold 0xffffffff):
+// `has` per lane, the mask as the return value.  Equal keys across the boundary go to the lowest lanes.
+__device__ __forceinline__ u64 wave_select_mask(uint32_t ko, u64 valid, int cnt, bool &has) {
+    u64 ltm, lem;
+    const uint32_t kp = wave_kth_u32(ko, valid, cnt - 1, 0, ltm, lem);
+    if (__popcll(lem) == cnt) {
+        has = ko <= kp;
+        return lem;
+    }
+    const u64 eq = lem & ~ltm;
+    const int need = cnt - __popcll(ltm);
+    has = (ko < kp) | ((ko == kp) & (mbcnt64(eq) < need));      // (exact ties only)
+    return __ballot(has);
+}
+
+// LANE_MAJOR: the positions p[i] ascend with (lane, i) -- every caller but the merge of a chunked selection.
+template <int VPL, bool LANE_MAJOR = true>
+__device__ __forceinline__ int wave_select_set(const float (&v)[VPL], const int (&p)[VPL], int cnt, int M,
+                                               u64 *lds /* kSelectLdsU64 per wave */, bool &has, int &dst, float &out_v, int &out_p) {
+    const int lane = lane_id();
     if (cnt == 1) {  // plain arg-min
         wave_select<VPL>(v, p, 1, M, out_v, out_p);
-        return;
+        has = lane == 0;
+        dst = 0;
+        return 1;
     }
-    const int lane = lane_id();
-    u64 key[VPL];
-    bool cand[VPL];
-#pragma unroll
-    for (int i = 0; i < VPL; ++i) {
-        cand[i] = p[i] != kBigPos;
-        key[i] = cand[i] ? (((u64)ord32(v[i]) << 32) | (uint32_t)p[i]) : kKeyMax;
+    if constexpr (VPL == 1 && LANE_MAJOR) {
+        const bool cand = p[0] != kBigPos;
+        const u64 valid = __ballot(cand);
+        const uint32_t ko = cand ? ord32(v[0]) : 0xffffffffu;
+        u64 selm = valid;
+        has = cand;
+        if (__popcll(valid) > cnt) selm = wave_select_mask(ko, valid, cnt, has);
+        dst = mbcnt64(selm);
+        out_v = v[0];
+        out_p = p[0];
+        return __popcll(selm);
     }
-    const int target = cnt - 1;
-    u64 *ldsA = lds, *ldsB = lds + 64;
-    if (VPL > 1 && cnt * VPL <= 64) {
-        // Two-level variant (the common 256 -> 16 case).  T0 = the cnt-th smallest of the 64
-        // per-lane minima bounds the answer from above: every one of the cnt smallest keys is
-        // <= T0, and at most cnt lanes (x VPL keys) hold keys <= T0, so the survivors fit in one
-        // key per lane; they are then ranked exactly.  The quickselect runs on one key per lane.
-        u64 lmin = key[0];
+    if constexpr (VPL > 1 && LANE_MAJOR) {
+        // (every slot holds a candidate: the callers with several keys per lane have no empty positions)
+        float lm = v[0];
 #pragma unroll
-        for (int i = 1; i < VPL; ++i) lmin = key[i] < lmin ? key[i] : lmin;
-        // The candidate set is a wave-uniform 64-bit MASK handled by scalar instructions (a per-lane bool carried
-        // round the loop is materialised as 0/1 VGPRs with v_cndmask / v_cmp pairs and nops on every round: the
-        // selection is bound by exactly that scalar/VALU ping-pong).  Keys are unique, so the lanes above the
-        // pivot are the complement of those below it minus the pivot's lane.
-        // (a bound is all T0 has to be: any lane minimum with cnt - 1 .. cnt + 3 smaller ones.  Up to cnt + 4 lanes then hold
-        // survivors -- more than 64 of them only if those lanes hold nearly all their keys below T0, in which case the exact
-        // cnt-th minimum is taken after all: at most cnt * VPL <= 64 survive that)
-        u64 T0 = wave_kth_lane_key(lmin, target, MCQ_SEL_WIN);
-        // (T0 == kKeyMax: fewer than cnt lanes hold a candidate.  Every candidate then survives -- at most (cnt - 1) * VPL < 64 of
-        // them -- and the non-candidates, whose key IS kKeyMax, must not: the bound becomes kKeyMax - 1 (a candidate's key is
-        // below it: its low word is a position), and the retry below, which would return kKeyMax again, is skipped)
-        const bool few = (T0 == kKeyMax);
-        if (few) T0 = kKeyMax - 1;
-        int base;
-        for (int attempt = 0;; ++attempt) {
-            base = 0;
-#pragma unroll
-            for (int i = 0; i < VPL; ++i) {
-                const bool sel = key[i] <= T0;
-                const u64 m = __ballot(sel);
-                const int dst = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-                if (sel && dst < 64) ldsA[dst] = key[i];
-                base += __popcll(m);
-            }
-            if (base <= 64 || attempt > 0 || few) break;
-            T0 = wave_kth_lane_key(lmin, target);
-        }
-        const int c0 = base < 64 ? base : 64;
-        // ranking walks the survivors eight at a time; the tail is padded with sentinels (never smaller than a key)
-        // instead of a one-by-one remainder loop that waits out an LDS round trip per element
-        if (lane >= c0 && lane < c0 + 8) ldsA[lane] = kKeyMax;      // may run into ldsB, which is written later
-        wave_lds_fence();
-        const u64 k = (lane < c0) ? ldsA[lane] : kKeyMax;
-        int rnk = 0;
-        const int c8 = (c0 + 7) & ~7;
-        for (int j = 0; j < c8; j += 8) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) rnk += (ldsA[j + u] < k) ? 1 : 0;
-        }
-        if (lane < c0 && rnk < cnt) ldsB[rnk] = k;
-        wave_lds_fence();
-        out_v = INFINITY;
-        out_p = M - 1;
-        if (lane < cnt) {
-            const u64 o = ldsB[lane];
-            out_p = (int)(uint32_t)o;
-            out_v = unord32((uint32_t)(o >> 32));
-        }
-        wave_lds_fence();
-        return;
-    }
-    if (VPL > 1 && cnt <= 64) {
-        // Two-level variant with up to two survivors per lane (32 of 256 with four keys per lane): T0 as above bounds
-        // the answer, at most cnt lanes hold keys <= T0, so at most cnt * VPL keys survive; lane l ranks the survivors
-        // l and l + 64 against all of them.  With more keys per lane (32 of 1,024: sixteen) cnt * VPL exceeds the 128
-        // slots, but the survivors rarely do (about 46 on the bench workload): they are counted first, and only a
-        // count above 128 falls through to the general quickselect below (sixteen ballots per round).
-        u64 lmin = key[0];
-#pragma unroll
-        for (int i = 1; i < VPL; ++i) lmin = key[i] < lmin ? key[i] : lmin;
-        const u64 T0 = wave_kth_lane_key(lmin, target);
-        int nsurv = 0;
-#pragma unroll
-        for (int i = 0; i < VPL; ++i) nsurv += __popcll(__ballot(key[i] <= T0));
-        if (nsurv <= 128) {
-        u64 *ldsS = lds, *ldsO = lds + 144;        // survivors [0, 136), results [144, 208)
-        int base = 0;
+        for (int i = 1; i < VPL; ++i) lm = __builtin_fminf(lm, v[i]);
+        u64 ltm, lem;
+        const float T0v = unord32(wave_kth_u32(ord32(lm), ~0ull, cnt - 1, MCQ_SEL_WIN, ltm, lem));
+        // survivors: at least cnt (one in each of >= cnt lanes), usually about 1.5 cnt
+        u64 m[VPL];
+        int c = 0;
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
-            const bool sel = key[i] <= T0;
-            const u64 m = __ballot(sel);
-            const int dst = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-            if (sel && dst < 128) ldsS[dst] = key[i];
-            base += __popcll(m);
+            m[i] = __ballot(v[i] <= T0v);
+            c += __popcll(m[i]);
         }
-        const int c0 = base < 128 ? base : 128;
-        if (lane < 8) ldsS[c0 + lane] = kKeyMax;                       // sentinel tail
-        wave_lds_fence();
-        const u64 ka = (lane < c0) ? ldsS[lane] : kKeyMax;
-        const int c8 = (c0 + 7) & ~7;
-        int ra = 0;
-        if (c0 <= 64) {
-            // the usual case (about 41 survivors for 32 of 256): nobody holds a second survivor, half the compares
-            for (int j = 0; j < c8; j += 8) {
+        if (c >= cnt && c <= 64) {
+            // score and position of survivor number d (in position order) go to lo[d] and lo[64 + d]: one ds_write2_b32 from
+            // the registers they are in
+            uint32_t *lo = reinterpret_cast<uint32_t *>(lds);
+            int d = 0;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) ra += (ldsS[j + u] < ka) ? 1 : 0;
-            }
-        } else {
-            const u64 kb = ldsS[lane + 64 < c0 ? lane + 64 : c0];      // (slot c0 holds a sentinel)
-            int rb = 0;
-            for (int j = 0; j < c8; j += 8) {
+            for (int i = 0; i < VPL; ++i) d = mbcnt64(m[i], d);            // survivors in the lanes below this one
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const u64 o = ldsS[j + u];
-                    ra += (o < ka) ? 1 : 0;
-                    rb += (o < kb) ? 1 : 0;
-                }
+            for (int i = 0; i < VPL; ++i) {
+                if (v[i] <= T0v) { lo[d] = __float_as_uint(v[i]); lo[64 + d] = (uint32_t)p[i]; }
+                if (i + 1 < VPL) d = add_lane_bit(d, m[i]);
             }
-            if (lane + 64 < c0 && rb < cnt) ldsO[rb] = kb;
-        }
-        if (lane < c0 && ra < cnt) ldsO[ra] = ka;
-        wave_lds_fence();
-        out_v = INFINITY;
-        out_p = M - 1;
-        if (lane < cnt) {
-            const u64 o = ldsO[lane];
-            out_p = (int)(uint32_t)o;
-            out_v = unord32((uint32_t)(o >> 32));
-        }
-        wave_lds_fence();
-        return;
+            wave_lds_fence();
+            const uint32_t ev = lo[lane], ep = lo[64 + lane];              // (lanes >= c read what an earlier selection left: unused)
+            wave_lds_fence();                                              // (read before a later selection writes here)
+            out_v = __uint_as_float(ev);
+            out_p = (int)ep;
+            const bool in = lane < c;
+            u64 selm = (c == 64) ? ~0ull : ((1ull << c) - 1ull);
+            has = in;
+            if (c != cnt) selm = wave_select_mask(in ? ord32(out_v) : 0xffffffffu, selm, cnt, has);
+            dst = mbcnt64(selm);
+            return cnt;
         }
     }
-    // quickselect: find the key T with exactly cnt - 1 keys below it.  Candidate sets as wave-uniform masks, one
-    // per key slot (see the two-level variant above); the pivot is the first candidate of the lowest slot that has one.
-    u64 T = 0;
+    // general form: unique 64-bit keys (score image || position), an exact quickselect over all slots -- candidate sets as
+    // wave-uniform masks, one per slot; the pivot is the first candidate of the lowest slot that has one
+    u64 key[VPL];
     u64 cmask[VPL];
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) cmask[i] = __ballot(cand[i]);
+    for (int i = 0; i < VPL; ++i) {
+        const bool cand = p[i] != kBigPos;
+        key[i] = cand ? (((u64)ord32(v[i]) << 32) | (uint32_t)p[i]) : kKeyMax;
+        cmask[i] = __ballot(cand);
+    }
+    const int target = cnt - 1;
+    u64 T = 0;
     for (;;) {                // every round removes at least the pivot from the candidates: <= 64 * VPL rounds
         u64 kp = kKeyMax;
         int ps = -1, pl = 0;
 #pragma unroll
         for (int i = VPL - 1; i >= 0; --i)
             if (cmask[i] != 0) { ps = i; pl = __ffsll((long long)cmask[i]) - 1; }
-        if (ps < 0) { T = kp; break; }
+        if (ps < 0) { T = kKeyMax - 1; break; }      // fewer than cnt candidates: all of them (their keys are below kKeyMax - 1)
 #pragma unroll
         for (int i = 0; i < VPL; ++i)
             if (i == ps) kp = readlane_u64(key[i], pl);      // uniform branch: one slot matches
@@ -339,40 +326,42 @@ __device__ __forceinline__ void wave_select_fast(const float (&v)[VPL], const in
             cmask[i] &= (r > target) ? ltm[i] : ~(ltm[i] | pivot_bit);
         }
     }
-    // compact the cnt selected keys to lds[0..cnt)
-    int base = 0;
+    // the selected keys, one per lane (at most cnt <= 64 of them), in the order of (lane, slot)
+    uint32_t *lo = reinterpret_cast<uint32_t *>(lds);
+    int d = 0, nsel = 0;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
-        const bool sel = key[i] <= T;
-        const u64 m = __ballot(sel);
-        const int dst = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-        if (sel && dst < 64) ldsA[dst] = key[i];
-        base += __popcll(m);
+        const u64 mi = __ballot(key[i] <= T);
+        d = mbcnt64(mi, d);
+        nsel += __popcll(mi);
     }
-    if (lane >= cnt && lane < cnt + 8) ldsA[lane] = kKeyMax;       // sentinel tail: see the two-level variant
-    wave_lds_fence();
-    const u64 k = (lane < cnt) ? ldsA[lane] : kKeyMax;
-    int rnk = 0;
-    const int c8 = (cnt + 7) & ~7;
-    for (int j = 0; j < c8; j += 8) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) rnk += (ldsA[j + u] < k) ? 1 : 0;
-    }
-    if (lane < cnt) ldsB[rnk] = k;
-    wave_lds_fence();
-    out_v = INFINITY;
-    out_p = M - 1;
-    if (lane < cnt) {
-        const u64 o = ldsB[lane];
-        out_p = (int)(uint32_t)o;
-        out_v = unord32((uint32_t)(o >> 32));
+    for (int i = 0; i < VPL; ++i) {
+        const bool s = key[i] <= T;
+        if (s && d < 64) { lo[d] = __float_as_uint(v[i]); lo[64 + d] = (uint32_t)p[i]; }
+        d += s ? 1 : 0;
     }
     wave_lds_fence();
+    has = lane < nsel;
+    const uint32_t ev = lo[lane], ep = lo[64 + lane];
+    wave_lds_fence();
+    out_v = __uint_as_float(ev);
+    out_p = (int)ep;
+    dst = lane;
+    if constexpr (!LANE_MAJOR) {
+        // the list is in ascending position whatever the lanes' order: rank by position among the selected
+        const int mine = has ? out_p : kBigPos;
+        int r = 0;
+        for (int j = 0; j < nsel; ++j) r += (__builtin_amdgcn_readlane(mine, j) < mine) ? 1 : 0;
+        dst = r;
+    }
+    return nsel;
 }
 
-// Test hook: one wave selects the `cnt` smallest of M = 64 * VPL scores (position = index) with wave_select_fast; lane j
-// writes the j-th.  Lets the tests drive every path of the selection with adversarial inputs (ties, all survivors in a few
-// lanes, more survivors than the two-per-lane path holds).
+// Test hook: one wave selects the `cnt` smallest of M = 64 * VPL scores (position = index) with wave_select_set; entry j of the
+// list (ascending position) goes to out[j]; a list that runs out of candidates is padded with (INF, M - 1) as the oracle pads
+// it.  Lets the tests drive every path of the selection with adversarial inputs (ties, all survivors in a few lanes, more
+// survivors than one per lane).
 template <int VPL>
 __global__ void __launch_bounds__(64)
 k_test_select(const float *__restrict__ scores, int cnt, float *__restrict__ out_v, int *__restrict__ out_p) {
@@ -385,12 +374,17 @@ k_test_select(const float *__restrict__ scores, int cnt, float *__restrict__ out
         p[i] = VPL * lane_id() + i;
         v[i] = sc[p[i]];
     }
+    bool has;
+    int dst, op;
     float ov;
-    int op;
-    wave_select_fast<VPL>(v, p, cnt, 64 * VPL, scratch, ov, op);
-    if (lane_id() < cnt) {
-        out_v[(size_t)blockIdx.x * 64 + lane_id()] = ov;
-        out_p[(size_t)blockIdx.x * 64 + lane_id()] = op;
+    const int nsel = wave_select_set<VPL>(v, p, cnt, 64 * VPL, scratch, has, dst, ov, op);
+    if (has) {
+        out_v[(size_t)blockIdx.x * 64 + dst] = ov;
+        out_p[(size_t)blockIdx.x * 64 + dst] = op;
+    }
+    if (lane_id() >= nsel && lane_id() < cnt) {
+        out_v[(size_t)blockIdx.x * 64 + lane_id()] = INFINITY;
+        out_p[(size_t)blockIdx.x * 64 + lane_id()] = 64 * VPL - 1;
     }
 }
 

@@ -272,17 +272,18 @@ k_tf_stage0(const float *__restrict__ G, const float *__restrict__ XC, const tf_
     }
     stp.at(1);                                  // all rows in, scores formed
     float ov;
-    int op;
-    wave_select_fast<VPL>(sv, sp, keep, K, sel[threadIdx.x >> 6], ov, op);
+    int op, dst;
+    bool has;
+    wave_select_set<VPL>(sv, sp, keep, K, sel[threadIdx.x >> 6], has, dst, ov, op);
     stp.at(2);                                  // selection done
     stp.flush(0, blockIdx.x, 16);
     if (N == 1) {                                             // the best entry is the result (:468-469)
         if (lane == 0) idx_final[b] = (CT)op;
         return;
     }
-    if (lane < keep) {
-        ent_out[(b * N + n) * keep + lane] = (CT)op;
-        S_out[(b * N + n) * keep + lane] = ov;
+    if (has) {                                                // the list in ascending entry: every survivor from the lane that holds it
+        ent_out[(b * N + n) * keep + dst] = (CT)op;
+        S_out[(b * N + n) * keep + dst] = ov;
     }
 }
 
@@ -350,9 +351,14 @@ k_tf_stage0_k16(const float *__restrict__ G, const float *__restrict__ XC, const
     MCQ_ROR(1) MCQ_ROR(2) MCQ_ROR(3) MCQ_ROR(4) MCQ_ROR(5) MCQ_ROR(6) MCQ_ROR(7) MCQ_ROR(8)
     MCQ_ROR(9) MCQ_ROR(10) MCQ_ROR(11) MCQ_ROR(12) MCQ_ROR(13) MCQ_ROR(14) MCQ_ROR(15)
 #undef MCQ_ROR
-    if (rnk < keep) {
-        ent_out[(b * N + n) * keep + rnk] = (uint8_t)k;
-        S_out[(b * N + n) * keep + rnk] = sv;
+    // the survivors (rank < keep) listed in ascending entry: the index is a prefix count within the lane's row of 16
+    const bool take = rnk < keep;
+    const u64 tm = __ballot(take);
+    const uint32_t rowbits = (uint32_t)(tm >> (lane & 48)) & 0xffffu;
+    const int dst = __popc(rowbits & ((1u << k) - 1u));
+    if (take) {
+        ent_out[(b * N + n) * keep + dst] = (uint8_t)k;
+        S_out[(b * N + n) * keep + dst] = sv;
     }
 }
 
@@ -444,7 +450,7 @@ __device__ __forceinline__ void tf_emit(const TfLists &L, long b, int N, int nle
 }
 
 // select `keep` of the wave's scores and write the next level's list (or, for the last combine, the result)
-template <int VPL, typename CT = uint8_t>
+template <int VPL, typename CT = uint8_t, bool LANE_MAJOR = true>
 __device__ __forceinline__ void tf_finish(const float (&sv)[VPL], const int (&sp)[VPL], int keep, int KCin, u64 *scratch,
                                           const TfLists &L, int vout /* level of the list written */, long b, int N,
                                           int gout, CT *__restrict__ idx_final) {
@@ -462,10 +468,11 @@ __device__ __forceinline__ void tf_finish(const float (&sv)[VPL], const int (&sp
         return;
     }
     float ov;
-    int op;
-    wave_select_fast<VPL>(sv, sp, keep, KCin * KCin, scratch, ov, op);
-    if (lane_id() < keep) {
-        const long o = (b * (N >> vout) + gout) * keep + lane_id();
+    int op, dst;
+    bool has;
+    wave_select_set<VPL, LANE_MAJOR>(sv, sp, keep, KCin * KCin, scratch, has, dst, ov, op);
+    if (has) {
+        const long o = (b * (N >> vout) + gout) * keep + dst;
         L.pos[vout][2 * o] = (uint8_t)(op / KCin);
         L.pos[vout][2 * o + 1] = (uint8_t)(op % KCin);
         L.S[vout][o] = ov;
@@ -509,143 +516,6 @@ k_tf_pair0(const float *__restrict__ G, const CT *__restrict__ idx, const float 
     tf_finish<VPL, CT>(sv, sp, keep, KC, scratch, L, 1, b, N, g, idx_final);
     stp.at(3);                                  // selection done, list written
     stp.flush(1, blockIdx.x, 64);
-}
-
-// Level 0 as a persistent loop WITH PREFETCH (round 5 experiment, opt-in: MCQ_PAIR0_LOOP=1).  The phase stamps say a k_tf_pair0
-// wave waits 2.2 k of its 10.9 k clocks for its first inputs (lists the previous launch wrote: they come from beyond the L2).
-// Here 8,192 waves -- what the chip holds -- each walk their items (same sibling pair, same XCD: the stride is a multiple of 8
-// and of the number of pairs) and request the next item's inputs right after the current item's gathers, so that they arrive
-// during its selection (the ISA waits for the gathers with vmcnt(6): the six prefetch loads stay in flight).  Same arithmetic,
-// same codes -- and 0.204 against 0.166 ms per launch at 65,536 vectors, with 16, 24 or 32 waves per CU alike (round 4 measured the
-// same for a loop without prefetch): a wave that lives on does not overlap its phases with its neighbours' the way a stream of
-// fresh waves does.  Kept as the measured answer to "hide the first-input latency".  One-byte entries, lists of 16, not the
-// last combine.
-struct P0In {
-    int e_i, e_b, old_n, old_m;
-    uint32_t w4;
-    float se, Eb;
-    f32x4 so;
-};
-__device__ __forceinline__ P0In p0_load(const uint8_t *__restrict__ idx, const float *__restrict__ E, const TfLists &L, unsigned item,
-                                        int N, int gsh, int lane) {
-    constexpr int KC = 16;
-    const int g = (int)(item & ((1u << gsh) - 1u));
-    const long b = (long)(item >> gsh);
-    const int n = 2 * g, m = n + 1;
-    const uint8_t *en = L.ent + (b * N + n) * KC, *em = en + KC;
-    const int i = lane >> 2, j0 = 4 * (lane & 3);
-    const int bl = lane < 2 * KC ? lane : 2 * KC;
-    P0In r;
-    r.e_i = en[i];
-    r.e_b = *(bl < KC ? en + bl : em + (bl < 2 * KC ? bl - KC : 0));
-    r.w4 = *reinterpret_cast<const uint32_t *>(em + j0);
-    r.old_n = idx[b * N + n];
-    r.old_m = idx[b * N + m];
-    r.se = L.S[0][(b * N + n) * KC + i];
-    r.so = *reinterpret_cast<const f32x4 *>(L.S[0] + (b * N + m) * KC + j0);
-    r.Eb = E[b];
-    return r;
-}
-
-__global__ void __launch_bounds__(64)
-k_tf_pair0_loop(const float *__restrict__ G, const uint8_t *__restrict__ idx, const float *__restrict__ E, TfLists L, unsigned items,
-                int N, int K, int keep) {
-    constexpr int KC = 16;
-    __shared__ u64 scratch[kSelectLdsU64];
-    const int lane = lane_id();
-    const int gsh = __builtin_ctz((unsigned)(N >> 1));
-    const int nksh = __builtin_ctz((unsigned)(N * K));
-    const unsigned stride = gridDim.x;
-    unsigned item = blockIdx.x;
-    if (item >= items) return;
-    const int i = lane >> 2, j0 = 4 * (lane & 3);
-    const int bl = lane < 2 * KC ? lane : 2 * KC;
-    P0In cur = p0_load(idx, E, L, item, N, gsh, lane);
-    for (;;) {
-        const int g = (int)(item & ((1u << gsh) - 1u));
-        const long b = (long)(item >> gsh);
-        const uint32_t rown = (uint32_t)(2 * g * K), colm = rown + (uint32_t)K;
-        // the leaf table of tf_leaf, from the inputs in `cur`
-        const uint32_t si = rown + (uint32_t)cur.e_i;
-        const uint32_t br = bl < KC ? rown + (uint32_t)cur.e_b : rown + (uint32_t)cur.old_n;
-        const uint32_t bc = (bl >= KC && bl < 2 * KC) ? colm + (uint32_t)cur.e_b : colm + (uint32_t)cur.old_m;
-        float gq[4];
-#pragma unroll
-        for (int v = 0; v < 4; ++v) gq[v] = G[(si << nksh) + colm + ((cur.w4 >> (8 * v)) & 0xffu)];
-        const float bv = G[(br << nksh) + bc];
-        // the next item's inputs: requested behind the gathers, needed only after this item's selection
-        // (unconditionally -- the last iteration re-reads its own item: behind a branch the compiler cannot count the loads in
-        // flight and waits for all of them before it uses the gathers)
-        const unsigned nxt = item + stride;
-        const P0In nx = p0_load(idx, E, L, nxt < items ? nxt : item, N, gsh, lane);
-        const float u = shfl_f(bv, i), w = shfl_f(bv, 2 * KC);
-        float sv[4];
-        int sp[4];
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const float vj = shfl_f(bv, KC + j0 + v);
-            const float d = ((gq[v] - u) - vj) + w;
-            sv[v] = ((cur.se + cur.so[v]) - cur.Eb) + 2.0f * d;
-            sp[v] = 4 * lane + v;
-        }
-        tf_finish<4, uint8_t>(sv, sp, keep, KC, scratch, L, 1, b, N, g, nullptr);
-        if (nxt >= items) break;
-        cur = nx;
-        item = nxt;
-    }
-}
-
-// Level 0 with IPW sibling pairs of a vector per wave (round 5 experiment, opt-in: MCQ_PAIR0_MULTI=2|4).  A k_tf_pair0 wave's
-// life is two dependent memory phases (first inputs 2.2 k clocks, gathers 3.4 k) and a selection (4.8 k); here the memory phases of
-// IPW independent items overlap completely -- every input of all items is requested, then every gather, and only the selections
-// run one after the other -- at the price of registers (50 VGPRs for two items, 70 for four: 8 / 7 waves per SIMD).  Same arithmetic
-// per item, same codes -- and slower: 0.188 (two items) / 0.170 (four) against 0.158 ms per launch at 65,536 vectors on one box,
-// 0.192 / 0.174 against 0.159 at 16 codebooks, 21.9 / 23.6 against 17.4 us at 4,096 vectors.  With the loop above that makes three
-// ways of giving a wave more than one item, all of them slower than one item per fresh wave.
-template <int IPW>
-__global__ void __launch_bounds__(64)
-k_tf_pair0_multi(const float *__restrict__ G, const uint8_t *__restrict__ idx, const float *__restrict__ E, TfLists L, long B,
-                 int N, int K, int keep) {
-    constexpr int KC = 16;
-    __shared__ u64 scratch[kSelectLdsU64];
-    const int lane = lane_id();
-    const int Gout = N >> 1;
-    const int gsh = __builtin_ctz((unsigned)Gout);
-    const int nksh = __builtin_ctz((unsigned)(N * K));
-    const unsigned item0 = blockIdx.x * IPW;                 // IPW consecutive pairs of ONE vector (IPW divides N / 2)
-    const long b = (long)(item0 >> gsh);
-    if (b >= B) return;
-    const int g0 = (int)(item0 & (unsigned)(Gout - 1));
-    const int i = lane >> 2, j0 = 4 * (lane & 3);
-    const int bl = lane < 2 * KC ? lane : 2 * KC;
-    P0In in[IPW];
-#pragma unroll
-    for (int q = 0; q < IPW; ++q) in[q] = p0_load(idx, E, L, item0 + q, N, gsh, lane);
-    float gq[IPW][4], bv[IPW];
-#pragma unroll
-    for (int q = 0; q < IPW; ++q) {
-        const uint32_t rown = (uint32_t)(2 * (g0 + q) * K), colm = rown + (uint32_t)K;
-        const uint32_t si = rown + (uint32_t)in[q].e_i;
-        const uint32_t br = bl < KC ? rown + (uint32_t)in[q].e_b : rown + (uint32_t)in[q].old_n;
-        const uint32_t bc = (bl >= KC && bl < 2 * KC) ? colm + (uint32_t)in[q].e_b : colm + (uint32_t)in[q].old_m;
-#pragma unroll
-        for (int v = 0; v < 4; ++v) gq[q][v] = G[(si << nksh) + colm + ((in[q].w4 >> (8 * v)) & 0xffu)];
-        bv[q] = G[(br << nksh) + bc];
-    }
-#pragma unroll
-    for (int q = 0; q < IPW; ++q) {
-        const float u = shfl_f(bv[q], i), w = shfl_f(bv[q], 2 * KC);
-        float sv[4];
-        int sp[4];
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const float vj = shfl_f(bv[q], KC + j0 + v);
-            const float d = ((gq[q][v] - u) - vj) + w;
-            sv[v] = ((in[q].se + in[q].so[v]) - in[q].Eb) + 2.0f * d;
-            sp[v] = 4 * lane + v;
-        }
-        tf_finish<4, uint8_t>(sv, sp, keep, KC, scratch, L, 1, b, N, g0 + q, nullptr);
-    }
 }
 
 // ------------------------------------------------------------ level-1 tables
@@ -850,123 +720,10 @@ __device__ __forceinline__ void tf_table1(const float *__restrict__ G, const CT 
 }
 
 
-// ------------------------------------------------ level-1 tables, lean form (round 5; opt-in: MCQ_TABLE1_LEAN=1)
-// An experiment that is kept because of what it rules out.  k_tf_level1 issues 522 VALU instructions per wave, and 522 x 4
-// clocks x its waves / 4 SIMDs equals its duration to 1.5 % (profiles/r04_pmc_counters.txt): it looked bound by VALU issue.
-// tf_table1 above spends most of those instructions on bookkeeping -- a division per gathered entry to unflatten the compact
-// |A| x |B| grid, four lane-role borders per wave, compares and selects round every LDS access.  This form builds the same
-// tables, entry by entry from the same expression (so the same bits: tests/test_gpu_parity.py runs both), with the lanes laid out
-// so that nearly every address is `a constant of the lane + an immediate`:
-//   * lane = 16 r + c covers compact row 4 it + r, compact column c of a leaf: slot (table, it) gathers a 4 x |B| stripe --
-//     no division, the row entries of a stripe are one LDS byte read shared by the two tables of the same row codebook, the
-//     column entries two reads per wave; a gather's address is one add of a row part and a column part
-//   * the borders of all four tables are two gathers: quarter q of the wave = table q, lane c of the quarter = compact row
-//     (u = G[s_i][o_m], read through the symmetry of G as above) resp. compact column (v = G[o_n][s_j]); the four corner
-//     values w = G[o_n][o_m] have wave-uniform addresses: scalar loads
-//   * ((g - u) - v) + w is formed with u, v from LDS at immediate offsets and stored at an immediate offset
-// HALF the VALU instructions (k_tf_table1: 607 -> 302 static, k_tf_level1 2,659 -> 1,298) -- and the same time: 378.1 against
-// 377.9 us per launch at 8 x 256 / 65,536 vectors, 22.9 against 22.4 ms per encode at 16 x 256 (same box, interleaved:
-// profiles/r05_ab_table1_lean.txt).  The kernel does not wait for its VALU count; nor for the number of L1 accesses (r05_ab_l1_diet.txt).
-// One-byte entries, lists of 16 (K >= 32, <= 256).
-__device__ __forceinline__ void tf_table1_lean(const float *__restrict__ G, const uint8_t *__restrict__ idx, const TfLists &L,
-                                               long b, int N, int K, int X, int Y, float *leaf /* LDS [4][LS] + bytes */,
-                                               float (&t)[4]) {
-    constexpr int KCH = 16, KC = 16, RS = KCH + 1, BO = KCH * RS, LS = BO + 36;
-    const int lane = lane_id();
-    const uint8_t *id = idx + b * N;
-    const uint8_t *ent = L.ent;
-    const int G1 = N >> 1;
-    const uint8_t *px = L.pos[1] + ((b * G1 + X) * KC) * 2, *py = L.pos[1] + ((b * G1 + Y) * KC) * 2;
-    uint8_t *cent = reinterpret_cast<uint8_t *>(leaf + 4 * LS);     // [4][16] compact list -> codebook entry
-    uint8_t *crank = cent + 64;                                     // [4][16] candidate -> compact rank of its leaf
-    const int NK = N * K;
-    const int nksh = __builtin_ctz((unsigned)NK);
-    const int w = lane >> 4, c = lane & 15;
-    const int cb = (w < 2) ? 2 * X + w : 2 * Y + (w - 2);           // this quarter's codebook
-    int mypos = (w < 2 ? px : py)[2 * c + (w & 1)];
-    int myent = ent[(b * N + cb) * KCH + c];
-    int oldv = id[cb];
-    asm volatile("" : "+v"(mypos), "+v"(myent), "+v"(oldv));
-    int oldq[4];
-#pragma unroll
-    for (int qq = 0; qq < 4; ++qq) oldq[qq] = __builtin_amdgcn_readlane(oldv, 16 * qq);
-    uint32_t m = 1u << mypos;
-    m |= (uint32_t)dpp_i<0x121>((int)m);
-    m |= (uint32_t)dpp_i<0x122>((int)m);
-    m |= (uint32_t)dpp_i<0x124>((int)m);
-    m |= (uint32_t)dpp_i<0x128>((int)m);
-    crank[lane] = (uint8_t)__popc(m & ((1u << mypos) - 1u));
-    if ((m >> c) & 1u) cent[w * 16 + __popc(m & ((1u << c) - 1u))] = (uint8_t)myent;
-    int nn[4];                                                      // |A| of codebooks 2X, 2X+1; |B| of 2Y, 2Y+1
-#pragma unroll
-    for (int qq = 0; qq < 4; ++qq) nn[qq] = __popc((uint32_t)__builtin_amdgcn_readlane((int)m, 16 * qq));
-    wave_lds_fence();
-    const uint32_t rown0 = (uint32_t)(2 * X * K), colm0 = (uint32_t)(2 * Y * K);
-    // ---- borders: quarter w = table (a = w >> 1, cc = w & 1), lane c = compact row / column
-    const bool hi_a = (lane & 32) != 0, hi_c = (lane & 16) != 0;
-    const uint32_t rownL = rown0 + (hi_a ? (uint32_t)K : 0u), colmL = colm0 + (hi_c ? (uint32_t)K : 0u);
-    const uint32_t onL = (uint32_t)(hi_a ? oldq[1] : oldq[0]), omL = (uint32_t)(hi_c ? oldq[3] : oldq[2]);
-    // (compact slots beyond |A| / |B| hold stale bytes: kept inside the codebook, their values are never used)
-    const uint32_t km = (uint32_t)(K - 1);
-    const uint32_t eu = cent[((lane >> 5) << 4) + c] & km, ev = cent[32 + (((lane >> 4) & 1) << 4) + c] & km;
-    // u: G[s_i][o_m] read as G[o_m][s_i] (bit-identical: G is symmetric); v: G[o_n][s_j]
-    const float bu = G[((colmL + omL) << nksh) + rownL + eu];
-    const float bvv = G[((rownL + onL) << nksh) + colmL + ev];
-    float wq[4];
-#pragma unroll
-    for (int tb = 0; tb < 4; ++tb) {
-        const int a = tb >> 1, cc = tb & 1;
-        wq[tb] = G[((size_t)(rown0 + a * K + oldq[a]) << nksh) + colm0 + cc * K + oldq[2 + cc]];      // wave-uniform address
-    }
-    // ---- core gathers: slot (tb, it) = rows 4 it .. 4 it + 3 of table tb, all its columns
-    const uint32_t ec0 = cent[32 + c], ec1 = cent[48 + c];
-    const uint32_t colp[2] = {colm0 + ec0, colm0 + (uint32_t)K + ec1};
-    const bool cok[2] = {c < nn[2], c < nn[3]};
-    float g[4][4];
-    bool on[4][4];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const bool rok = 4 * it + w < nn[a];
-#pragma unroll
-            for (int cc = 0; cc < 2; ++cc) { on[2 * a + cc][it] = rok && cok[cc]; g[2 * a + cc][it] = 0.f; }
-            if (4 * it < nn[a]) {             // wave-uniform
-                const uint32_t er = cent[a * 16 + 4 * it + w];
-                const uint32_t rowp = (rown0 + (uint32_t)(a * K) + er) << nksh;
-#pragma unroll
-                for (int cc = 0; cc < 2; ++cc)
-                    if (on[2 * a + cc][it]) g[2 * a + cc][it] = G[rowp + colp[cc]];
-            }
-        }
-    leaf[w * LS + BO + c] = bu;               // (beyond |A| / |B|: never read)
-    leaf[w * LS + BO + 16 + c] = bvv;
-    wave_lds_fence();
-#pragma unroll
-    for (int tb = 0; tb < 4; ++tb) {
-        const int a = tb >> 1;
-        float *lt = leaf + tb * LS;
-        const float vj = lt[BO + 16 + c];
-#pragma unroll
-        for (int it = 0; it < 4; ++it)
-            if (4 * it < nn[a]) {             // wave-uniform
-                if (on[tb][it]) lt[(4 * it + w) * RS + c] = ((g[tb][it] - lt[BO + 4 * it + w]) - vj) + wq[tb];
-            }
-    }
-    wave_lds_fence();
-    const int i = lane >> 2, j0 = 4 * (lane & 3);
-    const int ri0 = crank[i], ri1 = crank[16 + i];
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-        const int rj0 = crank[32 + j0 + v], rj1 = crank[48 + j0 + v];
-        t[v] = ((leaf[ri0 * RS + rj0] + leaf[LS + ri0 * RS + rj1]) + leaf[2 * LS + ri1 * RS + rj0]) + leaf[3 * LS + ri1 * RS + rj1];
-    }
-}
-
 constexpr int tf_leaf_lds_floats(int KCH, int code_bytes = 1) { return 4 * (KCH * (KCH + 1) + 36) + 16 + 16 * code_bytes; }
 
 // combine of level 1: siblings X = 2g, Y = 2g + 1 (pairs of codebooks).  One wave per (b, g).
-template <int KCH, int KC, typename CT = uint8_t, bool LEAN = false>
+template <int KCH, int KC, typename CT = uint8_t>
 __device__ __forceinline__ void tf_pair1_body(unsigned bid, float *leaf, const float *__restrict__ G, const CT *__restrict__ idx,
                                               const float *__restrict__ E, const TfLists &L, long B, int N, int K, int keep,
                                               CT *__restrict__ idx_final, const int *__restrict__ nact) {
@@ -990,8 +747,7 @@ __device__ __forceinline__ void tf_pair1_body(unsigned bid, float *leaf, const f
 #pragma unroll
     for (int v = 0; v < VPL; ++v) so[v] = L.S[1][(b * G1 + Y) * KC + j0 + v];
     float t[VPL];
-    if constexpr (LEAN && KCH == 16 && KC == 16 && sizeof(CT) == 1) tf_table1_lean(G, idx, L, b, N, K, X, Y, leaf, t);
-    else tf_table1<KCH, KC, CT>(G, idx, L, b, N, K, X, Y, leaf, t, stp);
+    tf_table1<KCH, KC, CT>(G, idx, L, b, N, K, X, Y, leaf, t, stp);
     float sv[VPL];
     int sp[VPL];
 #pragma unroll
@@ -1005,18 +761,18 @@ __device__ __forceinline__ void tf_pair1_body(unsigned bid, float *leaf, const f
     stp.flush(2, bid, 64);
 }
 
-template <int KCH, int KC, typename CT = uint8_t, bool LEAN = false>
+template <int KCH, int KC, typename CT = uint8_t>
 __global__ void __launch_bounds__(64)
 k_tf_pair1(const float *__restrict__ G, const CT *__restrict__ idx, const float *__restrict__ E, TfLists L, long B,
            int N, int K, int keep, CT *__restrict__ idx_final, const int *__restrict__ nact) {
     __shared__ __attribute__((aligned(16))) float leaf[tf_leaf_lds_floats(KCH, sizeof(CT))];
-    tf_pair1_body<KCH, KC, CT, LEAN>(blockIdx.x, leaf, G, idx, E, L, B, N, K, keep, idx_final, nact);
+    tf_pair1_body<KCH, KC, CT>(blockIdx.x, leaf, G, idx, E, L, B, N, K, keep, idx_final, nact);
 }
 
 // T_1 of COUSIN pairs under the siblings of a higher level -> tabs[b][t][KC*KC].  One wave per (b, t); workgroup id
 // mod ntab = t, so an XCD reads the leaf blocks of its own tables only.  Under sibling pair g each side has `per`
 // level-1 groups: t = (g * per + a) * per + c  ->  X = 2 g per + a,  Y = (2 g + 1) per + c.
-template <int KCH, int KC, typename CT = uint8_t, bool LEAN = false>
+template <int KCH, int KC, typename CT = uint8_t>
 __device__ __forceinline__ void tf_table1_body(unsigned bid, float *leaf, const float *__restrict__ G, const CT *__restrict__ idx,
                                                const TfLists &L, long B, int N, int K, int ntab, int per, float *__restrict__ tabs,
                                                const int *__restrict__ nact) {
@@ -1031,8 +787,7 @@ __device__ __forceinline__ void tf_table1_body(unsigned bid, float *leaf, const 
     const int c = t & (per - 1), a = (t >> psh) & (per - 1), g = t >> (2 * psh);
     const int X = 2 * g * per + a, Y = (2 * g + 1) * per + c;
     float tv[VPL];
-    if constexpr (LEAN && KCH == 16 && KC == 16 && sizeof(CT) == 1) tf_table1_lean(G, idx, L, b, N, K, X, Y, leaf, tv);
-    else tf_table1<KCH, KC, CT>(G, idx, L, b, N, K, X, Y, leaf, tv, stp);
+    tf_table1<KCH, KC, CT>(G, idx, L, b, N, K, X, Y, leaf, tv, stp);
     float *dst = tabs + ((size_t)(b * ntab + t) * (KC * KC) + VPL * lane);
     if constexpr (VPL == 4) {
         __builtin_nontemporal_store((f32x4){tv[0], tv[1], tv[2], tv[3]}, reinterpret_cast<f32x4 *>(dst));
@@ -1044,26 +799,26 @@ __device__ __forceinline__ void tf_table1_body(unsigned bid, float *leaf, const 
     stp.flush(3, bid, 64);
 }
 
-template <int KCH, int KC, typename CT = uint8_t, bool LEAN = false>
+template <int KCH, int KC, typename CT = uint8_t>
 __global__ void __launch_bounds__(64)
 k_tf_table1(const float *__restrict__ G, const CT *__restrict__ idx, TfLists L, long B, int N, int K, int ntab,
             int per, float *__restrict__ tabs, const int *__restrict__ nact) {
     __shared__ __attribute__((aligned(16))) float leaf[tf_leaf_lds_floats(KCH, sizeof(CT))];
-    tf_table1_body<KCH, KC, CT, LEAN>(blockIdx.x, leaf, G, idx, L, B, N, K, ntab, per, tabs, nact);
+    tf_table1_body<KCH, KC, CT>(blockIdx.x, leaf, G, idx, L, B, N, K, ntab, per, tabs, nact);
 }
 
 // The sibling combines of level 1 and the cousin tables the level-2 combine needs, in ONE launch: both read the level-1 lists
 // and nothing of each other; the workgroup-to-XCD mapping of both kinds is what it is in their own launches (the pair
 // blocks are a multiple of 8).
-template <int KCH, int KC, typename CT = uint8_t, bool LEAN = false>
+template <int KCH, int KC, typename CT = uint8_t>
 __global__ void __launch_bounds__(64)
 k_tf_level1(const float *__restrict__ G, const CT *__restrict__ idx, const float *__restrict__ E, TfLists L, long B, int N,
             int K, int keep, int ntab, int per, float *__restrict__ tabs, const int *__restrict__ nact, unsigned pair_blocks,
             unsigned tab_blocks, int ntab2, int per2, float *__restrict__ tabs2) {
     __shared__ __attribute__((aligned(16))) float leaf[tf_leaf_lds_floats(KCH, sizeof(CT))];
-    if (blockIdx.x < pair_blocks) tf_pair1_body<KCH, KC, CT, LEAN>(blockIdx.x, leaf, G, idx, E, L, B, N, K, keep, nullptr, nact);
-    else if (blockIdx.x < pair_blocks + tab_blocks) tf_table1_body<KCH, KC, CT, LEAN>(blockIdx.x - pair_blocks, leaf, G, idx, L, B, N, K, ntab, per, tabs, nact);
-    else tf_table1_body<KCH, KC, CT, LEAN>(blockIdx.x - pair_blocks - tab_blocks, leaf, G, idx, L, B, N, K, ntab2, per2, tabs2, nact);   // (16 codebooks: the tables of level 3 as well)
+    if (blockIdx.x < pair_blocks) tf_pair1_body<KCH, KC, CT>(blockIdx.x, leaf, G, idx, E, L, B, N, K, keep, nullptr, nact);
+    else if (blockIdx.x < pair_blocks + tab_blocks) tf_table1_body<KCH, KC, CT>(blockIdx.x - pair_blocks, leaf, G, idx, L, B, N, K, ntab, per, tabs, nact);
+    else tf_table1_body<KCH, KC, CT>(blockIdx.x - pair_blocks - tab_blocks, leaf, G, idx, L, B, N, K, ntab2, per2, tabs2, nact);   // (16 codebooks: the tables of level 3 as well)
 }
 
 // copy COUNT tables of KH x KH floats each from global memory (rows of KH) to LDS (rows of KH + 1: the odd row stride keeps the
@@ -1230,14 +985,15 @@ k_tf_comb(const float *__restrict__ E, TfLists L, long B, int N, int v, int keep
                 sp[u] = p0 + u;
             }
             float ov;
-            int op;
-            wave_select_fast<VPL>(sv, sp, keep, KC * KC, sel2, ov, op);
-            const bool got = lane < keep;
+            int op, dst;
+            bool got;
+            wave_select_set<VPL>(sv, sp, keep, KC * KC, sel2, got, dst, ov, op);
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 if (q == c) { cv[q] = got ? ov : INFINITY; cp[q] = got ? op : kBigPos; }
         }
-        tf_finish<4, CT>(cv, cp, keep, KC, sel2, L, v + 1, b, N, h, nullptr);
+        // (the chunk survivors lie wherever their chunk's selection left them: the merge orders its list by position itself)
+        tf_finish<4, CT, false>(cv, cp, keep, KC, sel2, L, v + 1, b, N, h, nullptr);
     } else {
         float bv = INFINITY;
         int bp = kBigPos;

@@ -567,9 +567,9 @@ def test_logits_refine_is_logits_argmax_then_refine_indexes():
 
 @pytest.mark.parametrize("per_lane,cnt", [(1, 8), (4, 8), (4, 16), (4, 32), (16, 16), (16, 32), (16, 64), (4, 1), (16, 1)])
 def test_wave_selection_paths(per_lane, cnt):
-    """wave_select_fast on its own (mcq_test_select): the cnt smallest of 64 * per_lane scores in (value, position) order,
-    for random scores, heavy ties, survivors clustered in a few lanes (more than the two-per-lane path holds: the general
-    quickselect takes over) and constant input"""
+    """wave_select_set on its own (mcq_test_select): the cnt smallest of 64 * per_lane scores by (value, position), listed in
+    ascending position (oracle/mcq_oracle.c::select_smallest), for random scores, heavy ties, survivors clustered in a few lanes
+    (more than one per lane: the general quickselect takes over) and constant input"""
     from quantization_amd import _lib
     L = _lib.lib()
     M = 64 * per_lane
@@ -599,7 +599,7 @@ def test_wave_selection_paths(per_lane, cnt):
     assert L.mcq_test_select(dsc.data_ptr(), len(cases), per_lane, cnt, ov.data_ptr(), op.data_ptr(), None) == 0
     torch.cuda.synchronize()
     for c in range(len(cases)):
-        order = np.lexsort((np.arange(M), sc[c]))[:cnt]          # by value, then position
+        order = np.sort(np.lexsort((np.arange(M), sc[c]))[:cnt])          # the cnt smallest by (value, position), listed by position
         assert np.array_equal(op[c, :cnt].cpu().numpy(), order), (c, per_lane, cnt)
         assert np.array_equal(ov[c, :cnt].cpu().numpy(), sc[c][order])
 
@@ -751,43 +751,3 @@ def test_compute_loss_of_a_512_entry_quantizer_follows_the_reference():
             want = z[f"grad_it{iters}.{name}"]
             g = p.grad.detach().cpu().numpy()
             assert np.linalg.norm(g - want) <= 1e-3 * np.linalg.norm(want) + 1e-7, (iters, name)
-
-
-@pytest.mark.parametrize("hook", ["MCQ_TABLE1_LEAN=1", "MCQ_PAIR0_LOOP=1", "MCQ_PAIR0_MULTI=2", "MCQ_PAIR0_MULTI=4"])
-def test_opt_in_kernel_variants_give_the_same_codes(hook):
-    """The round-5 experiments that are kept behind environment hooks because they are no faster (LAB_NOTEBOOK.md):
-    MCQ_TABLE1_LEAN=1 (tf_table1_lean: the level-1 tables with a third fewer VALU instructions), MCQ_PAIR0_LOOP=1
-    (k_tf_pair0_loop: level 0 as persistent waves that prefetch their next item) and MCQ_PAIR0_MULTI=2|4 (k_tf_pair0_multi: that
-    many sibling pairs of a vector per wave, memory phases overlapped).  The hooks are read once per process, so a
-    variant runs in a child: every shape whose combine tree has level-1 tables over lists of 16 (4, 8 and 16 codebooks of 64
-    and 256 entries), bit-exact against the oracle."""
-    import subprocess
-    import sys
-    code = r'''
-import sys
-import numpy as np, torch
-sys.path.insert(0, %r); sys.path.insert(0, %r)
-from golden import fixtures
-from oracle.oracle import OracleQuantizer
-from quantization_amd import Quantizer
-for name in ("config_a_d256_n4", "trained_d64_b8_p2", "synth_d40_k64_n8", "synth_d64_k256_n16", "stress_mean10_d64_b8_p2"):
-    fx = fixtures.load(name)
-    st = fx["state"]
-    q = Quantizer(fx["D"], fx["K"], fx["N"])
-    sd = q.state_dict()
-    for k, v in st.items():
-        sd[k] = torch.from_numpy(np.asarray(v))
-    q.load_state_dict(sd)
-    q = q.cuda()
-    o = OracleQuantizer(st["centers"], float(st["centers_scale"]), st["to_logits.weight"], st["to_logits.bias"], float(st["logits_scale"]))
-    x = torch.from_numpy(fx["x"]).cuda()
-    for it in (1, 5):
-        with torch.no_grad():
-            got = q.encode(x, it, as_bytes=False).cpu().numpy()
-        want = o.compute_indexes(fx["x"], it)
-        assert np.array_equal(got, want), (name, it, int((got != want).any(axis=1).sum()))
-print("lean ok")
-''' % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    env = dict(os.environ, **dict([hook.split("=")]))
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "lean ok" in r.stdout, r.stderr[-3000:]
