@@ -434,7 +434,16 @@ int run_tf_combines(const float *G, const CT *idx_cur, CT *idx_new, const Worksp
         CT *fin = (N == 2) ? idx_new : nullptr;
         const dim3 grid((unsigned)(B * (N / 2)));
         if (prof) prof->begin(CAT_LEVEL0);
-        MCQ_TF_LAUNCH2((k_tf_pair0<8, CT>), (k_tf_pair0<16, CT>), grid, dim3(64), G, idx_cur, w.E, L, B, N, K, keep, fin, nact);
+        bool done0 = false;
+        if constexpr (sizeof(CT) == 1) {
+            // lists of 16 one-byte entries: the slot-major kernel (a 16-lane group of a gather = one table row: a fifth faster than
+            // the lane-major one, profiles/r06_ab_pair0_slot_major.txt)
+            if (!small) {
+                hipLaunchKernelGGL(k_tf_pair0s, grid, dim3(64), 0, st, G, idx_cur, w.E, L, B, N, K, keep, fin, nact);
+                done0 = true;
+            }
+        }
+        if (!done0) MCQ_TF_LAUNCH2((k_tf_pair0<8, CT>), (k_tf_pair0<16, CT>), grid, dim3(64), G, idx_cur, w.E, L, B, N, K, keep, fin, nact);
         MCQ_LAUNCH_CHECK();
         if (prof) prof->end(CAT_LEVEL0);
     }
@@ -1288,6 +1297,11 @@ int mcq_test_select(const float *scores, int cases, int per_lane, int cnt, float
         case 1: hipLaunchKernelGGL((k_test_select<1>), dim3(cases), dim3(64), 0, st, scores, cnt, out_v, out_p); break;
         case 4: hipLaunchKernelGGL((k_test_select<4>), dim3(cases), dim3(64), 0, st, scores, cnt, out_v, out_p); break;
         case 16: hipLaunchKernelGGL((k_test_select<16>), dim3(cases), dim3(64), 0, st, scores, cnt, out_v, out_p); break;
+        // (negative: the same number of keys per lane in the slot-major layout, key i of a lane at position 64 * i + lane; the third
+        // layout, positions in any order, is the general form followed by a rank by position)
+        case -4: hipLaunchKernelGGL((k_test_select<4, kSlotMajor>), dim3(cases), dim3(64), 0, st, scores, cnt, out_v, out_p); break;
+        case -16: hipLaunchKernelGGL((k_test_select<16, kSlotMajor>), dim3(cases), dim3(64), 0, st, scores, cnt, out_v, out_p); break;
+        case -1004: hipLaunchKernelGGL((k_test_select<4, kAnyOrder>), dim3(cases), dim3(64), 0, st, scores, cnt, out_v, out_p); break;
         default: return MCQ_EINVAL;
     }
     hipError_t e = hipGetLastError();

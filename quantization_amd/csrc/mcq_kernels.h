@@ -227,8 +227,12 @@ __device__ __forceinline__ u64 wave_select_mask(uint32_t ko, u64 valid, int cnt,
     return __ballot(has);
 }
 
-// LANE_MAJOR: the positions p[i] ascend with (lane, i) -- every caller but the merge of a chunked selection.
-template <int VPL, bool LANE_MAJOR = true>
+// How the wave holds its candidates: kLaneMajor -- position p[i] = VPL * lane + i (a lane holds VPL consecutive candidates: the
+// loads of stage 0 are 16-byte pieces per lane); kSlotMajor -- p[i] = 64 * i + lane (a 16-lane group shares a table row: the
+// gathers of the level-0 combine); kAnyOrder -- anything (the merge of a chunked selection).  Either way the list is handed
+// over in ascending position.
+enum { kLaneMajor = 0, kSlotMajor = 1, kAnyOrder = 2 };
+template <int VPL, int LAYOUT = kLaneMajor>
 __device__ __forceinline__ int wave_select_set(const float (&v)[VPL], const int (&p)[VPL], int cnt, int M,
                                                u64 *lds /* kSelectLdsU64 per wave */, bool &has, int &dst, float &out_v, int &out_p) {
     const int lane = lane_id();
@@ -238,7 +242,7 @@ __device__ __forceinline__ int wave_select_set(const float (&v)[VPL], const int 
         dst = 0;
         return 1;
     }
-    if constexpr (VPL == 1 && LANE_MAJOR) {
+    if constexpr (VPL == 1 && LAYOUT != kAnyOrder) {
         const bool cand = p[0] != kBigPos;
         const u64 valid = __ballot(cand);
         const uint32_t ko = cand ? ord32(v[0]) : 0xffffffffu;
@@ -250,7 +254,7 @@ __device__ __forceinline__ int wave_select_set(const float (&v)[VPL], const int 
         out_p = p[0];
         return __popcll(selm);
     }
-    if constexpr (VPL > 1 && LANE_MAJOR) {
+    if constexpr (VPL > 1 && LAYOUT != kAnyOrder) {
         // (every slot holds a candidate: the callers with several keys per lane have no empty positions)
         float lm = v[0];
 #pragma unroll
@@ -269,13 +273,23 @@ __device__ __forceinline__ int wave_select_set(const float (&v)[VPL], const int 
             // score and position of survivor number d (in position order) go to lo[d] and lo[64 + d]: one ds_write2_b32 from
             // the registers they are in
             uint32_t *lo = reinterpret_cast<uint32_t *>(lds);
-            int d = 0;
+            if constexpr (LAYOUT == kLaneMajor) {
+                int d = 0;
 #pragma unroll
-            for (int i = 0; i < VPL; ++i) d = mbcnt64(m[i], d);            // survivors in the lanes below this one
+                for (int i = 0; i < VPL; ++i) d = mbcnt64(m[i], d);        // survivors in the lanes below this one
 #pragma unroll
-            for (int i = 0; i < VPL; ++i) {
-                if (v[i] <= T0v) { lo[d] = __float_as_uint(v[i]); lo[64 + d] = (uint32_t)p[i]; }
-                if (i + 1 < VPL) d = add_lane_bit(d, m[i]);
+                for (int i = 0; i < VPL; ++i) {
+                    if (v[i] <= T0v) { lo[d] = __float_as_uint(v[i]); lo[64 + d] = (uint32_t)p[i]; }
+                    if (i + 1 < VPL) d = add_lane_bit(d, m[i]);
+                }
+            } else {
+                int base = 0;                                              // survivors in the slots before this one (wave-uniform)
+#pragma unroll
+                for (int i = 0; i < VPL; ++i) {
+                    const int d = mbcnt64(m[i], base);
+                    if (v[i] <= T0v) { lo[d] = __float_as_uint(v[i]); lo[64 + d] = (uint32_t)p[i]; }
+                    base += __popcll(m[i]);
+                }
             }
             wave_lds_fence();
             const uint32_t ev = lo[lane], ep = lo[64 + lane];              // (lanes >= c read what an earlier selection left: unused)
@@ -326,20 +340,31 @@ __device__ __forceinline__ int wave_select_set(const float (&v)[VPL], const int 
             cmask[i] &= (r > target) ? ltm[i] : ~(ltm[i] | pivot_bit);
         }
     }
-    // the selected keys, one per lane (at most cnt <= 64 of them), in the order of (lane, slot)
+    // the selected keys, one per lane (at most cnt <= 64 of them), in position order where the layout gives one
     uint32_t *lo = reinterpret_cast<uint32_t *>(lds);
     int d = 0, nsel = 0;
+    if constexpr (LAYOUT == kSlotMajor) {
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) {
-        const u64 mi = __ballot(key[i] <= T);
-        d = mbcnt64(mi, d);
-        nsel += __popcll(mi);
-    }
+        for (int i = 0; i < VPL; ++i) {
+            const bool s = key[i] <= T;
+            const u64 mi = __ballot(s);
+            d = mbcnt64(mi, nsel);
+            if (s && d < 64) { lo[d] = __float_as_uint(v[i]); lo[64 + d] = (uint32_t)p[i]; }
+            nsel += __popcll(mi);
+        }
+    } else {
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) {
-        const bool s = key[i] <= T;
-        if (s && d < 64) { lo[d] = __float_as_uint(v[i]); lo[64 + d] = (uint32_t)p[i]; }
-        d += s ? 1 : 0;
+        for (int i = 0; i < VPL; ++i) {
+            const u64 mi = __ballot(key[i] <= T);
+            d = mbcnt64(mi, d);
+            nsel += __popcll(mi);
+        }
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const bool s = key[i] <= T;
+            if (s && d < 64) { lo[d] = __float_as_uint(v[i]); lo[64 + d] = (uint32_t)p[i]; }
+            d += s ? 1 : 0;
+        }
     }
     wave_lds_fence();
     has = lane < nsel;
@@ -348,7 +373,7 @@ __device__ __forceinline__ int wave_select_set(const float (&v)[VPL], const int 
     out_v = __uint_as_float(ev);
     out_p = (int)ep;
     dst = lane;
-    if constexpr (!LANE_MAJOR) {
+    if constexpr (LAYOUT == kAnyOrder) {
         // the list is in ascending position whatever the lanes' order: rank by position among the selected
         const int mine = has ? out_p : kBigPos;
         int r = 0;
@@ -362,7 +387,7 @@ __device__ __forceinline__ int wave_select_set(const float (&v)[VPL], const int 
 // list (ascending position) goes to out[j]; a list that runs out of candidates is padded with (INF, M - 1) as the oracle pads
 // it.  Lets the tests drive every path of the selection with adversarial inputs (ties, all survivors in a few lanes, more
 // survivors than one per lane).
-template <int VPL>
+template <int VPL, int LAYOUT = kLaneMajor>
 __global__ void __launch_bounds__(64)
 k_test_select(const float *__restrict__ scores, int cnt, float *__restrict__ out_v, int *__restrict__ out_p) {
     __shared__ u64 scratch[kSelectLdsU64];
@@ -371,13 +396,13 @@ k_test_select(const float *__restrict__ scores, int cnt, float *__restrict__ out
     int p[VPL];
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
-        p[i] = VPL * lane_id() + i;
+        p[i] = (LAYOUT == kSlotMajor) ? 64 * i + lane_id() : VPL * lane_id() + i;
         v[i] = sc[p[i]];
     }
     bool has;
     int dst, op;
     float ov;
-    const int nsel = wave_select_set<VPL>(v, p, cnt, 64 * VPL, scratch, has, dst, ov, op);
+    const int nsel = wave_select_set<VPL, LAYOUT>(v, p, cnt, 64 * VPL, scratch, has, dst, ov, op);
     if (has) {
         out_v[(size_t)blockIdx.x * 64 + dst] = ov;
         out_p[(size_t)blockIdx.x * 64 + dst] = op;

@@ -450,7 +450,7 @@ __device__ __forceinline__ void tf_emit(const TfLists &L, long b, int N, int nle
 }
 
 // select `keep` of the wave's scores and write the next level's list (or, for the last combine, the result)
-template <int VPL, typename CT = uint8_t, bool LANE_MAJOR = true>
+template <int VPL, typename CT = uint8_t, int LAYOUT = kLaneMajor>
 __device__ __forceinline__ void tf_finish(const float (&sv)[VPL], const int (&sp)[VPL], int keep, int KCin, u64 *scratch,
                                           const TfLists &L, int vout /* level of the list written */, long b, int N,
                                           int gout, CT *__restrict__ idx_final) {
@@ -470,7 +470,7 @@ __device__ __forceinline__ void tf_finish(const float (&sv)[VPL], const int (&sp
     float ov;
     int op, dst;
     bool has;
-    wave_select_set<VPL, LANE_MAJOR>(sv, sp, keep, KCin * KCin, scratch, has, dst, ov, op);
+    wave_select_set<VPL, LAYOUT>(sv, sp, keep, KCin * KCin, scratch, has, dst, ov, op);
     if (has) {
         const long o = (b * (N >> vout) + gout) * keep + dst;
         L.pos[vout][2 * o] = (uint8_t)(op / KCin);
@@ -514,6 +514,72 @@ k_tf_pair0(const float *__restrict__ G, const CT *__restrict__ idx, const float 
     }
     stp.at(2);                                  // leaf table gathered, scores formed
     tf_finish<VPL, CT>(sv, sp, keep, KC, scratch, L, 1, b, N, g, idx_final);
+    stp.at(3);                                  // selection done, list written
+    stp.flush(1, blockIdx.x, 64);
+}
+
+// Level 0, lists of 16 one-byte entries, in the SLOT-MAJOR layout (round 6): slot v of lane l is the pair (row i = 4 v + l / 16,
+// column j = l % 16), position 64 v + l.  k_tf_pair0 above gives a lane one row and four columns, so a 16-lane group of a gather
+// touches four rows x four columns -- sixteen 64-byte pieces, sixteen L1 accesses (the L1 counts one access per 16-lane group and
+// 64-byte piece, and k_tf_pair0 runs at 0.89 accesses per clock and CU of the one it has: LAB_NOTEBOOK.md).  Here a group is ONE row
+// and its sixteen columns: the columns of a shortlist fall into about ten of the row's sixteen pieces, so a gather costs about 41
+// accesses instead of 62.  The rest follows: the row entries of a slot are the four bytes of one dword of the list (a wave-uniform
+// load, the lane takes byte l / 16), the scores of a list reach the lanes as one coalesced load and four ds_bpermute, the border
+// lanes reuse the column entry they hold.  Same expressions, same values; the list leaves in ascending position as ever
+// (wave_select_set<kSlotMajor>).
+__global__ void __launch_bounds__(64)
+k_tf_pair0s(const float *__restrict__ G, const uint8_t *__restrict__ idx, const float *__restrict__ E, TfLists L, long B,
+            int N, int K, int keep, uint8_t *__restrict__ idx_final, const int *__restrict__ nact) {
+    constexpr int KC = 16, VPL = 4;
+    __shared__ u64 scratch[kSelectLdsU64];
+    Stamps stp;
+    if (nact) B = *nact;
+    const int Gout = N >> 1;
+    const int g = (int)(blockIdx.x & (unsigned)(Gout - 1));
+    const long b = (long)(blockIdx.x >> __builtin_ctz((unsigned)Gout));
+    if (b >= B) return;
+    const int lane = lane_id();
+    const int n = 2 * g, m = n + 1;
+    const int q4 = lane >> 4, c = lane & 15;
+    const uint8_t *en = L.ent + (b * N + n) * KC, *em = en + KC;
+    const float *Sn = L.S[0] + (b * N + n) * KC, *Sm = Sn + KC;
+    // everything a lane needs from the lists, requested together
+    const uint32_t *enw = reinterpret_cast<const uint32_t *>(en);
+    uint32_t rw[VPL];                                        // dword v of list n = the entries of rows 4 v .. 4 v + 3
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) rw[v] = enw[v];
+    int e_j = em[c];                                         // column entry (also the border entry of lanes 16 .. 31)
+    int e_b = en[c];                                         // row entry at position c: the border entry of lanes 0 .. 15
+    int old_n = idx[b * N + n], old_m = idx[b * N + m];
+    const float sn_c = Sn[c], so = Sm[c];
+    const float Eb = E[b];
+    asm volatile("" : "+v"(e_j), "+v"(e_b), "+v"(old_n), "+v"(old_m));
+    stp.at(1);                                  // lists and scores in
+    const int nksh = __builtin_ctz((unsigned)(N * K));
+    const uint32_t rown = (uint32_t)(n * K), colm = (uint32_t)(m * K);
+    float gq[VPL];
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+        const uint32_t e_i = (rw[v] >> (8 * q4)) & 0xffu;
+        gq[v] = G[((rown + e_i) << nksh) + colm + (uint32_t)e_j];
+    }
+    // border: lanes [0, 16) G[s_n,l][o_m], [16, 32) G[o_n][s_m,l-16], the others G[o_n][o_m]
+    const uint32_t br = lane < KC ? rown + (uint32_t)e_b : rown + (uint32_t)old_n;
+    const uint32_t bc = (lane >= KC && lane < 2 * KC) ? colm + (uint32_t)e_j : colm + (uint32_t)old_m;
+    const float bv = G[(br << nksh) + bc];
+    const float vj = shfl_f(bv, KC + c), w = shfl_f(bv, 2 * KC);
+    float sv[VPL];
+    int sp[VPL];
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+        const int i = 4 * v + q4;
+        const float u = shfl_f(bv, i), se = shfl_f(sn_c, i);
+        const float d = ((gq[v] - u) - vj) + w;
+        sv[v] = ((se + so) - Eb) + 2.0f * d;
+        sp[v] = 64 * v + lane;
+    }
+    stp.at(2);                                  // leaf table gathered, scores formed
+    tf_finish<VPL, uint8_t, kSlotMajor>(sv, sp, keep, KC, scratch, L, 1, b, N, g, idx_final);
     stp.at(3);                                  // selection done, list written
     stp.flush(1, blockIdx.x, 64);
 }
@@ -993,7 +1059,7 @@ k_tf_comb(const float *__restrict__ E, TfLists L, long B, int N, int v, int keep
                 if (q == c) { cv[q] = got ? ov : INFINITY; cp[q] = got ? op : kBigPos; }
         }
         // (the chunk survivors lie wherever their chunk's selection left them: the merge orders its list by position itself)
-        tf_finish<4, CT, false>(cv, cp, keep, KC, sel2, L, v + 1, b, N, h, nullptr);
+        tf_finish<4, CT, kAnyOrder>(cv, cp, keep, KC, sel2, L, v + 1, b, N, h, nullptr);
     } else {
         float bv = INFINITY;
         int bp = kBigPos;

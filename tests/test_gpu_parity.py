@@ -565,15 +565,19 @@ def test_logits_refine_is_logits_argmax_then_refine_indexes():
         assert torch.equal(i2, q._compute_indexes(x, iters))
 
 
-@pytest.mark.parametrize("per_lane,cnt", [(1, 8), (4, 8), (4, 16), (4, 32), (16, 16), (16, 32), (16, 64), (4, 1), (16, 1)])
+@pytest.mark.parametrize("per_lane,cnt", [(1, 8), (4, 8), (4, 16), (4, 32), (16, 16), (16, 32), (16, 64), (4, 1), (16, 1),
+                                          (-4, 16), (-4, 32), (-16, 32), (-4, 64), (-1004, 16), (-1004, 64)])
 def test_wave_selection_paths(per_lane, cnt):
     """wave_select_set on its own (mcq_test_select): the cnt smallest of 64 * per_lane scores by (value, position), listed in
     ascending position (oracle/mcq_oracle.c::select_smallest), for random scores, heavy ties, survivors clustered in a few lanes
     (more than one per lane: the general quickselect takes over) and constant input"""
     from quantization_amd import _lib
     L = _lib.lib()
-    M = 64 * per_lane
-    rs = np.random.RandomState(per_lane * 100 + cnt)
+    # (negative per_lane: the slot-major layout, key i of a lane at position 64 i + lane; -1004: four keys per lane handled as
+    # positions in no particular order -- the general form and a rank by position)
+    kpl = abs(per_lane) % 1000
+    M = 64 * kpl
+    rs = np.random.RandomState(abs(per_lane) * 100 + cnt)
     cases = []
     for c in range(40):
         kind = c % 5
@@ -583,9 +587,12 @@ def test_wave_selection_paths(per_lane, cnt):
             sc = rs.randint(0, 6, size=M).astype(np.float64)
         elif kind == 2:                                   # the small scores all sit in a few lanes
             sc = rs.standard_normal(M) + 100
-            lanes = rs.choice(64, size=max(cnt, 12), replace=False)
+            lanes = rs.choice(64, size=min(64, max(cnt, 12)), replace=False)
             for l in lanes:
-                sc[per_lane * l:per_lane * (l + 1)] = rs.standard_normal(per_lane)
+                if per_lane in (-4, -16):
+                    sc[l::64] = rs.standard_normal(kpl)
+                else:
+                    sc[kpl * l:kpl * (l + 1)] = rs.standard_normal(kpl)
         elif kind == 3:
             sc = np.full(M, 3.25)
         else:                                             # negative and positive, zeros
