@@ -96,7 +96,7 @@ def kernel_work(B, D, N, K):
 
 # kernel-name prefixes of the launch categories (rocprofv3's Kernel_Name without `void mcq::`), for the --pmc passes
 CATEGORY_KERNELS = {"logits_product_argmax": "k_fgemm<1>", "xc_product": "k_fgemm<0>", "frames_to_limbs": "k_fix_rows<",
-                    "residual_energies": "k_tf_er<", "stage0_tables": "k_tf_stage0", "combine_level0": "k_tf_pair0<",
+                    "residual_energies": "k_tf_er<", "stage0_tables": "k_tf_stage0", "combine_level0": "k_tf_pair0",
                     "combine_level1": "k_tf_pair1<", "tables_level1": "k_tf_table1<", "combine_level2": "k_tf_comb<",
                     "level1_combines_and_tables": "k_tf_level1<", "tables_upper_levels": "k_tf_up<",
                     "combine_upper_levels": "k_tf_comb3<"}
@@ -220,23 +220,36 @@ def pmc_live(D, N, B, iters, budget_s=200.0):
 
 
 def pmc_committed(dom_name, D, N, K, B, iters):
-    """the newest committed --pmc passes of the same command (profiles/rNN_pmc_traffic*.json), when the live read is off"""
+    """the newest committed --pmc passes of EXACTLY this workload (profiles/rNN_pmc_traffic*.json carry their shape as `_shape`;
+    files from before round 6 are the headline shape when they have no suffix and (dim, codebooks, 256, 65,536, 5) of their
+    `_d<dim>_n<codebooks>` suffix otherwise), when the live read is off.  Counters of another batch size or pass count would
+    price this launch time against the wrong bytes: no match, no counters."""
     import glob
-    tag = "" if (D, N, K, B, iters) == (512, 8, 256, 65536, 5) else f"_d{D}_n{N}"
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r??_pmc_traffic{tag}.json")))
-    if not files or (tag == "" and (D, N, K, B, iters) != (512, 8, 256, 65536, 5)):
-        return None, None
-    pmc = json.load(open(files[-1]))
-    if dom_name not in pmc:
-        return None, None
-    return pmc[dom_name], "committed: profiles/%s (separate --pmc runs of this command; not counters of this run)" % os.path.basename(files[-1])
+    import re
+    want = {"D": D, "N": N, "K": K, "B": B, "iters": iters}
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r??_pmc_traffic*.json")), reverse=True):
+        try:
+            pmc = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        shape = pmc.get("_shape")
+        if shape is None:
+            m = re.search(r"_pmc_traffic(?:_d(\d+)_n(\d+))?\.json$", f)
+            shape = {"D": int(m.group(1)) if m.group(1) else 512, "N": int(m.group(2)) if m.group(2) else 8, "K": 256, "B": 65536, "iters": 5}
+        if shape == want and dom_name in pmc:
+            return pmc[dom_name], "committed: profiles/%s (separate --pmc runs of this command; not counters of this run)" % os.path.basename(f)
+    return None, None
 
 
 def roofline_of(dom_name, kern, work, pmc, pmc_src):
-    """`roofline` of the dominant launch category.  A product: i8 MFMA operations against the dense i8 peak.  A table kernel
-    has no FLOPs and its HBM bytes are small: what binds it is the L2 -> L1 path, priced by the 128-byte LINES its 4-byte gathers
-    move (TCP_TCC_READ_REQ x 128 B) against the L2 peak -- `frac` -- with the useful bytes beside it (`useful_frac`) and the HBM
-    figures as the sub-object `hbm`."""
+    """`roofline` of the dominant launch category, ONE definition for every round: `frac` = the kernel's USEFUL work per launch /
+    its launch time / the peak of the resource named by `bound`.
+      * a product (`bound: "mfma"`): i8 MFMA operations against the dense i8 peak;
+      * a table kernel (`bound: "hbm"`): its algorithmic HBM bytes (per-vector inputs, lists and tables written and read back:
+        SURVEY 8d's per-vector figure x the vectors of a launch) against the HBM peak.  It has no FLOPs.
+    What actually limits a table kernel is reported BESIDE that, never as `frac`: `l2.useful_frac` (the 4-byte Gram entries it
+    uses against the L2 -> L1 peak) and `l2.line_saturation` (the 128-byte lines its gathers move, TCP_TCC_READ_REQ x 128 B,
+    against the same peak: a gauge of how full that path is, most of it waste)."""
     dom_fl, dom_by, dom_tb = work
     dom_ms = kern["avg_ms"]
     traffic = pmc.get("traffic_bytes") if pmc else None
@@ -250,24 +263,20 @@ def roofline_of(dom_name, kern, work, pmc, pmc_src):
                 "note": "i8 MFMA operations (ten limb products per multiply-add of the exact fixed-point product) against "
                         "the dense i8 peak; unit reads TOP/s"}
     hbm_ach = dom_by / (dom_ms * 1e-3) / 1e9
-    hbm = {"achieved": round(hbm_ach, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(hbm_ach / PEAK_HBM_GBPS, 4),
-           "gbyte_per_launch": round(dom_by / 1e9, 3),
-           "note": "algorithmic HBM bytes (per-vector inputs, lists and tables written and read back) / launch time"}
     useful = dom_tb / (dom_ms * 1e-3) / 1e9
+    l2 = {"peak": PEAK_L2_GBPS, "unit": "GB/s", "useful_table_gbyte_per_launch": round(dom_tb / 1e9, 3),
+          "useful_frac": round(useful / PEAK_L2_GBPS, 4)}
     if lines:
-        ach = lines / (dom_ms * 1e-3) / 1e9
-        return {"bound": "l2", "kernel": dom_name, "achieved": round(ach, 1), "peak": PEAK_L2_GBPS, "unit": "GB/s",
-                "frac": round(ach / PEAK_L2_GBPS, 4), "useful_frac": round(useful / PEAK_L2_GBPS, 4),
-                "line_gbyte_per_launch": round(lines / 1e9, 3), "useful_table_gbyte_per_launch": round(dom_tb / 1e9, 3),
-                "lines_per_useful_byte": round(lines / max(dom_tb, 1.0), 2),
-                "traffic": traffic, "traffic_source": pmc_src, "avg_launch_ms": round(float(dom_ms), 4), "hbm": hbm,
-                "note": "a table kernel: no FLOPs to price, HBM far from its peak.  What binds it is the L2 -> L1 path: every 4-byte "
-                        "Gram gather that misses the L1 moves a 128-byte line.  achieved = TCP_TCC_READ_REQ x 128 B per launch / the "
-                        "launch time measured here (HIP events), peak = the aggregate L2 -> L1 rate of MI355X_MICROARCH.md; "
-                        "useful_frac prices only the entries used; traffic = HBM-side bytes (2*FETCH_SIZE + WRITE_SIZE) x 1024"}
-    return dict(hbm, bound="hbm", kernel=dom_name, traffic=traffic, traffic_source=pmc_src, avg_launch_ms=round(float(dom_ms), 4),
-                l2={"useful_table_gbyte_per_launch": round(dom_tb / 1e9, 3), "l2_frac_useful": round(useful / PEAK_L2_GBPS, 4),
-                    "note": "no L1 <- L2 request counter for this shape: the L2 line figure is not priced"})
+        l2.update(line_gbyte_per_launch=round(lines / 1e9, 3), line_saturation=round(lines / (dom_ms * 1e-3) / 1e9 / PEAK_L2_GBPS, 4),
+                  lines_per_useful_byte=round(lines / max(dom_tb, 1.0), 2))
+    l2["note"] = ("what binds a table kernel: every 4-byte Gram gather that misses the L1 moves a 128-byte line (TCP_TCC_READ_REQ x 128 B "
+                  "per launch / the launch time = line_saturation of the aggregate L2 -> L1 rate); useful_frac prices only the entries used")
+    return {"bound": "hbm", "kernel": dom_name, "achieved": round(hbm_ach, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+            "frac": round(hbm_ach / PEAK_HBM_GBPS, 4), "traffic": traffic, "traffic_source": pmc_src,
+            "algorithmic_gbyte_per_launch": round(dom_by / 1e9, 3), "avg_launch_ms": round(float(dom_ms), 4), "l2": l2,
+            "note": "a table kernel (no FLOPs): frac = algorithmic HBM bytes per launch (per-vector inputs, lists and tables written "
+                    "and read back) / launch time (HIP events) / 8 TB/s -- the same definition every round; traffic = HBM-side bytes "
+                    "of the PMC passes, (2*FETCH_SIZE + WRITE_SIZE) x 1024.  The kernel is not HBM-bound: see l2"}
 
 
 def load_quantizer(state, D, K, N, dev):
@@ -295,40 +304,46 @@ def timed(fn, reps):
     return ts[len(ts) // 2]
 
 
-def cpu_baseline(state, D, budget_s=12.0):
-    """torch-CPU restatement of the reference's op sequence on this host: a short probe picks
-    the thread count and chunk size (torch on hundreds of threads is slower than on 16-32 for
-    these small ops), then a bounded sample is timed."""
+def cpu_baseline(state, D, budget_s=30.0):
+    """torch-CPU restatement of the reference's op sequence on this host: x ~ N(0,1) fp32 seed 0, chunk
+    sweep {64, 256, 1024}, all host threads -- and, because torch on hundreds of threads is slower than on 8-32 for these small
+    ops, the same chunks on 8 and 32 threads.  The whole sweep table is reported; `value` is a bounded sample (about budget_s of
+    CPU work) at the best point, `cores` the threads it used."""
     from oracle.torch_port import TorchPortQuantizer
     ncpu = os.cpu_count() or 1
     port = TorchPortQuantizer(state)
-    rs = np.random.RandomState(99)
-    probe = torch.from_numpy(rs.standard_normal((128, D)).astype(np.float32))
+    rs = np.random.RandomState(0)
+    pool = torch.from_numpy(rs.standard_normal((1024, D)).astype(np.float32))
     torch.set_num_threads(min(ncpu, 8))
-    port.encode(probe[:32], 5, chunk=32)   # warm-up
-    best = (0.0, min(ncpu, 8), 128)
+    port.encode(pool[:32], 5, chunk=32)   # warm-up (excluded)
+    sweep, best = [], (0.0, min(ncpu, 8), 64)
     t_probe = time.time()
-    for threads in sorted({min(ncpu, t) for t in (8, 16, 32, 64)}):
+    for threads in sorted({min(ncpu, t) for t in (8, 32, ncpu)}):
         torch.set_num_threads(threads)
-        for chunk in (64, 128):
+        for chunk in (64, 256, 1024):
+            if time.time() - t_probe > 45:      # (a slow host: keep what the sweep has so far)
+                break
+            n = max(chunk, 128)
             t = time.time()
-            port.encode(probe, 5, chunk=chunk)
-            r = 128 / (time.time() - t)
+            port.encode(pool[:n], 5, chunk=chunk)
+            r = n / (time.time() - t)
+            sweep.append({"threads": threads, "chunk": chunk, "vectors": n, "vectors_per_s": round(r, 1)})
             if r > best[0]:
                 best = (r, threads, chunk)
-        if time.time() - t_probe > 20:
-            break
     rate, threads, chunk = best
     torch.set_num_threads(threads)
-    n = int(max(chunk, min(16384, rate * budget_s)) // chunk * chunk)
+    n = int(max(chunk, min(32768, rate * budget_s)) // chunk * chunk)
     xs = torch.from_numpy(rs.standard_normal((n, D)).astype(np.float32))
     t = time.time()
     port.encode(xs, 5, chunk=chunk)
     dt = time.time() - t
-    return {"value": round(n / dt, 1), "unit": "vectors/s", "cores": threads, "kind": "port",
-            "sample": f"{n} Gaussian vectors of the same workload, torch-CPU restatement of the reference op "
+    allc = [p_ for p_ in sweep if p_["threads"] == ncpu]
+    return {"value": round(n / dt, 1), "unit": "vectors/s", "cores": threads, "kind": "port", "host_threads": ncpu,
+            "sample": f"{n} Gaussian vectors (seed 0) of the same workload, torch-CPU restatement of the reference op "
                       f"sequence (oracle/torch_port.py), chunks of {chunk}, {threads} of {ncpu} host threads "
-                      f"(best of a short sweep), {dt:.1f} s"}
+                      f"(the best point of the sweep), {dt:.1f} s",
+            "all_threads_best": max((p_["vectors_per_s"] for p_ in allc), default=None),
+            "sweep": sweep}
 
 
 def fixture_parity(q, dev, iters):
@@ -343,24 +358,52 @@ def fixture_parity(q, dev, iters):
     with torch.no_grad():
         got = q.encode(torch.from_numpy(x).to(dev), 5).cpu().numpy()
     bad = (got != z["codes_it5"]).any(axis=1)
-    margin = z["margin_it5"]
+    margin = z["margin2_it5"] if "margin2_it5" in z.files else z["margin_it5"]
     return {"rows": int(len(bad)), "mismatches": int(bad.sum()),
             "near_tie_mismatches": int((bad & (margin < NEAR_TIE)).sum()),
             "clear_margin_mismatches": int((bad & (margin >= NEAR_TIE)).sum()),
             "note": "codes the reference's Quantizer.encode returned for the same seeded state and inputs; a near tie "
-                    "has an fp64 decision margin < 2e-6 (the reference's own code flips under a re-ordered fp32 sum)"}
+                    "has an fp64 decision margin < 2e-6 of the competing scores (the reference's own code flips under a re-ordered fp32 sum)"}
 
 
-def trainer_leg(dev, D, N, batch, p_iters, process_group=None, data_parallel=False):
-    """ms per QuantizerTrainer.step in both phases (free-running, no host sync per step)."""
+def oracle_pin(o_cls):
+    """Which build of the CPU oracle checked this run (it is compiled where it runs): compiler, flags, a checksum of the library
+    and a 64-row known-answer self-test against codes the REFERENCE produced (tests/golden/config_b_d512_n8.npz)."""
+    import hashlib
+    import re
+    import subprocess
+    from quantization_amd import synthetic as gen
+    from oracle import oracle as omod
+    info = {}
+    try:
+        mk = open(os.path.join(ROOT, "oracle", "Makefile")).read()
+        info["cflags"] = re.search(r"^CFLAGS\s*=\s*(.*)$", mk, re.M).group(1).strip()
+        info["cc"] = subprocess.run(["gcc", "--version"], capture_output=True, text=True).stdout.split("\n")[0]
+        info["library_sha256_16"] = hashlib.sha256(open(omod._SO, "rb").read()).hexdigest()[:16]
+        z = np.load(os.path.join(ROOT, "tests", "golden", "config_b_d512_n8.npz"))
+        st = gen.synthetic_state(int(z["state_seed"]), int(z["D"]), int(z["K"]), int(z["N"]))
+        o = o_cls(st["centers"], float(st["centers_scale"]), st["to_logits.weight"], st["to_logits.bias"], float(st["logits_scale"]))
+        x = gen.make_gaussian(int(z["x_seed"]), int(z["B"]), int(z["D"]))[:64]
+        got = o.encode(x, 5)
+        info["self_test"] = {"rows": 64, "equal_to_reference_codes": bool(np.array_equal(got, z["codes_it5"][:64])),
+                             "codes_sha256_16": hashlib.sha256(np.ascontiguousarray(got).tobytes()).hexdigest()[:16]}
+    except Exception as e:      # noqa: BLE001
+        info["error"] = f"{type(e).__name__}: {e}"[:200]
+    return info
+
+
+def trainer_leg(dev, D, N, batch, p_iters, process_group=None, data_parallel=False, overlap=True, force_collectives=False):
+    """ms per QuantizerTrainer.step in both phases (free-running, no host sync per step).  overlap=False: the whole gradient bucket
+    in ONE all-reduce after the backward (MCQ_TRAINER_OVERLAP=0) instead of two overlapped parts."""
     from quantization_amd import QuantizerTrainer
     random.seed(0)
     torch.manual_seed(0)
     tr = QuantizerTrainer(dim=D, bytes_per_frame=N, device=dev, phase_one_iters=p_iters, phase_two_iters=p_iters,
-                          process_group=process_group, data_parallel=data_parallel)
+                          process_group=process_group, data_parallel=data_parallel, force_collectives=force_collectives)
+    tr.overlap_all_reduce = bool(overlap)
     xt = torch.randn(batch, D, device=dev)
-    ms = {}
-    for phase, until in (("phase1_ms_per_step", p_iters), ("phase2_ms_per_step", 2 * p_iters + 1)):
+    ms, nparam = {}, {}
+    for phase, until in (("phase1", p_iters), ("phase2", 2 * p_iters + 1)):
         for _ in range(10):
             tr.step(xt)
         torch.cuda.synchronize()
@@ -368,10 +411,12 @@ def trainer_leg(dev, D, N, batch, p_iters, process_group=None, data_parallel=Fal
         while tr.cur_iter < until - 5:
             tr.step(xt)
         torch.cuda.synchronize()
-        ms[phase] = round((time.perf_counter() - t4) / (tr.cur_iter - n0) * 1e3, 3)
+        ms[phase + "_ms_per_step"] = round((time.perf_counter() - t4) / (tr.cur_iter - n0) * 1e3, 3)
+        qq = tr.quantizer
+        # what a data-parallel step all-reduces: the flat gradient bucket + the forward batch sums (N K mean probabilities, N K counts, 4 sums)
+        nparam[phase] = sum(p.numel() for p in qq.parameters()) + 2 * qq.num_codebooks * qq.codebook_size + 4
         while tr.cur_iter < until + (1 if until == p_iters else 0):
             tr.step(xt)
-    nparam = sum(p.numel() for p in tr.quantizer.parameters())
     return ms, nparam
 
 
@@ -412,6 +457,10 @@ def main():
     ap.add_argument("--no-pmc-check", action="store_true",
                     help="do not run the rocprofv3 --pmc child that reads the dominant kernel's L1 <- L2 requests live")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--dp-iters", type=int, default=2000,
+                    help="iterations per phase of the data-parallel config-E trainer leg under --gpus N > 1 (BASELINE config E: 10,000)")
+    ap.add_argument("--shard-vectors", type=int, default=1 << 20,
+                    help="vectors per GPU of the config-C shard leg under --gpus N > 1 (BASELINE config C: 8M over 8 GPUs)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -485,25 +534,66 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # ---- data-parallel trainer (BASELINE config E): every rank takes part in the collectives
+    # ---- BASELINE config C under --gpus N > 1: the 8M-vector encode sharded over the GPUs, 1,048,576 vectors per GPU, no collective on
+    # the data path; every rank times its own shard between barriers, value = all shards / the slowest rank
+    shard = None
+    if dist is not None and not args.no_secondary:
+        shard = {}
+        try:
+            Bs = args.shard_vectors
+            gs = torch.Generator(device=dev)
+            gs.manual_seed(1000 + rank)
+            xs_ = torch.randn(Bs, D, generator=gs, device=dev, dtype=torch.float32)
+            with torch.no_grad():
+                q.encode(xs_, iters)
+                torch.cuda.synchronize()
+                barrier()
+                torch.cuda.synchronize()
+                t0s = time.perf_counter()
+                for _ in range(2):
+                    cs_ = q.encode(xs_, iters)
+                torch.cuda.synchronize()
+                barrier()
+                torch.cuda.synchronize()
+                ts = torch.tensor([time.perf_counter() - t0s], device=dev, dtype=torch.float64)
+            every = [torch.zeros_like(ts) for _ in range(world)]
+            dist.all_gather(every, ts)
+            dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+            shard = {"batch_per_gpu": Bs, "global_batch": Bs * world, "steps": 2, "encode_vectors_per_s": round(world * Bs * 2 / float(ts.item()), 1),
+                     "ms_per_step": round(float(ts.item()) / 2 * 1e3, 2),
+                     "per_rank_vectors_per_s": [round(Bs * 2 / float(e.item()), 1) for e in every],
+                     "note": "BASELINE.json configs[2]: batch-sharded encode, 1,048,576 vectors per GPU (8,388,608 over 8 GPUs), no "
+                             "collective on the data path; barrier + synchronize on both sides, the slowest rank's time"}
+            del xs_, cs_
+            torch.cuda.empty_cache()
+        except Exception as e:      # noqa: BLE001
+            shard = {"error": f"{type(e).__name__}: {e}"[:300]}
+
+    # ---- data-parallel trainer (BASELINE config E): every rank takes part in the collectives.  Config E's schedule at
+    # --dp-iters iterations per phase (default 2,000 + 2,000; the config's own 10,000 + 10,000 with --dp-iters 10000), for a global and
+    # a per-GPU batch of 4,096 frames, with the gradient all-reduce in two overlapped parts and as one collective
     dp = None
     dp_failed = False
     if dist is not None and not args.no_secondary:
-        dp = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend()}
+        dp = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "iterations_per_phase": args.dp_iters}
         try:      # (a failure here must not take the headline line with it)
-            for tag, per_gpu in (("global_batch_4096", max(4096 // world, 64)), ("per_gpu_batch_4096", 4096)):
-                ms, nparam = trainer_leg(dev, D, N, per_gpu, 40, data_parallel=True)
-                tt = torch.tensor([ms["phase1_ms_per_step"], ms["phase2_ms_per_step"]], device=dev, dtype=torch.float64)
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                dp[tag] = {"per_gpu_batch": per_gpu, "global_batch": per_gpu * world,
-                           "phase1_ms_per_step": round(float(tt[0]), 3), "phase2_ms_per_step": round(float(tt[1]), 3),
-                           "all_reduce_bytes_per_step_phase2": 4 * nparam + 4 * (N * K * 2 + 4)}
+            for tag, per_gpu in (("config_e_global_batch_4096", max(4096 // world, 64)), ("config_e_per_gpu_batch_4096", 4096)):
+                for ov in (True, False):
+                    ms, nparam = trainer_leg(dev, D, N, per_gpu, args.dp_iters, data_parallel=True, overlap=ov)
+                    tt = torch.tensor([ms["phase1_ms_per_step"], ms["phase2_ms_per_step"]], device=dev, dtype=torch.float64)
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    d_ = dp.setdefault(tag, {"per_gpu_batch": per_gpu, "global_batch": per_gpu * world,
+                                             "all_reduce_bytes_per_step_phase1": 4 * nparam["phase1"],
+                                             "all_reduce_bytes_per_step_phase2": 4 * nparam["phase2"]})
+                    key = "overlapped_two_part_all_reduce" if ov else "one_all_reduce"
+                    d_[key] = {"phase1_ms_per_step": round(float(tt[0]), 3), "phase2_ms_per_step": round(float(tt[1]), 3),
+                               "frames_per_s_phase2": round(per_gpu * world / (float(tt[1]) * 1e-3), 1)}
         except Exception as e:      # noqa: BLE001  (reported in the line AND in the exit code, after the line is out)
             dp["error"] = f"{type(e).__name__}: {e}"[:300]
             dp_failed = True
         dp["note"] = ("QuantizerTrainer.step, data_parallel=True: the flat gradient bucket all-reduced (RCCL) in two parts -- "
-                      "the centers' gradient while the classifier's backward still runs, the rest after it -- + one small "
-                      "forward all-reduce of the batch sums per step; max over ranks")
+                      "the centers' gradient while the classifier's backward still runs, the rest after it -- or as one collective "
+                      "(MCQ_TRAINER_OVERLAP=0), + one small forward all-reduce of the batch sums per step; max over ranks")
 
     if dist is not None:      # a failure of the trainer leg on ANY rank fails the run (after the headline line is printed)
         f = torch.tensor([1.0 if dp_failed else 0.0], device=dev)
@@ -523,7 +613,8 @@ def main():
                         state["to_logits.bias"], float(state["logits_scale"]))
     rows = np.random.RandomState(1).choice(B, min(256, B), replace=False)
     want = o.encode(x[rows].cpu().numpy(), iters)
-    parity = {"sampled_rows_vs_oracle": int(len(rows)), "bit_exact": bool(np.array_equal(codes[rows].cpu().numpy(), want))}
+    parity = {"sampled_rows_vs_oracle": int(len(rows)), "bit_exact": bool(np.array_equal(codes[rows].cpu().numpy(), want)),
+              "oracle_build": oracle_pin(OracleQuantizer)}
     if (D, N, K) == (512, 8, 256) and not args.no_secondary:      # (--no-secondary: every launch has the headline shape)
         parity["vs_reference_fixture"] = fixture_parity(q, dev, iters)
 
@@ -542,7 +633,11 @@ def main():
         dom_name = max(kernels, key=lambda n: kernels[n]["ms_per_encode"])
         pmc, pmc_src = None, None
         if world == 1 and not args.no_pmc_check and not args.no_secondary:
-            pmc_all = pmc_live(D, N, B, iters)
+            try:      # (a rocprofv3 format change or a partial output file must not take the headline line with it)
+                pmc_all = pmc_live(D, N, B, iters)
+            except Exception as e:      # noqa: BLE001
+                pmc_all = None
+                sys.stderr.write(f"bench.py: live --pmc read failed ({type(e).__name__}: {e}); falling back to the committed passes\n")
             if pmc_all and dom_name in pmc_all:
                 pmc, pmc_src = pmc_all[dom_name], "live: rocprofv3 --kernel-trace --pmc child runs of this command (bench.py pmc_live)"
         if pmc is None:
@@ -572,6 +667,14 @@ def main():
         if _lines > 0:
             line_floor_ms = round((LIMB_PRODUCTS * exec_fpv * B / (PEAK_I8_MFMA_TOPS * 1e12) + iters * _lines / (PEAK_L2_GBPS * 1e9)) * 1e3, 3)
     value = world * B * args.steps / dt
+    if roofline is not None:
+        roofline["whole_encode"] = {"ms_per_step": round(dt / args.steps * 1e3, 3), "executed_floor_ms": executed_floor_ms,
+                                    "frac_of_floor": round(executed_floor_ms / (dt / args.steps * 1e3), 4),
+                                    "line_floor_ms": line_floor_ms,
+                                    "frac_of_line_floor": None if line_floor_ms is None else round(line_floor_ms / (dt / args.steps * 1e3), 4),
+                                    "note": "the whole encode against what THIS algorithm costs at the chip's peaks (products at the dense i8 "
+                                            "peak + the table passes' useful bytes at the L2 peak), and against the same with the table passes "
+                                            "priced by the 128-byte lines they move: see whole_encode"}
     out = {
         "metric": "vectors encoded/sec at dim=512, 8 codebooks; uint8 codes bit-exact vs ref",
         "value": round(value, 1), "unit": "vectors/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -609,6 +712,8 @@ def main():
     }
     if dp is not None:
         out["dp_trainer"] = dp
+    if shard is not None:
+        out["configs"] = {"C_shard_dim512_bytes8_1M": shard}
     if args.no_secondary:
         print(json.dumps(out), flush=True)
         if dist is not None:
@@ -718,30 +823,57 @@ def main():
 
     # ---- secondary: QuantizerTrainer.step (BASELINE config E shape on one GPU: dim 512, 8 bytes, batch 4096)
     if world == 1:
-        ms_t, _ = trainer_leg(dev, D, N, 4096, 60)
-        out["trainer_step"] = dict(ms_t, batch=4096, note="QuantizerTrainer.step, fused (autograd-free) path, free-running")
-        # BASELINE config E at its length: the trainer's DEFAULT schedule (10,000 + 10,000 iterations, quantization.py:581-583),
-        # batches of 4,096 fresh Gaussian frames (tests/test_gpu_trainer_long.py checks what such a run converges to)
-        from quantization_amd import QuantizerTrainer
-        random.seed(0)
-        torch.manual_seed(0)
-        tr = QuantizerTrainer(dim=D, bytes_per_frame=N, device=dev)
-        gq = torch.Generator(device=dev)
-        gq.manual_seed(1)
-        torch.cuda.synchronize()
-        t5 = time.perf_counter()
-        nsteps = 0
-        while not tr.done():
-            tr.step(torch.randn(4096, D, device=dev, generator=gq))
-            nsteps += 1
-        torch.cuda.synchronize()
-        tot = time.perf_counter() - t5
-        out["trainer_step"]["config_e"] = {"steps": nsteps, "trainer_total_s": round(tot, 2), "ms_per_step": round(tot / nsteps * 1e3, 4),
-                                           "frames_per_s": round(nsteps * 4096 / tot, 1),
-                                           "note": "QuantizerTrainer(dim=512, bytes_per_frame=8) with its default 10,000 + 10,000 iterations "
-                                                   "on one GPU, 4,096 frames per step, frame generation included"}
+        try:
+            ms_t, _ = trainer_leg(dev, D, N, 4096, 60)
+            out["trainer_step"] = dict(ms_t, batch=4096, note="QuantizerTrainer.step, fused (autograd-free) path, free-running")
+            # the same step with every collective of the data-parallel path issued through RCCL in a group of ONE rank
+            # (force_collectives): what the collectives cost on this box before any link is involved
+            try:
+                import socket
+                import torch.distributed as dist1
+                with socket.socket() as so:
+                    so.bind(("127.0.0.1", 0))
+                    port = so.getsockname()[1]
+                dist1.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", world_size=1, rank=0, device_id=dev)
+                one = {}
+                for ov in (True, False):
+                    ms1, np1 = trainer_leg(dev, D, N, 4096, 60, data_parallel=True, overlap=ov, force_collectives=True)
+                    one["overlapped_two_part_all_reduce" if ov else "one_all_reduce"] = ms1
+                one["all_reduce_bytes_per_step"] = {k_: 4 * v_ for k_, v_ in np1.items()}
+                one["note"] = ("one-rank nccl (= RCCL) group, force_collectives=True: the broadcast of the parameters, the forward all-reduce "
+                               "and the gradient all-reduce(s) of every step run through RCCL; against trainer_step.phase*_ms_per_step "
+                               "this is the collectives' fixed cost")
+                out["trainer_step"]["one_rank_rccl"] = one
+                dist1.destroy_process_group()
+            except Exception as e:      # noqa: BLE001
+                out["trainer_step"]["one_rank_rccl"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            # BASELINE config E at its length: the trainer's DEFAULT schedule (10,000 + 10,000 iterations, quantization.py:581-583),
+            # batches of 4,096 fresh Gaussian frames (tests/test_gpu_trainer_long.py checks what such a run converges to)
+            from quantization_amd import QuantizerTrainer
+            random.seed(0)
+            torch.manual_seed(0)
+            tr = QuantizerTrainer(dim=D, bytes_per_frame=N, device=dev)
+            gq = torch.Generator(device=dev)
+            gq.manual_seed(1)
+            torch.cuda.synchronize()
+            t5 = time.perf_counter()
+            nsteps = 0
+            while not tr.done():
+                tr.step(torch.randn(4096, D, device=dev, generator=gq))
+                nsteps += 1
+            torch.cuda.synchronize()
+            tot = time.perf_counter() - t5
+            out["trainer_step"]["config_e"] = {"steps": nsteps, "trainer_total_s": round(tot, 2), "ms_per_step": round(tot / nsteps * 1e3, 4),
+                                               "frames_per_s": round(nsteps * 4096 / tot, 1),
+                                               "note": "QuantizerTrainer(dim=512, bytes_per_frame=8) with its default 10,000 + 10,000 iterations "
+                                                       "on one GPU, 4,096 frames per step, frame generation included"}
+        except Exception as e:      # noqa: BLE001  (an optional leg: the headline line must still come out)
+            out.setdefault("trainer_step", {})["error"] = f"{type(e).__name__}: {e}"[:300]
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(state, D)
+        try:
+            out["cpu_baseline"] = cpu_baseline(state, D)
+        except Exception as e:      # noqa: BLE001
+            out["cpu_baseline"] = {"value": None, "unit": "vectors/s", "cores": 0, "kind": "port", "sample": "failed", "error": f"{type(e).__name__}: {e}"[:300]}
     print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

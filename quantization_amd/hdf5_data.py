@@ -38,6 +38,13 @@ class MiniHdf5File:
                 self.buf = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
             except ValueError as e:          # (an empty file cannot be mapped)
                 raise Hdf5FormatError(f"{filename}: not an HDF5 file ({e})") from None
+        try:
+            self._parse_superblock(filename)
+        except BaseException:                  # (a junk file: the mapping must not outlive the failed constructor)
+            self.close()
+            raise
+
+    def _parse_superblock(self, filename: str):
         b = self.buf
         base = -1
         off = 0

@@ -1,9 +1,10 @@
 #!/usr/bin/env python
 """profiles/rNN_pmc_traffic.json from the FETCH_SIZE / WRITE_SIZE passes of tools/pmc_passes.sh.
-usage: pmc_traffic.py gpurun_out/<pmc dir> > profiles/rNN_pmc_traffic.json   (keys = bench.py's kernel categories)"""
+usage: pmc_traffic.py gpurun_out/<pmc dir> [dim codebooks [batch passes]] > profiles/rNN_pmc_traffic.json   (keys = bench.py's kernel categories)"""
 import collections, csv, glob, json, os, re, sys
 root = sys.argv[1]
 DIM, NCB = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (512, 8)
+BATCH, ITERS = (int(sys.argv[4]), int(sys.argv[5])) if len(sys.argv) > 5 else (65536, 5)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import category_kernels      # category -> kernel-name prefix (the same map bench.py's live read uses)
 KERNELS = category_kernels(NCB)
@@ -20,6 +21,8 @@ out = {"_note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, KB pe
                 "are included; Gram-table reads served by an L2 are not.",
        "source": "profiles/rNN_pmc_counters.txt (tools/pmc_passes.sh, tools/pmc_traffic.py)"}
 out["_note"] = out["_note"].replace("dim 512, 8 codebooks", f"dim {DIM}, {NCB} codebooks")
+# the workload these counters belong to: bench.py's pmc_committed() only prices a launch of EXACTLY this shape with them
+out["_shape"] = {"D": DIM, "N": NCB, "K": 256, "B": BATCH, "iters": ITERS}
 for cat, prefix in KERNELS.items():
     names = [n for n in vals if n.startswith(prefix)]
     f = [x for n in names for x in vals[n]["FETCH_SIZE"]]
