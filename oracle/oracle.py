@@ -81,12 +81,17 @@ def ladder(N: int, K: int):
 class OracleQuantizer:
     """CPU oracle for one quantizer state (numpy in, numpy out)."""
 
-    def __init__(self, centers, centers_scale, weight=None, bias=None, logits_scale=0.0):
+    def __init__(self, centers, centers_scale, weight=None, bias=None, logits_scale=0.0, scales_exp=None):
+        """scales_exp: (exp(10 centers_scale), exp(10 logits_scale)) as fp32 values to use instead of this host's torch exp --
+        the factors a fixture's reference run computed with (torch's fp32 exp differs in the last bit between CPUs)."""
         lib = _load()
         centers = _f32(centers)
         self.N, self.K, self.D = centers.shape
-        self.cscale_exp = scale_exp(centers_scale)
-        self.lscale_exp = scale_exp(logits_scale)
+        if scales_exp is not None:
+            self.cscale_exp, self.lscale_exp = float(np.float32(scales_exp[0])), float(np.float32(scales_exp[1]))
+        else:
+            self.cscale_exp = scale_exp(centers_scale)
+            self.lscale_exp = scale_exp(logits_scale)
         f = ctypes.c_float
         if weight is not None:
             weight = _f32(weight)
@@ -103,7 +108,7 @@ class OracleQuantizer:
     def from_state_dict(cls, sd):
         g = lambda k: np.asarray(sd[k].detach().cpu().numpy() if hasattr(sd[k], "detach") else sd[k])
         return cls(g("centers"), float(g("centers_scale")), g("to_logits.weight"), g("to_logits.bias"),
-                   float(g("logits_scale")))
+                   float(g("logits_scale")), scales_exp=getattr(sd, "scales_exp", None))
 
     def __del__(self):
         try:

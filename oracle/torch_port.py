@@ -30,13 +30,18 @@ class TorchPortQuantizer:
         self.N, self.K, self.D = self.centers.shape
         self.weight, self.bias = t("to_logits.weight"), t("to_logits.bias")
         self.centers_scale, self.logits_scale = t("centers_scale"), t("logits_scale")
+        # the two scale factors: this host's torch exp, or the ones a fixture pins (tests/golden/fixtures.PinnedState: torch's fp32
+        # exp differs in the last bit between CPUs, and the fixtures' codes belong to the generating machine's)
+        pin = getattr(state, "scales_exp", None)
+        self.cscale = torch.tensor(pin[0], dtype=torch.float32) if pin is not None else (self.centers_scale * 10.0).exp()
+        self.lscale = torch.tensor(pin[1], dtype=torch.float32) if pin is not None else (self.logits_scale * 10.0).exp()
 
     def scaled_centers(self):
-        return (self.centers_scale * 10.0).exp() * self.centers
+        return self.cscale * self.centers
 
     def compute_indexes(self, x: torch.Tensor, iters: int) -> torch.Tensor:
         B = x.shape[0]
-        sx = (self.logits_scale * 10.0).exp() * x
+        sx = self.lscale * x
         logits = torch.nn.functional.linear(sx, self.weight, self.bias).reshape(B, self.N, self.K)
         idx = logits.argmax(dim=-1)
         for _ in range(iters):

@@ -5,6 +5,7 @@
 #include "mcq_fix_kernels.h"
 #include "mcq_loss_kernels.h"
 #include "mcq_tf_kernels.h"
+#include "mcq_pass16_kernels.h"
 #include "mcq_train_kernels.h"
 
 #include <cstdlib>
@@ -424,6 +425,12 @@ const char *const kCatNames[CAT_COUNT] = {
         }                                                                                                    \
         if (!s_) hipLaunchKernelGGL(BIGK, grid, block, 0, st, __VA_ARGS__);                                  \
     } while (0)
+// MCQ_PASS16=0: the separate kernels for 16 x 16 codebooks as well (same-box A/B of the LDS-resident pass; identical results)
+inline bool pass16_enabled() {
+    static const bool on = !(getenv("MCQ_PASS16") && atoi(getenv("MCQ_PASS16")) == 0);
+    return on;
+}
+
 template <typename CT>
 int run_tf_combines(const float *G, const CT *idx_cur, CT *idx_new, const WorkspaceT<CT> &w, const TfLists &L, long B, int N,
                     int K, const int *nact, hipStream_t st, Prof *prof) {
@@ -571,6 +578,7 @@ int run_encode_t(const float *x, long B, const void *prepared, float lscale, int
             if (rc) return rc;
             if (prof) prof->end(CAT_XC);
         }
+        int iters_left = iters;
         // without skipping: indexes are refined in place in w.idx, nothing is packed
         CT *idx_cur = w.idx, *idx_new = skip ? w.idxB : w.idx, *idx_pk = w.idxC;
         const int *map_cur = nullptr, *nact = nullptr;
@@ -581,11 +589,31 @@ int run_encode_t(const float *x, long B, const void *prepared, float lscale, int
             if (prof) prof->untimed();
         }
         bool wrote_direct = false;
+        if constexpr (sizeof(CT) == 1) {
+            // 16 codebooks of 16 entries (the trainer's first phase at 8 bytes per frame): ALL passes of the call in one launch of
+            // persistent workgroups that hold the Gram matrix in LDS (mcq_pass16_kernels.h); not under the profiler, whose
+            // categories are the separate launches
+            if (K == 16 && N == 16 && iters > 0 && !skip && prof == nullptr && pass16_enabled()) {
+                static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tf_pass16),
+                                                             hipFuncAttributeMaxDynamicSharedMemorySize, kP16LdsBytes);
+                if (attr != hipSuccess) return (int)attr;
+                Pass16Args a;
+                a.G = P.G; a.XC = w.XC; a.xx = w.xx; a.Q = P.Q; a.idx = w.idx; a.B = Bc; a.iters = iters;
+                const bool direct_out = pack == 1;
+                a.out_i64 = (direct_out && out_i64) ? out_i64 + lo * N : nullptr;
+                a.out_u8 = direct_out ? (out_u8 ? out_u8 + lo * N : (codes_also ? codes_also + lo * N : nullptr)) : nullptr;
+                const long wgs = (Bc + kP16Waves - 1) / kP16Waves;
+                hipLaunchKernelGGL(k_tf_pass16, dim3((unsigned)(wgs < 256 ? wgs : 256)), dim3(64 * kP16Waves), kP16LdsBytes, st, a);
+                MCQ_LAUNCH_CHECK();
+                if (direct_out) continue;
+                iters_left = 0;
+            }
+        }
         // E / R of pass it + 1 can be formed by the wave that emits the indexes of pass it (tf_emit), which saves that pass
         // its two E / R launches: 4, 8 or 16 codebooks, no compaction of the vectors between the passes, not under the profiler
         const bool er_in_emit = !skip && (N == 4 || N == 8 || N == 16);
         bool er_ready = false;
-        for (int it = 0; it < iters; ++it) {
+        for (int it = 0; it < iters_left; ++it) {
             if (!er_ready) {
                 if (prof) prof->begin(CAT_ER);
                 rc = launch_tf_er<CT>(N, P.G, w.XC, idx_cur, w.xx, Bc, K, w.E, w.R, w.gterms, nact, map_cur, st);

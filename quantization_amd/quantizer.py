@@ -75,8 +75,8 @@ def _is_pow2(n: int) -> bool:
 
 def _scale_exp(scale: Tensor, speed: float) -> float:
     """exp(scale * speed) as the reference forms it on the host (fp32 multiply, fp32
-    exp; quantization.py:78, :278) -- evaluated on CPU so that the derived state is
-    the same on every machine regardless of the device's exp()."""
+    exp; quantization.py:78, :278) -- evaluated on the CPU as the reference evaluates it there.  (Not the same bits on every
+    machine: see Quantizer.pin_scale_factors.)"""
     return float((scale.detach().to("cpu", torch.float32) * speed).exp())
 
 
@@ -103,6 +103,7 @@ class Quantizer(nn.Module):
         # opt-in (not in the reference): vectors whose indexes a refinement pass leaves unchanged are
         # final (the pass is a deterministic map) and skip the remaining passes; same codes, less work
         self.skip_fixed_points = False
+        self._pinned_scales = None   # pin_scale_factors()
         self._prep = None       # (key, device buffer) of derived state for the kernels
         self._ws = None         # cached encode workspace (device uint8 tensor)
 
@@ -145,6 +146,22 @@ class Quantizer(nn.Module):
         self.id_str = bytes(self.id_buf.tolist()).decode("utf-8")   # quantization.py:57-59
         self._prep = None
         return ret
+
+    def pin_scale_factors(self, cscale_exp=None, lscale_exp=None) -> None:
+        """Use THESE fp32 values for exp(10 * centers_scale) and exp(10 * logits_scale) in inference (autograd off) instead of
+        forming them with the host's exp; call with no arguments to unpin.  Why: torch's fp32 exp is not the same function on
+        every CPU -- the same argument gave 0x40c6eb47 on a Xeon and 0x40c6eb46 on an EPYC (round 6) -- so the reference's own codes for
+        near-tie vectors depend on the machine it ran on, and so do this module's.  A caller that needs codes bit-identical to
+        another machine's (the test fixtures captured from the reference; an index built elsewhere) passes that machine's
+        factors.  Not used by the training flavour of the derived state (the scales are read on the device there)."""
+        if cscale_exp is None and lscale_exp is None:
+            self._pinned_scales = None
+        else:
+            assert cscale_exp is not None and lscale_exp is not None
+            # (the pin belongs to the scale parameters as they are NOW: once they change -- an optimizer step, load_state_dict --
+            # the factors are formed from the new values again)
+            self._pinned_scales = (float(cscale_exp), float(lscale_exp), float(self.centers_scale.detach()), float(self.logits_scale.detach()))
+        self._prep = None
 
     def invalidate_cache(self) -> None:
         """Drop the cached derived state.  Needed only after parameters were modified in a way torch does not
@@ -226,8 +243,12 @@ class Quantizer(nn.Module):
                 both = both.to("cpu")       # both scalars in one device->host copy; exp on the host
                 scales = None               # host-formed factors: no device copy belongs to this state
                 scale_flags = 0
-                cscale_exp = _scale_exp(both[0], self.scale_speed)
-                lscale_exp = _scale_exp(both[1], self.scale_speed)
+                pin = self._pinned_scales
+                if pin is not None and (float(both[0]), float(both[1])) == pin[2:]:
+                    cscale_exp, lscale_exp = pin[0], pin[1]
+                else:
+                    cscale_exp = _scale_exp(both[0], self.scale_speed)
+                    lscale_exp = _scale_exp(both[1], self.scale_speed)
                 rc = L.mcq_prepare(centers.data_ptr(), cscale_exp, None if decode_only else weight.data_ptr(),
                                    None if decode_only else bias.data_ptr(), N, K, D, blob.data_ptr(), st)
         _lib.check(rc, "mcq_prepare")

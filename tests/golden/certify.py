@@ -1,27 +1,29 @@
 """Certification of a row on which an implementation's codes differ from the reference's (SURVEY.md section 7 "hard parts": a
 mismatching row must be CERTIFIED as an fp32 near-tie by an fp64 recheck).
 
-What is known per fixture: the reference's indexes after every pass (`refpass`, captured by tests/golden/make_golden_certify.py) and,
-from the oracle, the implementation's indexes after every pass (the HIP kernels equal the oracle bit for bit, tested separately).
-So the FIRST pass in which the two part is known, and both start it from the same indexes.  certify_row replays that pass in fp64
-(fp64_search.replay_pass) twice -- once following the reference's result, once the implementation's -- and reports, node by node of
-the combine tree, whether the followed result's ancestor lay inside the fp64 shortlist and, where it did not, by how much
-(`rel`: the score gap to the shortlist's boundary, relative to the two competing scores).  A legitimate difference is one where every
-such bend is below NEAR: somewhere a candidate sat within fp32 noise of a shortlist's boundary (or of the winner), one side kept it, the
-other did not, and whatever follows -- up to a visibly different reconstruction error -- is the search continuing from there.
+What is known per fixture: the reference's indexes after every pass (`refpass`, captured by tests/golden/make_golden_certify.py), the
+fp32 scale factors it computed with (`scales_exp`) and, from the oracle, the implementation's indexes after every pass (the HIP kernels
+equal the oracle bit for bit, tested separately).  So the FIRST pass in which the two part is known, and both start it from the same
+indexes.  certify_row runs that pass in fp64 with the search's NEAR-TIES as choice points (fp64_search.explain_by_near_ties): a decision
+-- a sort-and-truncate's boundary, the final top-1 -- whose two competing scores lie within NEAR of each other, relatively, may go
+either way.  A legitimate difference is one where EACH side's result is what the fp64 search returns under some resolution of its
+near-ties; the certificate names those decisions (level and group of the combine tree) and their gaps.  Whatever follows a flipped
+near-tie -- other candidates in later shortlists, up to a visibly different reconstruction error -- is the search continuing from there,
+which is why the end results are compared by outcome only loosely (OUTCOME).
 Pass 0 (the arg max of the logits, :297-301) is certified by the logit gap."""
 import numpy as np
 
 from . import fp64_search as f64
 
 NEAR = 1e-6           # a bend below this, relative to the competing scores, is fp32 summation-order noise
-OUTCOME = 2e-2        # |SSE(impl) - SSE(ref)| / SSE(ref): what a legitimate boundary flip has been seen to cost or gain (<= 0.7 %)
+OUTCOME = 5e-2        # |SSE(impl) - SSE(ref)| / SSE(ref): what a flipped near-tie has been seen to cost or gain downstream (<= 1.5 %)
 
 
 def _oracle(fx):
     from oracle.oracle import OracleQuantizer
     s = fx["state"]
-    return OracleQuantizer(s["centers"], float(s["centers_scale"]), s["to_logits.weight"], s["to_logits.bias"], float(s["logits_scale"]))
+    return OracleQuantizer(s["centers"], float(s["centers_scale"]), s["to_logits.weight"], s["to_logits.bias"], float(s["logits_scale"]),
+                           scales_exp=getattr(s, "scales_exp", None))
 
 
 def oracle_passes(fx, row, npass):
@@ -54,33 +56,9 @@ def oracle_lists(fx, row, idx_prev):
     return lists, np.asarray(t["idx"]).astype(np.int64)
 
 
-def _lost_at(lists, T, N):
-    """first node (level, group), bottom-up, where tuple T's restriction is not in the kept list; None if it survives to the top"""
-    v, L = 0, 1
-    while True:
-        groups = N // L
-        for g in range(groups):
-            if (v, g) not in lists:
-                return None
-            if not (lists[(v, g)] == T[g * L:(g + 1) * L][None, :]).all(axis=1).any():
-                return (v, g)
-        if groups == 1:
-            return None
-        v, L = v + 1, L * 2
-
-
 def certify_row(fx, it, row, impl_code=None):
     """Returns a dict describing where and why row `row` differs at `it` passes; raises AssertionError if the difference is not a
-    certified near-tie.  impl_code: the implementation's indexes of that row (must be what the oracle gives).
-
-    In the first pass p where the two part (both start it from the same indexes), with F the fp64 result of that pass, each side
-    T in (reference R, oracle O) that is not F is explained by decisions within NEAR of a tie, all measured in fp64 relative to
-    the two competing scores:
-      * T's ancestor lay OUTSIDE an fp64 shortlist and was kept (replay_pass, slack > 0): the bend must be < NEAR;
-      * T lay inside every fp64 shortlist but is not the fp64 winner: then its side lost F on the way --
-        the oracle's own shortlists (its trace) say at which node: F's ancestor must be within NEAR of the worst candidate the
-        oracle kept there; for the reference, whose shortlists are not recorded, F's closest approach to a shortlist boundary
-        along the fp64 search must be < NEAR -- or T ties with F at the top-1 within NEAR."""
+    certified near-tie.  impl_code: the implementation's indexes of that row (must be what the oracle gives)."""
     assert "refpass" in fx, "fixture without the reference's per-pass indexes (tests/golden/make_golden_certify.py)"
     ref = fx["refpass"][:it + 1, row].astype(np.int64)                 # (it + 1, N)
     imp = oracle_passes(fx, row, it)
@@ -103,45 +81,17 @@ def certify_row(fx, it, row, impl_code=None):
     else:
         prev = ref[p - 1]
         assert np.array_equal(prev, imp[p - 1])
-        F = f64.refine_fp64(C, x[None].astype(np.float64), prev[None])[0][0].astype(np.int64)
-        findings = []                        # (gap, description)
+        findings = []
         for who, T in (("reference", ref[p]), ("oracle", imp[p])):
-            if np.array_equal(T, F):
-                continue
-            nodes = f64.replay_pass(C, x, prev, T)
-            bends = [nd for nd in nodes if nd["slack"] > 0 and nd["keep"] > 1]
-            for nd in bends:
-                findings.append((nd["rel"], "pass %d, level %d, group %d (prune to %d of %d): the %s kept a candidate of fp64 rank %d"
-                                 % (p, nd["level"], nd["group"], nd["keep"], nd["n_candidates"], who, nd["rank"])))
-            top = nodes[-1]
-            if top["rank"] > 0 and not bends:
-                # inside every fp64 shortlist, not the fp64 winner: a tie at the top-1, or this side lost F below
-                if top["rel"] < NEAR:
-                    findings.append((top["rel"], "pass %d, top-1: the %s's winner ties with the fp64 winner" % (p, who)))
-                elif who == "oracle":
-                    lists, o_idx = oracle_lists(fx, row, prev)
-                    assert np.array_equal(o_idx, T)
-                    node = _lost_at(lists, F, N)
-                    assert node is not None, (out, "the oracle kept the fp64 winner to the top and chose a clearly worse one")
-                    v, g = node
-                    fF = f64.tuple_score(C, x, prev, v, g, F[g << v:(g + 1) << v])
-                    worst_kept = max(f64.tuple_score(C, x, prev, v, g, t) for t in lists[(v, g)])
-                    rel = (worst_kept - fF) / (max(abs(worst_kept), abs(fF)) + 1e-300)
-                    # (rel > 0: the oracle kept a candidate that fp64 ranks below F's ancestor, by that much)
-                    findings.append((abs(rel), "pass %d, level %d, group %d (prune to %d): the oracle dropped the fp64 winner's ancestor for a "
-                                     "candidate %.2e worse" % (p, v, g, len(lists[(v, g)]), rel)))
-                    assert rel >= 0, (out, findings, "the oracle dropped a candidate that fp64 ranks inside its shortlist by a clear margin")
-                else:
-                    nodesF = f64.replay_pass(C, x, prev, F)
-                    # F's closest approach to a boundary: slack is f(F|g) - f(last kept); the first dropped one is not recorded,
-                    # so bound it by the gap of the pass's stored margin for this row (margin2: smallest boundary gap of the search)
-                    m2 = float(fx[f"margin2_it{it}"][row]) if f"margin2_it{it}" in fx else None
-                    findings.append((m2 if m2 is not None else 1.0,
-                                     "pass %d: the reference lost the fp64 winner at a shortlist boundary (closest boundary gap of the row)" % p))
-                    del nodesF
+            flips = f64.explain_by_near_ties(C, x, prev, T, NEAR)
+            assert flips is not None, (out, f"the {who}'s result of pass {p} is not an outcome of the fp64 search under any resolution "
+                                            f"of its near-ties (gaps < {NEAR:g})")
+            out["flips_" + who] = [(lv, g, float(gap)) for (lv, g), gap in flips]
+            for (lv, g), gap in flips:
+                findings.append((float(gap), "pass %d, level %d, group %d: the %s resolves this near-tie against the fp64 order" % (p, lv, g, who)))
         assert findings, (out, "both results are the fp64 result, yet they differ")
         gap, stage = max(findings)
-        out.update(stage=stage, gap=float(gap), who=stage, findings=findings)
+        out.update(stage=stage, gap=float(gap), findings=findings)
         assert gap < NEAR, out
     # outcome: the reconstruction errors of the two final codes
     sse_ref = float(fx[f"sse64_it{it}"][row]) if f"sse64_it{it}" in fx else float(f64.sse_fp64(fx["state"], x[None], ref[it][None])[0])

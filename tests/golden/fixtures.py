@@ -25,6 +25,13 @@ def trace_names():
     return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(HERE, "trace_*.npz")))
 
 
+class PinnedState(dict):
+    """a quantizer state (the state-dict entries) that also carries, as an ATTRIBUTE, the fp32 scale factors the reference's run
+    computed with (`scales_exp` of the fixture): the helpers that build a Quantizer / an OracleQuantizer / the fp64 search from a
+    state pin them, so the problem instance is the reference's on every host (torch's fp32 exp differs in the last bit between CPUs)"""
+    scales_exp = None
+
+
 def load(name):
     z = np.load(os.path.join(HERE, name + ".npz"))
     fx = {k: z[k] for k in z.files}
@@ -36,6 +43,9 @@ def load(name):
         assert gen.checksum(state["centers"]) == float(fx["centers_checksum"]), "regenerated state differs"
     x = gen.make_kind(str(fx["x_kind"]), int(fx["x_seed"]), B, D)
     assert gen.checksum(x) == float(fx["x_checksum"]), "regenerated input differs from the fixture's"
+    state = PinnedState(state)
+    if "scales_exp" in fx:
+        state.scales_exp = (float(fx["scales_exp"][0]), float(fx["scales_exp"][1]))
     fx.update(D=D, K=K, N=N, B=B, state=state, x=x)
     fx["iters"] = sorted(int(k[len("codes_it"):]) for k in fx if k.startswith("codes_it"))
     return fx

@@ -19,16 +19,28 @@ def k_cutoff(K, L):
     return min(kc, 128)
 
 
-def scaled_state(sd):
-    """(C (N,K,D) fp64 of the fp32 scaled centers, W fp64, bias fp64, logits scale fp32) as get_centers() / _logits() form them
-    (:77-79, :277-279): the scale factors are fp32 exp()s and the scaled centers fp32 products."""
-    try:        # torch's fp32 exp is what the reference computes with; numpy's may differ in the last bit
+def scale_factors(sd):
+    """(exp(10 centers_scale), exp(10 logits_scale)) as fp32: the factors pinned in the state (`scales_exp`, captured from the
+    reference's own torch on the machine that generated the fixture) when it carries them -- torch's fp32 exp differs in the last
+    bit between CPUs (measured: Xeon ...47, EPYC ...46 for the same argument), and one bit of the scale moves near-tie codes --
+    else torch's exp on this host, else numpy's."""
+    pinned = getattr(sd, "scales_exp", None)      # (fixtures.PinnedState)
+    if pinned is not None:
+        return np.float32(pinned[0]), np.float32(pinned[1])
+    try:
         import torch
         cs = np.float32((torch.tensor(float(sd["centers_scale"]), dtype=torch.float32) * 10.0).exp().item())
         ls = np.float32((torch.tensor(float(sd["logits_scale"]), dtype=torch.float32) * 10.0).exp().item())
     except ImportError:
         cs = np.exp(np.float32(sd["centers_scale"]) * np.float32(10.0)).astype(np.float32)
         ls = np.exp(np.float32(sd["logits_scale"]) * np.float32(10.0)).astype(np.float32)
+    return cs, ls
+
+
+def scaled_state(sd):
+    """(C (N,K,D) fp64 of the fp32 scaled centers, W fp64, bias fp64, logits scale fp32) as get_centers() / _logits() form them
+    (:77-79, :277-279): the scale factors are fp32 exp()s and the scaled centers fp32 products."""
+    cs, ls = scale_factors(sd)
     C = (cs * sd["centers"].astype(np.float32)).astype(np.float32).astype(np.float64)
     return C, sd["to_logits.weight"].astype(np.float64), sd["to_logits.bias"].astype(np.float64), ls
 
@@ -216,3 +228,108 @@ def tuple_score(C, x, idx_prev, level, group, tup):
     for j, n in enumerate(range(group * L, (group + 1) * L)):
         y += C[n, int(tup[j])] - old[n]
     return float(y @ y)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# one vector, one pass, with the search's NEAR-TIES as choice points: is a given result an outcome of the search under some
+# resolution of them?
+# ---------------------------------------------------------------------------------------------------------------------
+def _rel(a, b):
+    return abs(a - b) / (max(abs(a), abs(b)) + 1e-300)
+
+
+def _truncate_choice(level, group, keep, tup, delta, f, near, choices, ties):
+    """keep `keep` of the candidates: the fp64 order, except that candidates within `near` (relative) of the boundary -- of the
+    best one when keep == 1 -- may be exchanged: choices[(level, group)] picks which (0 = the fp64 order)."""
+    order = np.argsort(f, kind="stable")
+    n = len(f)
+    if n <= keep:
+        return tup[order], delta[order], f[order]
+    # the cluster of ranks round the boundary keep - 1 | keep whose members are within `near` of a boundary score
+    lo, hi = keep - 1, keep
+    if _rel(f[order[lo]], f[order[hi]]) >= near:
+        return tup[order[:keep]], delta[order[:keep]], f[order[:keep]]
+    while lo > 0 and _rel(f[order[lo - 1]], f[order[keep]]) < near and keep - lo < 3:
+        lo -= 1
+    while hi + 1 < n and _rel(f[order[hi + 1]], f[order[keep - 1]]) < near and hi - keep < 2:
+        hi += 1
+    import itertools
+    members = list(range(lo, hi + 1))
+    need = keep - lo
+    combos = list(itertools.combinations(members, need))      # combos[0] = the fp64 order's own choice
+    pick = choices.get((level, group), 0)
+    gap = _rel(f[order[keep - 1]], f[order[keep]])
+    ties.append(((level, group), len(combos), gap))
+    ranks = list(range(lo)) + list(combos[min(pick, len(combos) - 1)])
+    sel = order[np.asarray(ranks, dtype=np.int64)]
+    return tup[sel], delta[sel], f[sel]
+
+
+def pass_with_choices(C, x, idx_prev, choices, near):
+    """the fp64 pass of ONE vector from idx_prev with the near-ties at the nodes in `choices` resolved as given;
+    returns (result (N,), [(node, alternatives, gap), ...] of every near-tie met on the way)"""
+    N, K, D = C.shape
+    x = x.astype(np.float64)
+    old = C[np.arange(N), idx_prev]
+    xerr = old.sum(axis=0) - x
+    E = float(xerr @ xerr)
+    ties = []
+    L = 1
+    keep = 1 if N == 1 else k_cutoff(K, L)
+    lists = []
+    for n in range(N):
+        delta = C[n] - old[n][None, :]
+        y = xerr[None, :] + delta
+        lists.append(_truncate_choice(0, n, keep, np.arange(K)[:, None], delta, (y * y).sum(-1), near, choices, ties))
+    Ng, v = N, 0
+    while Ng > 1:
+        v += 1
+        L *= 2
+        newN = Ng // 2
+        keep = 1 if newN == 1 else k_cutoff(K, L)
+        nxt = []
+        for g in range(newN):
+            te, de, fe = lists[2 * g]
+            to, do, fo = lists[2 * g + 1]
+            tup = np.concatenate([np.repeat(te, len(to), axis=0), np.tile(to, (len(te), 1))], axis=1)
+            delta = (de[:, None, :] + do[None, :, :]).reshape(-1, D)
+            f = ((fe[:, None] + fo[None, :]) - E + 2.0 * (de @ do.T)).reshape(-1)
+            nxt.append(_truncate_choice(v, g, keep, tup, delta, f, near, choices, ties))
+        lists = nxt
+        Ng = newN
+    return lists[0][0][0].astype(np.int64), ties
+
+
+def explain_by_near_ties(C, x, idx_prev, target, near, budget=400, max_flips=4):
+    """Is `target` what the fp64 pass from idx_prev gives under SOME resolution of its near-ties (decisions whose competing scores are
+    within `near`, relative)?  Breadth-first over sets of flipped near-ties, smallest sets first.  Returns the list of flips
+    [((level, group), gap), ...] (empty: target IS the fp64 result) or None."""
+    target = np.asarray(target).astype(np.int64)
+    frontier = [dict()]
+    seen = set()
+    runs = 0
+    for depth in range(max_flips + 1):
+        nxt = []
+        for ch in frontier:
+            key = tuple(sorted(ch.items()))
+            if key in seen:
+                continue
+            seen.add(key)
+            res, ties = pass_with_choices(C, x, idx_prev, ch, near)
+            runs += 1
+            gaps = dict((node, gap) for node, _, gap in ties)
+            if np.array_equal(res, target):
+                return [(node, gaps.get(node, 0.0)) for node in sorted(ch)]
+            if runs >= budget:
+                return None
+            for node, alts, _ in ties:
+                if node in ch:
+                    continue
+                for a in range(1, alts):
+                    c2 = dict(ch)
+                    c2[node] = a
+                    nxt.append(c2)
+        frontier = nxt
+        if not frontier:
+            break
+    return None

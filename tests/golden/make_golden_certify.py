@@ -9,6 +9,8 @@ New fields per fixture (P = the largest stored pass count):
   margin2_it{it}     (B,) float32   smallest decision gap along the fp64 search RELATIVE TO THE TWO COMPETING SCORES (fp64_search._gap2);
                                     margin_it{it}, normalised by |x|^2 + E, calls every row of an offset fixture a near-tie
   sse64_it{it}       (B,) float64   fp64 |sum_n C[n, code_n] - x|^2 of the reference's code: the outcome of its search
+  scales_exp         (2,) float32   exp(10 centers_scale), exp(10 logits_scale) as the reference formed them on the generating machine
+                                    (torch's fp32 exp differs in the last bit between CPUs: tests pin these, fixtures.PinnedState)
 Checks while it runs: refpass[it] equals the stored codes_it{it}; the fp64 margins of the old definition equal the stored ones."""
 import os
 import sys
@@ -40,6 +42,10 @@ def patch(name):
         raw[f"sse64_it{it}"] = f64.sse_fp64(sd, x, refpass[it])
         print(f"[{name}] iters={it}: near-tie rows (< 2e-6) old normalisation {int((m_old < 2e-6).sum())}, new {int((m2 < 2e-6).sum())} of {len(x)};"
               f" fp64 codes differ from the reference's on {int((c64 != refpass[it]).any(axis=1).sum())}")
+    # the fp32 scale factors the reference computed with HERE (its get_centers() / _logits(): torch's fp32 exp on this machine)
+    import torch
+    with torch.no_grad():
+        raw["scales_exp"] = np.asarray([float((q.centers_scale * q.scale_speed).exp()), float((q.logits_scale * q.scale_speed).exp())], np.float32)
     raw["refpass"] = refpass
     np.savez_compressed(path, **raw)
 

@@ -16,7 +16,7 @@ NAMES = ["stress_mean10_d512_b8_p2", "stress_outlier300_d64_b4_p2", "stress_mean
 def test_mismatching_rows_are_certified_near_ties(name, capsys):
     fx = fixtures.load(name)
     s = fx["state"]
-    o = OracleQuantizer(s["centers"], float(s["centers_scale"]), s["to_logits.weight"], s["to_logits.bias"], float(s["logits_scale"]))
+    o = OracleQuantizer(s["centers"], float(s["centers_scale"]), s["to_logits.weight"], s["to_logits.bias"], float(s["logits_scale"]), scales_exp=getattr(s, "scales_exp", None))
     found = 0
     for it in fx["iters"]:
         codes = np.asarray(o.compute_indexes(fx["x"], it)).reshape(fx[f"codes_it{it}"].shape)

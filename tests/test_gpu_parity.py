@@ -28,12 +28,14 @@ def load_quantizer(state, D, K, N, device="cuda:0"):
     for k, v in state.items():
         sd[k] = torch.from_numpy(np.asarray(v))
     q.load_state_dict(sd)
+    if getattr(state, "scales_exp", None) is not None:      # a fixture's state: the scale factors of the reference's run (fixtures.PinnedState)
+        q.pin_scale_factors(*state.scales_exp)
     return q.to(device)
 
 
 def oracle_of(state):
     return OracleQuantizer(state["centers"], float(state["centers_scale"]), state["to_logits.weight"],
-                           state["to_logits.bias"], float(state["logits_scale"]))
+                           state["to_logits.bias"], float(state["logits_scale"]), scales_exp=getattr(state, "scales_exp", None))
 
 
 @pytest.mark.parametrize("name", ALL)

@@ -12,7 +12,7 @@ SMALL = [n for n in ALL if not n.startswith("config_b") and not n.startswith("co
 def _oracle(fx):
     s = fx["state"]
     return OracleQuantizer(s["centers"], float(s["centers_scale"]), s["to_logits.weight"], s["to_logits.bias"],
-                           float(s["logits_scale"]))
+                           float(s["logits_scale"]), scales_exp=getattr(s, "scales_exp", None))
 
 
 def test_fixture_inventory():
