@@ -53,7 +53,11 @@ extern "C" {
 #define MCQ_EUNSUPPORTED (-2) /* outside the supported (K, N) domain             */
 #define MCQ_EWORKSPACE (-3) /* workspace smaller than mcq_encode_workspace_bytes */
 
-#define MCQ_ABI_VERSION 6   /* 6: the products of the path are formed from CENTERED rows and frames (`prepared` also holds the codebooks' own
+#define MCQ_ABI_VERSION 7   /* 7: no signature changed.  The shortlists of a refinement pass are SETS listed in ascending position (they were
+                               listed by (value, position) until 6: oracle/mcq_oracle.c::select_smallest) -- results differ from ABI 6 only
+                               where two later scores tie exactly; mcq_test_select hands the list over in that order and takes the layout
+                               in the sign of per_lane; 16 codebooks of 16 entries run all passes of a call in one launch (k_tf_pass16);
+                               6: the products of the path are formed from CENTERED rows and frames (`prepared` also holds the codebooks' own
                                means and the classifier rows' products with the data mean, Q and the Gram matrix are those of
                                C[n][k] - mu_n, the frame planes of the workspace those of x - mean: sizes changed, signatures did
                                not), mcq_profile_encode times the shipped launch sequence and
@@ -285,7 +289,9 @@ int mcq_logits(const float *x, long B, const void *prepared, float lscale_exp, i
                float *out, void *workspace, size_t workspace_bytes, void *stream);
 
 /* The wave-level selection of the search on its own: `cases` independent problems of 64 * per_lane scores each
- * (per_lane 1, 4 or 16; position = index); out_v / out_p [cases][64] receive the cnt smallest in (value, position) order.
+ * (per_lane 1, 4 or 16: key i of lane l at position per_lane * l + i; -4 / -16: the slot-major layout, position 64 * i + l; -1004:
+ * four keys per lane handled as positions in no particular order); out_v / out_p [cases][64] receive the cnt smallest by
+ * (value, position) LISTED IN ASCENDING POSITION (a list that runs out of candidates is padded with (INF, M - 1)).
  * Test hook for the selection's paths (ties, clustered survivors).                                                       */
 int mcq_test_select(const float *scores, int cases, int per_lane, int cnt, float *out_v, int *out_p, void *stream);
 

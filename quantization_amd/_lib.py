@@ -125,7 +125,7 @@ def lib():
     L.mcq_profile_encode.argtypes = [vp, i64, vp, f32, i32, i32, i32, i32, vp, sz, vp, ctypes.POINTER(f32), ctypes.POINTER(i32), i32]
     L.mcq_profile_category_name.restype = ctypes.c_char_p
     L.mcq_profile_category_name.argtypes = [i32]
-    assert L.mcq_abi_version() == 6
+    assert L.mcq_abi_version() == 7
     _lib = L
     return L
 

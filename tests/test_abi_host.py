@@ -24,7 +24,7 @@ def test_header_symbols_are_exported():
     assert declared == set(_lib_mod.SYMBOLS), declared ^ set(_lib_mod.SYMBOLS)
     for s in declared:
         assert hasattr(L, s), s
-    assert L.mcq_abi_version() == 6
+    assert L.mcq_abi_version() == 7
 
 
 def test_size_queries():
