@@ -428,6 +428,17 @@ def trainer_leg(dev, D, N, batch, p_iters, process_group=None, data_parallel=Fal
     return ms, nparam
 
 
+_REAL_STDOUT = None
+
+
+def emit(obj):
+    """the JSON line, on the real stdout (see main)"""
+    data = (json.dumps(obj) + "\n").encode()
+    fd = _REAL_STDOUT if _REAL_STDOUT is not None else 1
+    while data:
+        data = data[os.write(fd, data):]
+
+
 def self_launch(n):
     """Re-run this command under torch.distributed.run with n ranks on 127.0.0.1 (a free port); returns its exit code."""
     import socket
@@ -440,7 +451,7 @@ def self_launch(n):
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.call(cmd, env=env)
+    return subprocess.call(cmd, env=env, stdout=(_REAL_STDOUT if _REAL_STDOUT is not None else None))      # (the ranks' line goes to OUR real stdout)
 
 
 def main():
@@ -471,6 +482,15 @@ def main():
                     help="vectors per GPU of the config-C shard leg under --gpus N > 1 (BASELINE config C: 8M over 8 GPUs)")
     args = ap.parse_args()
 
+    # The ONE line of this command goes to the process's real stdout; everything else that writes to file descriptor 1 -- RCCL prints
+    # a version banner there, from C, when its first communicator comes up, and it lands AFTER the line when the buffers are flushed at
+    # exit -- is sent to stderr from here on.
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, torch.distributed.run
         # on the loopback address), pass every argument through and leave with the launcher's exit code
@@ -486,8 +506,8 @@ def main():
         seen = [None] * world
         dist.all_gather_object(seen, {"rank": rank, "local_rank": local_rank, "pid": os.getpid()})
         if rank == 0:
-            print(json.dumps({"rendezvous": world, "gpus": args.gpus, "backend": dist.get_backend(),
-                              "ranks": sorted(r["rank"] for r in seen), "pids": len({r["pid"] for r in seen})}), flush=True)
+            emit({"rendezvous": world, "gpus": args.gpus, "backend": dist.get_backend(),
+                  "ranks": sorted(r["rank"] for r in seen), "pids": len({r["pid"] for r in seen})})
         dist.barrier()
         dist.destroy_process_group()
         assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
@@ -723,7 +743,7 @@ def main():
     if shard is not None:
         out["configs"] = {"C_shard_dim512_bytes8_1M": shard}
     if args.no_secondary:
-        print(json.dumps(out), flush=True)
+        emit(out)
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
@@ -882,7 +902,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(state, D)
         except Exception as e:      # noqa: BLE001
             out["cpu_baseline"] = {"value": None, "unit": "vectors/s", "cores": 0, "kind": "port", "sample": "failed", "error": f"{type(e).__name__}: {e}"[:300]}
-    print(json.dumps(out), flush=True)
+    emit(out)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -2,10 +2,10 @@
 # copy the summaries of one tools/final_profiles.sh run (gpurun_out/<dir>) into profiles/ as the round's set
 # usage: tools/refresh_profiles.sh gpurun_out/final_r03 [r03]
 set -eu
-S=$1; R=${2:-r05}; P=$(dirname $0)/../profiles
-tail -1 $S/bench.json > $P/${R}_bench.json
-tail -1 $S/bench_under_rocprof.json > $P/${R}_bench_under_rocprof.json
-tail -1 $S/bench_dp2.json > $P/${R}_bench_dp2_dryrun.json
+S=$1; R=${2:-r06}; P=$(dirname $0)/../profiles
+grep "^{" $S/bench.json | tail -1 > $P/${R}_bench.json
+grep "^{" $S/bench_under_rocprof.json | tail -1 > $P/${R}_bench_under_rocprof.json
+grep "^{" $S/bench_dp2.json | tail -1 > $P/${R}_bench_dp2_dryrun.json
 cp $(ls $S/kt/*/*kernel_stats.csv | head -1) $P/${R}_kernel_stats.csv
 cp $(ls $S/tr1/*/*kernel_stats.csv | head -1) $P/${R}_trainer_phase1_kernel_stats.csv
 cp $(ls $S/tr2/*/*kernel_stats.csv | head -1) $P/${R}_trainer_phase2_kernel_stats.csv
