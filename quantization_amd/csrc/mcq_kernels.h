@@ -124,7 +124,7 @@ __device__ __forceinline__ f32x4 load_h4(const void *p) {
 #ifndef MCQ_SEL_WIN
 #define MCQ_SEL_WIN 4      // window of the bound on the lane minima (wave_kth_u32): any minimum with cnt - 1 .. cnt + 3 smaller ones
 #endif
-constexpr int kSelectLdsU64 = 64;   // per-wave LDS scratch of wave_select_set, in u64: one (score, position) slot per lane
+constexpr int kSelectLdsU64 = 128;  // per-wave LDS scratch of wave_select_set, in u64: 128 scores + 128 positions (one survivor per lane, two when they cluster)
 
 __device__ __forceinline__ uint32_t ord32(float v) {
     const uint32_t b = __float_as_uint(v);
@@ -203,6 +203,55 @@ __device__ __forceinline__ uint32_t wave_kth_u32(uint32_t k, u64 cm, int target,
     return kp;
 }
 
+// The same over TWO keys per lane (k0 of lanes cm0, k1 of lanes cm1), exact: the key kp with at most `target` keys below it and more than
+// `target` not above it; the four masks of the last round are returned.
+__device__ __forceinline__ uint32_t wave_kth_u32x2(uint32_t k0, uint32_t k1, u64 cm0, u64 cm1, int target, u64 &lt0, u64 &lt1, u64 &le0,
+                                                   u64 &le1) {
+    uint32_t kp;
+    int t0, t1;
+    u64 c0, c1;
+    asm("s_mov_b64 %[c0], %[i0]\n\t"
+        "s_mov_b64 %[c1], %[i1]\n\t"
+        "1:\n\t"
+        "s_cmp_lg_u64 %[c0], 0\n\t"
+        "s_cbranch_scc0 4f\n\t"
+        "s_ff1_i32_b64 %[t0], %[c0]\n\t"
+        "v_readlane_b32 %[kp], %[k0], %[t0]\n\t"
+        "s_branch 5f\n\t"
+        "4:\n\t"
+        "s_ff1_i32_b64 %[t0], %[c1]\n\t"
+        "v_readlane_b32 %[kp], %[k1], %[t0]\n\t"
+        "5:\n\t"
+        "s_nop 1\n\t"
+        "v_cmp_gt_u32_e64 %[lt0], %[kp], %[k0]\n\t"
+        "v_cmp_gt_u32_e64 %[lt1], %[kp], %[k1]\n\t"
+        "s_bcnt1_i32_b64 %[t0], %[lt0]\n\t"
+        "s_bcnt1_i32_b64 %[t1], %[lt1]\n\t"
+        "s_add_i32 %[t0], %[t0], %[t1]\n\t"
+        "s_cmp_gt_u32 %[t0], %[tg]\n\t"
+        "s_cbranch_scc1 2f\n\t"
+        "v_cmp_ge_u32_e64 %[le0], %[kp], %[k0]\n\t"
+        "v_cmp_ge_u32_e64 %[le1], %[kp], %[k1]\n\t"
+        "s_bcnt1_i32_b64 %[t0], %[le0]\n\t"
+        "s_bcnt1_i32_b64 %[t1], %[le1]\n\t"
+        "s_add_i32 %[t0], %[t0], %[t1]\n\t"
+        "s_cmp_gt_u32 %[t0], %[tg]\n\t"
+        "s_cbranch_scc1 3f\n\t"
+        "s_andn2_b64 %[c0], %[c0], %[le0]\n\t"
+        "s_andn2_b64 %[c1], %[c1], %[le1]\n\t"
+        "s_branch 1b\n\t"
+        "2:\n\t"
+        "s_and_b64 %[c0], %[c0], %[lt0]\n\t"
+        "s_and_b64 %[c1], %[c1], %[lt1]\n\t"
+        "s_branch 1b\n\t"
+        "3:"
+        : [kp] "=&s"(kp), [lt0] "=&s"(lt0), [lt1] "=&s"(lt1), [le0] "=&s"(le0), [le1] "=&s"(le1), [t0] "=&s"(t0), [t1] "=&s"(t1),
+          [c0] "=&s"(c0), [c1] "=&s"(c1)
+        : [k0] "v"(k0), [k1] "v"(k1), [tg] "s"(target), [i0] "s"(cm0), [i1] "s"(cm1)
+        : "scc");
+    return kp;
+}
+
 // d + bit `lane` of the wave-uniform mask m, as ONE instruction (add with carry-in; the compiler's own form of d + (s ? 1 : 0) is a
 // select and an add)
 __device__ __forceinline__ int add_lane_bit(int d, u64 m) {
@@ -270,7 +319,7 @@ __device__ __forceinline__ int wave_select_set(const float (&v)[VPL], const int 
             c += __popcll(m[i]);
         }
         if (c >= cnt && c <= 64) {
-            // score and position of survivor number d (in position order) go to lo[d] and lo[64 + d]: one ds_write2_b32 from
+            // score and position of survivor number d (in position order) go to lo[d] and lo[128 + d]: one ds_write2_b32 from
             // the registers they are in
             uint32_t *lo = reinterpret_cast<uint32_t *>(lds);
             if constexpr (LAYOUT == kLaneMajor) {
@@ -279,7 +328,7 @@ __device__ __forceinline__ int wave_select_set(const float (&v)[VPL], const int 
                 for (int i = 0; i < VPL; ++i) d = mbcnt64(m[i], d);        // survivors in the lanes below this one
 #pragma unroll
                 for (int i = 0; i < VPL; ++i) {
-                    if (v[i] <= T0v) { lo[d] = __float_as_uint(v[i]); lo[64 + d] = (uint32_t)p[i]; }
+                    if (v[i] <= T0v) { lo[d] = __float_as_uint(v[i]); lo[128 + d] = (uint32_t)p[i]; }
                     if (i + 1 < VPL) d = add_lane_bit(d, m[i]);
                 }
             } else {
@@ -287,12 +336,12 @@ __device__ __forceinline__ int wave_select_set(const float (&v)[VPL], const int 
 #pragma unroll
                 for (int i = 0; i < VPL; ++i) {
                     const int d = mbcnt64(m[i], base);
-                    if (v[i] <= T0v) { lo[d] = __float_as_uint(v[i]); lo[64 + d] = (uint32_t)p[i]; }
+                    if (v[i] <= T0v) { lo[d] = __float_as_uint(v[i]); lo[128 + d] = (uint32_t)p[i]; }
                     base += __popcll(m[i]);
                 }
             }
             wave_lds_fence();
-            const uint32_t ev = lo[lane], ep = lo[64 + lane];              // (lanes >= c read what an earlier selection left: unused)
+            const uint32_t ev = lo[lane], ep = lo[128 + lane];              // (lanes >= c read what an earlier selection left: unused)
             wave_lds_fence();                                              // (read before a later selection writes here)
             out_v = __uint_as_float(ev);
             out_p = (int)ep;
@@ -301,6 +350,59 @@ __device__ __forceinline__ int wave_select_set(const float (&v)[VPL], const int 
             has = in;
             if (c != cnt) selm = wave_select_mask(in ? ord32(out_v) : 0xffffffffu, selm, cnt, has);
             dst = mbcnt64(selm);
+            return cnt;
+        }
+        if (c > 64 && c <= 128) {
+            // The survivors cluster (a lane's keys share a table row: up to all of them lie below the bound): TWO per lane.  Survivor d,
+            // in position order, goes to slot d / 64 of lane d % 64; an exact quickselect over both slots; the cnt selected are then
+            // brought to one per lane, in the same order, through the same scratch.
+            uint32_t *lo = reinterpret_cast<uint32_t *>(lds);
+            if constexpr (LAYOUT == kLaneMajor) {
+                int d = 0;
+#pragma unroll
+                for (int i = 0; i < VPL; ++i) d = mbcnt64(m[i], d);
+#pragma unroll
+                for (int i = 0; i < VPL; ++i) {
+                    if (v[i] <= T0v) { lo[d] = __float_as_uint(v[i]); lo[128 + d] = (uint32_t)p[i]; }
+                    if (i + 1 < VPL) d = add_lane_bit(d, m[i]);
+                }
+            } else {
+                int base = 0;
+#pragma unroll
+                for (int i = 0; i < VPL; ++i) {
+                    const int d = mbcnt64(m[i], base);
+                    if (v[i] <= T0v) { lo[d] = __float_as_uint(v[i]); lo[128 + d] = (uint32_t)p[i]; }
+                    base += __popcll(m[i]);
+                }
+            }
+            wave_lds_fence();
+            const uint32_t v0 = lo[lane], v1 = lo[64 + lane], p0 = lo[128 + lane], p1 = lo[192 + lane];
+            wave_lds_fence();
+            const bool in1 = lane + 64 < c;
+            const u64 cm1 = (c == 128) ? ~0ull : ((1ull << (c - 64)) - 1ull);
+            const uint32_t k0 = ord32(__uint_as_float(v0)), k1 = in1 ? ord32(__uint_as_float(v1)) : 0xffffffffu;
+            u64 lt0, lt1, le0, le1;
+            const uint32_t kp = wave_kth_u32x2(k0, k1, ~0ull, cm1, cnt - 1, lt0, lt1, le0, le1);
+            bool h0 = k0 <= kp, h1 = k1 <= kp;
+            u64 s0 = le0, s1 = le1;
+            if (__popcll(le0) + __popcll(le1) != cnt) {      // equal scores across the boundary: the lowest positions fill the list
+                const u64 eq0 = le0 & ~lt0, eq1 = le1 & ~lt1;
+                const int need = cnt - __popcll(lt0) - __popcll(lt1);
+                h0 = (k0 < kp) | ((k0 == kp) & (mbcnt64(eq0) < need));
+                h1 = (k1 < kp) | ((k1 == kp) & (mbcnt64(eq1, __popcll(eq0)) < need));
+                s0 = __ballot(h0);
+                s1 = __ballot(h1);
+            }
+            const int d0 = mbcnt64(s0), d1 = mbcnt64(s1, __popcll(s0));
+            if (h0) { lo[d0] = v0; lo[128 + d0] = p0; }
+            if (h1) { lo[d1] = v1; lo[128 + d1] = p1; }
+            wave_lds_fence();
+            const uint32_t ev = lo[lane], ep = lo[128 + lane];
+            wave_lds_fence();
+            out_v = __uint_as_float(ev);
+            out_p = (int)ep;
+            has = lane < cnt;
+            dst = lane;
             return cnt;
         }
     }
@@ -349,7 +451,7 @@ __device__ __forceinline__ int wave_select_set(const float (&v)[VPL], const int 
             const bool s = key[i] <= T;
             const u64 mi = __ballot(s);
             d = mbcnt64(mi, nsel);
-            if (s && d < 64) { lo[d] = __float_as_uint(v[i]); lo[64 + d] = (uint32_t)p[i]; }
+            if (s && d < 64) { lo[d] = __float_as_uint(v[i]); lo[128 + d] = (uint32_t)p[i]; }
             nsel += __popcll(mi);
         }
     } else {
@@ -362,13 +464,13 @@ __device__ __forceinline__ int wave_select_set(const float (&v)[VPL], const int 
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
             const bool s = key[i] <= T;
-            if (s && d < 64) { lo[d] = __float_as_uint(v[i]); lo[64 + d] = (uint32_t)p[i]; }
+            if (s && d < 64) { lo[d] = __float_as_uint(v[i]); lo[128 + d] = (uint32_t)p[i]; }
             d += s ? 1 : 0;
         }
     }
     wave_lds_fence();
     has = lane < nsel;
-    const uint32_t ev = lo[lane], ep = lo[64 + lane];
+    const uint32_t ev = lo[lane], ep = lo[128 + lane];
     wave_lds_fence();
     out_v = __uint_as_float(ev);
     out_p = (int)ep;

@@ -5,7 +5,7 @@
 // G is 256 x 256, symmetric bit for bit, and a pass never reads a same-codebook entry off the diagonal, so the 120 blocks
 // (n, m), n < m, of 16 x 16 floats -- 122,880 bytes -- plus the diagonal (E / R) hold everything a pass reads.  One persistent
 // workgroup of eight waves per CU fills them by LDS-DMA; each WAVE then carries one vector at a time through ALL passes of the
-// call -- E / R, stage 0, the four combine levels, the winner's walk -- with every Gram read a ds_read, the candidate lists in 3.5 KB
+// call -- E / R, stage 0, the four combine levels, the winner's walk -- with every Gram read a ds_read, the candidate lists in 4 KB
 // of wave-private LDS, the indexes in registers between passes: one launch per call instead of five per pass, no list traffic
 // through global memory, no dependent L2 round trips (the separate kernels' waves live 3.6 us at 4,096 vectors, nearly all of it
 // waiting for L2-hit gathers and for the lists the launch before wrote).
@@ -45,10 +45,10 @@ constexpr int kP16S2 = 1280;         // f32 [4][16]
 constexpr int kP16S3 = 1536;         // f32 [2][16]
 constexpr int kP16T1 = 1664;         // f32 [8][9]      one level-1 table at a time (rows of 9: odd stride)
 constexpr int kP16T2 = 1952;         // f32 [16][17]    one level-2 table at a time
-constexpr int kP16Sel = 3040;        // u64 [64]        selection scratch
-constexpr int kP16Scratch = 3584;
-constexpr int kP16LdsBytes = kP16GramFloats * 4 + kP16Waves * kP16Scratch;      // 153,600
-static_assert(kP16Sel + 512 <= kP16Scratch && kP16T2 + 16 * 17 * 4 <= kP16Sel && kP16T1 + 8 * 9 * 4 <= kP16T2, "");
+constexpr int kP16Sel = 3040;        // u64 [128]       selection scratch
+constexpr int kP16Scratch = 4096;
+constexpr int kP16LdsBytes = kP16GramFloats * 4 + kP16Waves * kP16Scratch;      // 157,696
+static_assert(kP16Sel + kSelectLdsU64 * 8 <= kP16Scratch && kP16T2 + 16 * 17 * 4 <= kP16Sel && kP16T1 + 8 * 9 * 4 <= kP16T2, "");
 
 __device__ __forceinline__ int shfl_i(int v, int src) { return __builtin_amdgcn_ds_bpermute(src << 2, v); }
 
