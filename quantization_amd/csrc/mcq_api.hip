@@ -590,20 +590,26 @@ int run_encode_t(const float *x, long B, const void *prepared, float lscale, int
         }
         bool wrote_direct = false;
         if constexpr (sizeof(CT) == 1) {
-            // 16 codebooks of 16 entries (the trainer's first phase at 8 bytes per frame): ALL passes of the call in one launch of
+            // 16 or 8 codebooks of 16 entries (the trainer's first phase at 8 / 4 bytes per frame): ALL passes of the call in one launch of
             // persistent workgroups that hold the Gram matrix in LDS (mcq_pass16_kernels.h); not under the profiler, whose
             // categories are the separate launches
-            if (K == 16 && N == 16 && iters > 0 && !skip && prof == nullptr && pass16_enabled()) {
-                static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tf_pass16),
-                                                             hipFuncAttributeMaxDynamicSharedMemorySize, kP16LdsBytes);
-                if (attr != hipSuccess) return (int)attr;
+            if (K == 16 && (N == 16 || N == 8) && iters > 0 && !skip && prof == nullptr && pass16_enabled()) {
+                static hipError_t attr16 = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tf_pass16<16>),
+                                                               hipFuncAttributeMaxDynamicSharedMemorySize, p16_lds_bytes<16>());
+                static hipError_t attr8 = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tf_pass16<8>),
+                                                              hipFuncAttributeMaxDynamicSharedMemorySize, p16_lds_bytes<8>());
+                if (attr16 != hipSuccess) return (int)attr16;
+                if (attr8 != hipSuccess) return (int)attr8;
                 Pass16Args a;
                 a.G = P.G; a.XC = w.XC; a.xx = w.xx; a.Q = P.Q; a.idx = w.idx; a.B = Bc; a.iters = iters;
                 const bool direct_out = pack == 1;
                 a.out_i64 = (direct_out && out_i64) ? out_i64 + lo * N : nullptr;
                 a.out_u8 = direct_out ? (out_u8 ? out_u8 + lo * N : (codes_also ? codes_also + lo * N : nullptr)) : nullptr;
                 const long wgs = (Bc + kP16Waves - 1) / kP16Waves;
-                hipLaunchKernelGGL(k_tf_pass16, dim3((unsigned)(wgs < 256 ? wgs : 256)), dim3(64 * kP16Waves), kP16LdsBytes, st, a);
+                if (N == 16)   // one workgroup per CU (157,696 B of LDS), two with eight codebooks (62,464 B)
+                    hipLaunchKernelGGL(k_tf_pass16<16>, dim3((unsigned)(wgs < 256 ? wgs : 256)), dim3(64 * kP16Waves), p16_lds_bytes<16>(), st, a);
+                else
+                    hipLaunchKernelGGL(k_tf_pass16<8>, dim3((unsigned)(wgs < 512 ? wgs : 512)), dim3(64 * kP16Waves), p16_lds_bytes<8>(), st, a);
                 MCQ_LAUNCH_CHECK();
                 if (direct_out) continue;
                 iters_left = 0;

@@ -1,5 +1,6 @@
-// mcq_pass16_kernels.h -- the refinement passes of 16 codebooks of 16 entries (QuantizerTrainer's first phase at 8 bytes per frame,
-// /root/reference/quantization/quantization.py:308-547 at K = 16, N = 16) with the GRAM MATRIX RESIDENT IN LDS.
+// mcq_pass16_kernels.h -- the refinement passes of 16 (or 8) codebooks of 16 entries (QuantizerTrainer's first phase at 8 (4) bytes per
+// frame, /root/reference/quantization/quantization.py:308-547 at K = 16) with the GRAM MATRIX RESIDENT IN LDS.  (Described for N = 16; with
+// 8 codebooks there are 28 blocks, two workgroups per CU and one combine level less.)
 //
 // This is the one shape where "codebooks staged once in LDS" (BASELINE.json north_star) is literally possible for the table form:
 // G is 256 x 256, symmetric bit for bit, and a pass never reads a same-codebook entry off the diagonal, so the 120 blocks
@@ -32,8 +33,8 @@ struct Pass16Args {
 };
 
 constexpr int kP16Waves = 8;
-constexpr int kP16Blocks = 120;                                    // codebook pairs n < m
-constexpr int kP16GramFloats = kP16Blocks * 256 + 256 + 256;       // blocks, diagonal, Q
+template <int N> constexpr int p16_blocks() { return N * (N - 1) / 2; }                           // codebook pairs n < m
+template <int N> constexpr int p16_gram_floats() { return p16_blocks<N>() * 256 + 2 * N * 16; }   // blocks, diagonal, Q
 // wave-private scratch (byte offsets)
 constexpr int kP16Ent0 = 0;          // u8  [16][8]     level-0 lists: entries
 constexpr int kP16Pos1 = 128;        // u8  [8][8][2]   level-1 lists: positions in the halves' lists
@@ -47,19 +48,21 @@ constexpr int kP16T1 = 1664;         // f32 [8][9]      one level-1 table at a t
 constexpr int kP16T2 = 1952;         // f32 [16][17]    one level-2 table at a time
 constexpr int kP16Sel = 3040;        // u64 [128]       selection scratch
 constexpr int kP16Scratch = 4096;
-constexpr int kP16LdsBytes = kP16GramFloats * 4 + kP16Waves * kP16Scratch;      // 157,696
+template <int N> constexpr int p16_lds_bytes() { return p16_gram_floats<N>() * 4 + kP16Waves * kP16Scratch; }      // 157,696 (N = 16), 62,464 (N = 8)
 static_assert(kP16Sel + kSelectLdsU64 * 8 <= kP16Scratch && kP16T2 + 16 * 17 * 4 <= kP16Sel && kP16T1 + 8 * 9 * 4 <= kP16T2, "");
 
 __device__ __forceinline__ int shfl_i(int v, int src) { return __builtin_amdgcn_ds_bpermute(src << 2, v); }
 
 // first float of block (n, m), n < m
-__device__ __forceinline__ int p16_blk(int n, int m) { return ((n * (31 - n)) / 2 + m - n - 1) * 256; }
+template <int N>
+__device__ __forceinline__ int p16_blk(int n, int m) { return ((n * (2 * N - 1 - n)) / 2 + m - n - 1) * 256; }
 
 // G[(n, i)][(m, j)], n != m, from the triangular store (G is symmetric bit for bit)
+template <int N>
 __device__ __forceinline__ float p16_g(const float *Gt, int n, int i, int m, int j) {
     const bool lt = n < m;
     const int lo = lt ? n : m, hi = lt ? m : n, a = lt ? i : j, b = lt ? j : i;
-    return Gt[p16_blk(lo, hi) + a * 16 + b];
+    return Gt[p16_blk<N>(lo, hi) + a * 16 + b];
 }
 
 // leaf entry D[n][m] (n < m) for the entries ea of n and eb of m; on / om the current entries: ((g - u) - v) + w
@@ -69,29 +72,32 @@ __device__ __forceinline__ float p16_leaf(const float *blk, int ea, int eb, int 
 }
 
 // T_1[X][Y][i][j] of two level-1 groups X < Y (pairs of codebooks) for this lane's candidates i of X and j of Y
+template <int N>
 __device__ __forceinline__ float p16_t1(const float *Gt, const uint8_t *ent0, const uint8_t *pos1, int e, int X, int Y, int i, int j) {
     const unsigned pi = *reinterpret_cast<const uint16_t *>(pos1 + (X * 8 + i) * 2), pj = *reinterpret_cast<const uint16_t *>(pos1 + (Y * 8 + j) * 2);
     const int i0 = pi & 0xff, i1 = pi >> 8, j0 = pj & 0xff, j1 = pj >> 8;
     const int ea0 = ent0[(2 * X) * 8 + i0], ea1 = ent0[(2 * X + 1) * 8 + i1], eb0 = ent0[(2 * Y) * 8 + j0], eb1 = ent0[(2 * Y + 1) * 8 + j1];
     const int on0 = __builtin_amdgcn_readlane(e, 2 * X), on1 = __builtin_amdgcn_readlane(e, 2 * X + 1);
     const int om0 = __builtin_amdgcn_readlane(e, 2 * Y), om1 = __builtin_amdgcn_readlane(e, 2 * Y + 1);
-    const float d00 = p16_leaf(Gt + p16_blk(2 * X, 2 * Y), ea0, eb0, on0, om0);
-    const float d01 = p16_leaf(Gt + p16_blk(2 * X, 2 * Y + 1), ea0, eb1, on0, om1);
-    const float d10 = p16_leaf(Gt + p16_blk(2 * X + 1, 2 * Y), ea1, eb0, on1, om0);
-    const float d11 = p16_leaf(Gt + p16_blk(2 * X + 1, 2 * Y + 1), ea1, eb1, on1, om1);
+    const float d00 = p16_leaf(Gt + p16_blk<N>(2 * X, 2 * Y), ea0, eb0, on0, om0);
+    const float d01 = p16_leaf(Gt + p16_blk<N>(2 * X, 2 * Y + 1), ea0, eb1, on0, om1);
+    const float d10 = p16_leaf(Gt + p16_blk<N>(2 * X + 1, 2 * Y), ea1, eb0, on1, om0);
+    const float d11 = p16_leaf(Gt + p16_blk<N>(2 * X + 1, 2 * Y + 1), ea1, eb1, on1, om1);
     return ((d00 + d01) + d10) + d11;
 }
 
+template <int N>
 __global__ void __launch_bounds__(64 * kP16Waves)
 k_tf_pass16(Pass16Args a) {
-    constexpr int N = 16;
+    static_assert(N == 16 || N == 8, "");
+    constexpr int NK = N * 16, XS = NK / 64, NT = N * N / 64;      // rows of G, x.C slots per lane, Gram terms of E / R per lane
     extern __shared__ __attribute__((aligned(16))) float p16_smem[];
     float *Gt = p16_smem;                        // [120][16][16]
-    float *Gd = Gt + kP16Blocks * 256;           // [256] G[r][r]
-    float *Qs = Gd + 256;                        // [256]
+    float *Gd = Gt + p16_blocks<N>() * 256;      // [NK] G[r][r]
+    float *Qs = Gd + NK;                         // [NK]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    char *ws = reinterpret_cast<char *>(Qs + 256) + wave * kP16Scratch;
+    char *ws = reinterpret_cast<char *>(Qs + NK) + wave * kP16Scratch;
     uint8_t *ent0 = reinterpret_cast<uint8_t *>(ws + kP16Ent0), *pos1 = reinterpret_cast<uint8_t *>(ws + kP16Pos1);
     uint8_t *pos2 = reinterpret_cast<uint8_t *>(ws + kP16Pos2), *pos3 = reinterpret_cast<uint8_t *>(ws + kP16Pos3);
     float *S0 = reinterpret_cast<float *>(ws + kP16S0), *S1 = reinterpret_cast<float *>(ws + kP16S1);
@@ -107,12 +113,12 @@ k_tf_pass16(Pass16Args a) {
         for (int n = 0; n < N - 1; ++n)
             for (int m = n + 1; m < N; ++m, ++cnt) {
                 if ((cnt & (kP16Waves - 1)) != wave) continue;
-                const unsigned go = (((unsigned)(n * 16) + vrow) * 256u + (unsigned)(m * 16) + 4u * vpart) * 4u;
+                const unsigned go = (((unsigned)(n * 16) + vrow) * (unsigned)NK + (unsigned)(m * 16) + 4u * vpart) * 4u;
                 const unsigned d = (unsigned)(size_t)Gt + (unsigned)cnt * 1024u;
                 asm volatile("s_mov_b32 m0, %[d]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[vo], %[p]" : : [vo] "v"(go), [p] "s"(a.G), [d] "s"(d) : "memory");
             }
-        if (tid < 256) {
-            Gd[tid] = a.G[(size_t)tid * 256 + tid];
+        if (tid < NK) {
+            Gd[tid] = a.G[(size_t)tid * NK + tid];
             Qs[tid] = a.Q[tid];
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -122,37 +128,37 @@ k_tf_pass16(Pass16Args a) {
     const int q4 = lane >> 4, k16 = lane & 15;
     for (long b = (long)blockIdx.x * kP16Waves + wave; b < a.B; b += (long)gridDim.x * kP16Waves) {
         // the vector's inputs: its 256 x.C products (slot r of lane l: row 64 r + l), its indexes (lane n < 16), |x|^2
-        float xcv[4];
+        float xcv[XS];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) xcv[r] = a.XC[(size_t)b * 256 + 64 * r + lane];
+        for (int r = 0; r < XS; ++r) xcv[r] = a.XC[(size_t)b * NK + 64 * r + lane];
         int e = lane < N ? (int)a.idx[b * N + lane] & 15 : 0;
         const float xxb = a.xx[b];
         for (int pass = 0; pass < a.iters; ++pass) {
             // ---------------------------------------------------------------- E, R (the arithmetic of tf_er_wave)
             float E, Rv;
             {
-                float gt[4];
+                float gt[NT];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int m = q4 + 4 * j, m2 = k16;                     // term t = lane + 64 j = m * 16 + m2
+                for (int j = 0; j < NT; ++j) {
+                    const int t = lane + 64 * j, m = t / N, m2 = t % N;     // term t = m * N + m2
                     const int om = shfl_i(e, m), om2 = shfl_i(e, m2);
                     const bool dg = m == m2;
                     const float gd = Gd[m * 16 + om];
-                    const float go = p16_g(Gt, m, om, dg ? (m ^ 1) : m2, om2);   // (the diagonal lanes read a valid address and drop it)
+                    const float go = p16_g<N>(Gt, m, om, dg ? (m ^ 1) : m2, om2);   // (the diagonal lanes read a valid address and drop it)
                     gt[j] = dg ? gd : go;
                 }
                 // XC[o_m] in lane m: row m * 16 + o_m of the vector's products = slot m / 4 of lane (m * 16 + o_m) % 64
                 const int qrow = (lane < N ? lane : 0) * 16 + e;
                 float xt = 0.f;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
+                for (int r = 0; r < XS; ++r) {
                     const float v = shfl_f(xcv[r], qrow & 63);
                     xt = ((qrow >> 6) == r) ? v : xt;
                 }
                 xt = lane < N ? xt : 0.f;
                 float gp = gt[0];
 #pragma unroll
-                for (int j = 1; j < 4; ++j) gp = gp + gt[j];
+                for (int j = 1; j < NT; ++j) gp = gp + gt[j];
                 const float gsum = wave_sum_butterfly(gp), xsum = wave_sum_butterfly(xt);
                 E = (gsum - 2.0f * xsum) + xxb;
                 const int n = lane < N ? lane : 0;
@@ -168,7 +174,7 @@ k_tf_pass16(Pass16Args a) {
             }
             // ---------------------------------------------------------------- stage 0: four codebooks per round, lane = (n - 4 r, k)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int r = 0; r < N / 4; ++r) {
                 const int n = 4 * r + q4;
                 float t = 0.f;
                 bool started = false;
@@ -176,7 +182,7 @@ k_tf_pass16(Pass16Args a) {
                 for (int m = 0; m < N; ++m) {
                     const int om = __builtin_amdgcn_readlane(e, m);
                     const bool use = m != n;
-                    const float gv = p16_g(Gt, m, om, use ? n : (n ^ 1), k16);      // row (m, o_m), column (n, k); own codebook: read and dropped
+                    const float gv = p16_g<N>(Gt, m, om, use ? n : (n ^ 1), k16);      // row (m, o_m), column (n, k); own codebook: read and dropped
                     const float sum = t + gv;
                     t = use ? (started ? sum : gv) : t;
                     started = started || use;
@@ -208,10 +214,10 @@ k_tf_pass16(Pass16Args a) {
             wave_lds_fence();
             // ---------------------------------------------------------------- level 0: the eight sibling pairs of codebooks
             const int i8 = lane >> 3, j8 = lane & 7;
-            for (int g = 0; g < 8; ++g) {
+            for (int g = 0; g < N / 2; ++g) {
                 const int n = 2 * g, m = n + 1;
                 const int on = __builtin_amdgcn_readlane(e, n), om = __builtin_amdgcn_readlane(e, m);
-                const float d = p16_leaf(Gt + p16_blk(n, m), ent0[n * 8 + i8], ent0[m * 8 + j8], on, om);
+                const float d = p16_leaf(Gt + p16_blk<N>(n, m), ent0[n * 8 + i8], ent0[m * 8 + j8], on, om);
                 float sv[1] = {((S0[n * 8 + i8] + S0[m * 8 + j8]) - E) + 2.0f * d};
                 int sp[1] = {lane};
                 bool has;
@@ -226,9 +232,9 @@ k_tf_pass16(Pass16Args a) {
             }
             wave_lds_fence();
             // ---------------------------------------------------------------- level 1: the four sibling pairs of level-1 groups
-            for (int h = 0; h < 4; ++h) {
+            for (int h = 0; h < N / 4; ++h) {
                 const int X = 2 * h, Y = X + 1;
-                const float t = p16_t1(Gt, ent0, pos1, e, X, Y, i8, j8);
+                const float t = p16_t1<N>(Gt, ent0, pos1, e, X, Y, i8, j8);
                 float sv[1] = {((S1[X * 8 + i8] + S1[Y * 8 + j8]) - E) + 2.0f * t};
                 int sp[1] = {lane};
                 bool has;
@@ -245,7 +251,8 @@ k_tf_pass16(Pass16Args a) {
             // ---------------------------------------------------------------- level 2: the two sibling pairs of level-2 groups
             // candidates p = 4 lane + v: i = lane / 4 of the left list, j = 4 (lane % 4) + v of the right one
             const int i16 = lane >> 2, jb = 4 * (lane & 3);
-            for (int q = 0; q < 2; ++q) {
+            int win = 0;
+            for (int q = 0; q < N / 8; ++q) {
                 const int P = 2 * q, Q2 = P + 1;                  // level-2 groups; their halves are the level-1 groups 2P, 2P+1 / 2Q2, 2Q2+1
                 const unsigned pi = *reinterpret_cast<const uint16_t *>(pos2 + (P * 16 + i16) * 2);
                 const uint64_t pj = *reinterpret_cast<const uint64_t *>(pos2 + (Q2 * 16 + jb) * 2);      // four (j0, j1) pairs
@@ -253,7 +260,7 @@ k_tf_pass16(Pass16Args a) {
 #pragma unroll
                 for (int tb = 0; tb < 4; ++tb) {
                     const int aa = tb >> 1, cc = tb & 1;
-                    T1a[i8 * 9 + j8] = p16_t1(Gt, ent0, pos1, e, 2 * P + aa, 2 * Q2 + cc, i8, j8);
+                    T1a[i8 * 9 + j8] = p16_t1<N>(Gt, ent0, pos1, e, 2 * P + aa, 2 * Q2 + cc, i8, j8);
                     wave_lds_fence();
                     const int ri = (int)((pi >> (8 * aa)) & 0xffu);
 #pragma unroll
@@ -272,20 +279,30 @@ k_tf_pass16(Pass16Args a) {
                     sv[v] = ((sx + S2[Q2 * 16 + jb + v]) - E) + 2.0f * part[v];
                     sp[v] = 4 * lane + v;
                 }
-                bool has;
-                int dst, op;
-                float ov;
-                wave_select_set<4>(sv, sp, 16, 256, sel, has, dst, ov, op);
-                if (has) {
-                    pos3[(q * 16 + dst) * 2] = (uint8_t)(op >> 4);
-                    pos3[(q * 16 + dst) * 2 + 1] = (uint8_t)(op & 15);
-                    S3[q * 16 + dst] = ov;
+                if constexpr (N == 8) {
+                    // eight codebooks: these 256 are the whole vector's candidates -> the winner
+                    float bv = INFINITY;
+                    int bp = kBigPos;
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) lexmin(bv, bp, sv[v], sp[v]);
+                    wave_lexmin(bv, bp);
+                    win = __builtin_amdgcn_readfirstlane(bp);
+                    if (win > 255) win = 255;                      // only reachable with NaN keys
+                } else {
+                    bool has;
+                    int dst, op;
+                    float ov;
+                    wave_select_set<4>(sv, sp, 16, 256, sel, has, dst, ov, op);
+                    if (has) {
+                        pos3[(q * 16 + dst) * 2] = (uint8_t)(op >> 4);
+                        pos3[(q * 16 + dst) * 2 + 1] = (uint8_t)(op & 15);
+                        S3[q * 16 + dst] = ov;
+                    }
                 }
             }
             wave_lds_fence();
             // ---------------------------------------------------------------- level 3: the two groups of eight codebooks -> the winner
-            int win;
-            {
+            if constexpr (N == 16) {
                 const unsigned pi3 = *reinterpret_cast<const uint16_t *>(pos3 + i16 * 2);
                 const uint64_t pj3 = *reinterpret_cast<const uint64_t *>(pos3 + (16 + jb) * 2);
                 float part[4];
@@ -298,7 +315,7 @@ k_tf_pass16(Pass16Args a) {
 #pragma unroll
                     for (int tb = 0; tb < 4; ++tb) {
                         const int aa = tb >> 1, cc = tb & 1;
-                        T1a[i8 * 9 + j8] = p16_t1(Gt, ent0, pos1, e, 2 * xc + aa, 4 + 2 * yc + cc, i8, j8);
+                        T1a[i8 * 9 + j8] = p16_t1<N>(Gt, ent0, pos1, e, 2 * xc + aa, 4 + 2 * yc + cc, i8, j8);
                         wave_lds_fence();
                         const int ri = (int)((pa >> (8 * aa)) & 0xffu);
 #pragma unroll
@@ -335,8 +352,8 @@ k_tf_pass16(Pass16Args a) {
                 int en = 0;
                 if (lane < N) {
                     const int n = lane;
-                    int p = (n >> 3) ? (win & 15) : (win >> 4);                               // position in the level-3 list of group n / 8
-                    p = pos3[((n >> 3) * 16 + p) * 2 + ((n >> 2) & 1)];                       // -> level-2 list of group n / 4
+                    int p = (n >> (N == 16 ? 3 : 2)) ? (win & 15) : (win >> 4);               // position in the top list of the vector's half
+                    if constexpr (N == 16) p = pos3[((n >> 3) * 16 + p) * 2 + ((n >> 2) & 1)];   // -> level-2 list of group n / 4
                     p = pos2[((n >> 2) * 16 + p) * 2 + ((n >> 1) & 1)];                       // -> level-1 list of group n / 2
                     p = pos1[((n >> 1) * 8 + p) * 2 + (n & 1)];                               // -> level-0 list of codebook n
                     en = ent0[n * 8 + p];
