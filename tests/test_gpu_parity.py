@@ -298,7 +298,7 @@ def test_small_workspace_forces_chunks_same_codes():
     assert rc == _lib.MCQ_EWORKSPACE
 
 
-@pytest.mark.parametrize("name", ["trained_d64_b8_p2", "trained_d64_b4_p1", "synth_d32_k256_n1", "synth_d64_k256_n16",
+@pytest.mark.parametrize("name", ["trained_d64_b8_p2", "trained_d64_b4_p1", "trained_d64_b8_p1", "synth_d32_k256_n1", "synth_d64_k256_n16",
                                   "synth_d32_k16_n64", "config_a_d256_n4"])
 def test_fixed_point_skipping_gives_identical_codes(name):
     fx = fixtures.load(name)
@@ -312,6 +312,22 @@ def test_fixed_point_skipping_gives_identical_codes(name):
         assert torch.equal(ref, got), (name, it)
     q.skip_fixed_points = True
     assert torch.equal(q.encode(x[:77], 5), q.encode(x, 5)[:77])
+
+
+@pytest.mark.parametrize("D,N,B", [(37, 8, 1), (512, 8, 4097), (200, 8, 530), (37, 16, 1), (512, 16, 4097), (300, 16, 9)])
+def test_passes_from_the_lds_resident_gram_matrix_vs_oracle(D, N, B):
+    """k_tf_pass16<N>: 8 or 16 codebooks of 16 entries, every pass of the call in one launch (persistent workgroups, grid-stride
+    over the vectors: B = 1, a ragged tail, more vectors than one round of waves); the packed bytes come from the same launch"""
+    sd = gen.synthetic_state(900 + D + N, D, 16, N)
+    q = load_quantizer(sd, D, 16, N)
+    o = oracle_of(sd)
+    x = gen.make_gaussian(11 + D + B, B, D)
+    x[B // 2] = 0
+    xg = torch.from_numpy(x).cuda()
+    for it in (1, 3, 6):
+        got = q.encode(xg, it, as_bytes=False).cpu().numpy()
+        assert np.array_equal(got, o.compute_indexes(x, it)), (D, N, B, it)
+    assert np.array_equal(q.encode(xg, 2, as_bytes=True).cpu().numpy(), o.encode(x, 2, as_bytes=True))
 
 
 @pytest.mark.parametrize("D,K,N,B,it", [(1024, 16, 64, 48, 1), (768, 256, 32, 48, 1), (2048, 256, 8, 100, 2),
