@@ -878,6 +878,10 @@ def main():
             # BASELINE config E at its length: the trainer's DEFAULT schedule (10,000 + 10,000 iterations, quantization.py:581-583),
             # batches of 4,096 fresh Gaussian frames (tests/test_gpu_trainer_long.py checks what such a run converges to)
             from quantization_amd import QuantizerTrainer
+            import gc
+            gc.collect()
+            gc.freeze()         # (the step is host-bound: a generation-2 collection over everything this process has built costs it 5 %)
+            torch.cuda.empty_cache()
             random.seed(0)
             torch.manual_seed(0)
             tr = QuantizerTrainer(dim=D, bytes_per_frame=N, device=dev)
@@ -894,7 +898,9 @@ def main():
             out["trainer_step"]["config_e"] = {"steps": nsteps, "trainer_total_s": round(tot, 2), "ms_per_step": round(tot / nsteps * 1e3, 4),
                                                "frames_per_s": round(nsteps * 4096 / tot, 1),
                                                "note": "QuantizerTrainer(dim=512, bytes_per_frame=8) with its default 10,000 + 10,000 iterations "
-                                                       "on one GPU, 4,096 frames per step, frame generation included"}
+                                                       "on one GPU, 4,096 frames per step, frame generation included; gc.freeze() before the leg "
+                                                       "(the step is host-bound, and Python's generation-2 collections over everything the earlier legs "
+                                                       "built cost it 5 %: a stand-alone script measures the same as this, tools/exp_config_e_after_rccl.py)"}
         except Exception as e:      # noqa: BLE001  (an optional leg: the headline line must still come out)
             out.setdefault("trainer_step", {})["error"] = f"{type(e).__name__}: {e}"[:300]
     if world == 1 and not args.no_cpu_baseline:
