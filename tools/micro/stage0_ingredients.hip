@@ -111,6 +111,58 @@ __global__ void __launch_bounds__(256) kl(const char *G, const unsigned long lon
     }
 }
 
+// Variants of HOW the x.C segment reaches the wave (everything else as "+ selection (everything)"):
+//   MODE 0  plain: requested first (the shipped order)          MODE 1  requested AFTER the rows
+//   MODE 2  by LDS-DMA into the wave's own 1 KB of LDS          MODE 3  by a FIFTH wave of the workgroup for the four vectors (LDS, barrier)
+template <int MODE>
+__global__ void __launch_bounds__(MODE == 3 ? 320 : 256) kx(const char *G, const unsigned long long *idx, const float *xc, const float *q, uint8_t *ent, float *S) {
+    __shared__ mcq::u64 sel[4][mcq::kSelectLdsU64];
+    __shared__ __attribute__((aligned(16))) float xl[4][256];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned n = blockIdx.x & 7;
+    if (MODE == 3 && wave == 4) {      // the loader: four 1 KB segments, then the barrier the row waves meet it at
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const unsigned b = (blockIdx.x >> 3) * 4 + w;
+            const f4 v = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(xc + ((size_t)b * 2048 + n * 256 + 4 * lane)));
+            *reinterpret_cast<f4 *>(&xl[w][4 * lane]) = v;
+        }
+        __syncthreads();
+        return;
+    }
+    const unsigned b = (blockIdx.x >> 3) * 4 + wave;
+    f4 xv = {0, 0, 0, 0};
+    const float *xp = xc + ((size_t)b * 2048 + n * 256 + 4 * lane);
+    if (MODE == 0) xv = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(xp));
+    if (MODE == 2) {
+        const unsigned d = (unsigned)(size_t)&xl[wave][0];
+        const float *base = xc + ((size_t)b * 2048 + n * 256);
+        const unsigned vo = lane * 16;
+        asm volatile("s_mov_b32 m0, %[d]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[vo], %[p]" : : [vo] "v"(vo), [p] "s"(base), [d] "s"(d) : "memory");
+    }
+    const f4 qv = *reinterpret_cast<const f4 *>(q + n * 256 + 4 * lane);
+    const unsigned long long iw = idx[__builtin_amdgcn_readfirstlane((int)b)];
+    f4 v[7];
+#pragma unroll
+    for (int u = 0; u < 7; ++u) {
+        const unsigned m = u < n ? u : u + 1;
+        const unsigned row = m * 256 + (unsigned)((iw >> (8 * m)) & 0xff);
+        v[u] = *reinterpret_cast<const f4 *>(G + (size_t)row * 8192 + n * 1024 + lane * 16);
+    }
+    if (MODE == 1) xv = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(xp));
+    f4 acc = v[0];
+#pragma unroll
+    for (int u = 1; u < 7; ++u) acc += v[u];
+    if (MODE == 2) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); xv = *reinterpret_cast<const f4 *>(&xl[wave][4 * lane]); }
+    if (MODE == 3) { __syncthreads(); xv = *reinterpret_cast<const f4 *>(&xl[wave][4 * lane]); }
+    acc = (qv + 2.0f * (acc - xv));
+    float sv[4] = {acc[0], acc[1], acc[2], acc[3]};
+    int sp[4] = {4 * lane, 4 * lane + 1, 4 * lane + 2, 4 * lane + 3};
+    float ov; int op, dst; bool has;
+    mcq::wave_select_set<4>(sv, sp, 16, 256, sel[wave], has, dst, ov, op);
+    if (has) { ent[((size_t)b * 8 + n) * 16 + dst] = (uint8_t)op; S[((size_t)b * 8 + n) * 16 + dst] = ov; }
+}
+
 int main() {
     const unsigned B = 65536;
     char *G; float *out, *xc, *q, *S; unsigned long long *idx; uint8_t *ent;
@@ -167,6 +219,18 @@ int main() {
         float ms; (void)hipEventElapsedTime(&ms, e0, e1);                                                         \
         if (rep == 2) printf("%-28s %.3f ms  %.1f TB/s of row segments\n", name, ms, blocks * 4.0 * 7 * 1024 / ms / 1e9); \
     }
+#define RUNX(name, M)                                                                                             \
+    for (int rep = 0; rep < 3; ++rep) {                                                                           \
+        (void)hipEventRecord(e0);                                                                                 \
+        kx<M><<<blocks, M == 3 ? 320 : 256>>>(G, idx, xc, q, ent, S);                                             \
+        (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);                                                  \
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1);                                                         \
+        if (rep == 2) printf("%-28s %.3f ms  %.1f TB/s of row segments\n", name, ms, blocks * 4.0 * 7 * 1024 / ms / 1e9); \
+    }
+    RUNX("x.C first (shipped order)", 0)
+    RUNX("x.C after the rows", 1)
+    RUNX("x.C by LDS-DMA", 2)
+    RUNX("x.C by a fifth wave", 3)
     RUNL("loop V=1, no prefetch", 1, 0)
     RUNL("loop V=2, x.C 1 ahead", 2, 1)
     RUNL("loop V=4, x.C 1 ahead", 4, 1)
