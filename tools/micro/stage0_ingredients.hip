@@ -22,6 +22,7 @@ __global__ void __launch_bounds__(256) k(const char *G, const unsigned long long
     // XC: 1 nontemporal from the 0.5 GB array (HBM), 2 the same with a plain load, 3 from a 16 MB window of it (cache resident)
     if (XC == 1) xv = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(xc + ((size_t)b * 2048 + n * 256 + 4 * lane)));
     if (XC == 2) xv = *reinterpret_cast<const f4 *>(xc + ((size_t)b * 2048 + n * 256 + 4 * lane));
+    if (XC == 10) xv = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(xc + (((size_t)n * 65536 + b) * 256 + 4 * lane)));      // codebook-major x.C: an XCD streams ONE contiguous 64 MB region
     if (XC == 9) xv = *reinterpret_cast<const f4 *>(xc + ((size_t)(b & 2047) * 2048 + n * 256 + 4 * lane));      // 16 MB window, plain load: L2 hits
     if (XC >= 3 && XC < 9) xv = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(xc + ((size_t)(b & ((1u << XC) * 256u - 1u)) * 2048 + n * 256 + 4 * lane)));      // window of 2^XC * 2 MB
     if (Q) qv = *reinterpret_cast<const f4 *>(q + n * 256 + 4 * lane);
@@ -203,6 +204,7 @@ int main() {
     RUN("delay 20, x.C from HBM", true, 1, true, true, 20)
     RUN("delay 40, no x.C", true, 0, true, true, 40)
     RUN("delay 40, x.C from HBM", true, 1, true, true, 40)
+    RUN("sel, x.C codebook-major (HBM)", true, 10, true, true, 1)
     RUN("sel, x.C 16 MB window, L2 hits", true, 9, true, true, 1)
     RUN("selection, x.C window 16 MB", true, 3, true, true, 1)
     RUN("selection, x.C window 32 MB", true, 4, true, true, 1)
