@@ -594,12 +594,19 @@ int run_encode_t(const float *x, long B, const void *prepared, float lscale, int
             // persistent workgroups that hold the Gram matrix in LDS (mcq_pass16_kernels.h); not under the profiler, whose
             // categories are the separate launches
             if (K == 16 && (N == 16 || N == 8) && iters > 0 && !skip && prof == nullptr && pass16_enabled()) {
-                static hipError_t attr16 = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tf_pass16<16>),
-                                                               hipFuncAttributeMaxDynamicSharedMemorySize, p16_lds_bytes<16>());
-                static hipError_t attr8 = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tf_pass16<8>),
-                                                              hipFuncAttributeMaxDynamicSharedMemorySize, p16_lds_bytes<8>());
-                if (attr16 != hipSuccess) return (int)attr16;
-                if (attr8 != hipSuccess) return (int)attr8;
+                // (the dynamic LDS above 64 KB has to be allowed once per DEVICE: a process may drive several)
+                static bool allowed16[64] = {};
+                int dev = 0;
+                if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 63;
+                if (!allowed16[dev] || dev == 63) {
+                    hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tf_pass16<16>),
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, p16_lds_bytes<16>());
+                    if (attr == hipSuccess)
+                        attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tf_pass16<8>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, p16_lds_bytes<8>());
+                    if (attr != hipSuccess) return (int)attr;
+                    allowed16[dev] = true;
+                }
                 Pass16Args a;
                 a.G = P.G; a.XC = w.XC; a.xx = w.xx; a.Q = P.Q; a.idx = w.idx; a.B = Bc; a.iters = iters;
                 const bool direct_out = pack == 1;
