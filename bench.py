@@ -895,6 +895,7 @@ def main():
                 nsteps += 1
             torch.cuda.synchronize()
             tot = time.perf_counter() - t5
+            gc.unfreeze()
             out["trainer_step"]["config_e"] = {"steps": nsteps, "trainer_total_s": round(tot, 2), "ms_per_step": round(tot / nsteps * 1e3, 4),
                                                "frames_per_s": round(nsteps * 4096 / tot, 1),
                                                "note": "QuantizerTrainer(dim=512, bytes_per_frame=8) with its default 10,000 + 10,000 iterations "
